@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HMC leapfrog steps/s + achieved HBM GB/s of the G sweep.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one leapfrog step of the hot path (hmc.py:117-152): momentum update with the
+gradient 2 Aw^T r + alpha grad R, position update with clamp-and-reflect, and the forward
+product Aw x for the next step -- ONE fused sweep of the resident kernel matrix -- plus the
+per-trajectory work that surrounds it (momentum draw and upload, the extra adjoint-only
+sweep, the Metropolis test).  Workload at N=1: BASELINE.json configs[1] (uniformgrid
+100x100x50 prisms, N=10^4 observations, dense G = 40 GB fp64 resident in HBM, Damping).
+With N>1 every rank runs an independent chain on its own GPU against its own copy of G
+(seed = 100 + rank: the reference's `mpiexec -n K` model, hmc.py:367-369): no data-path
+collective, weak scaling; value = steps of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (nx, ny, nz, anomaly block (ix0, ix1, iy0, iy1, iz0, iz1))  -- SURVEY 8d
+    "c2_uniform_100x100x50": (100, 100, 50, (40, 59, 40, 59, 10, 24)),
+    "c1_uniform_20x30x10": (20, 30, 10, (7, 10, 10, 17, 2, 4)),
+}
+
+
+def make_problem(name):
+    from gravinv3dhmc_amd import mesher
+    nx, ny, nz, blk = WORKLOADS[name]
+    mesh = mesher.PrismMesh((0, 100.0 * nx, 0, 100.0 * ny, 0, 100.0 * nz), (100, 100, 100))
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 100.0 * ny, ny),
+                                             np.linspace(0, 100.0 * nx, nx))]
+    zp = np.zeros_like(xp)
+    rho = np.zeros((nz, ny, nx))
+    rho[blk[4]:blk[5] + 1, blk[2]:blk[3] + 1, blk[0]:blk[1] + 1] = 1.0
+    return mesh, xp, yp, zp, rho.ravel()
+
+
+def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=12.0):
+    """The CPU restatement (oracle, kind "port") on a column-subsampled copy of the same
+    workload: same N, every k-th cell, all host cores via OpenMP; steps/s is scaled by the
+    subsampling factor (cost per step is linear in the number of cells)."""
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    M = mesh.size
+    k = max(1, M // 10000)
+    b = mesh.cell_bounds()[::k]
+    t0 = time.time()
+    K = oracle.prism_gz_kernel(xp, yp, zp, b)
+    Aw, wm = oracle.col_weight(K)
+    t_build = time.time() - t0
+    del K
+    P = oracle.Problem(Aw, dobs, 0.001 * wm, "Damping", 1.0, 0.01, wm=wm)
+    Ms = wm.size
+    rng = np.random.default_rng(1)
+    x = 0.001 * wm
+    L, steps, t_run = 10, 0, 0.0
+    while t_run < target_s and steps < 400:
+        p0 = rng.normal(size=Ms) * 0.001
+        t1 = time.time()
+        x, acc, out, _ = P.leapfrog(x, p0, 0.01, L, 0.0 * wm, 1.0 * wm, 0.5)
+        t_run += time.time() - t1
+        steps += L
+    sps_sample = steps / t_run
+    return {"value": sps_sample * Ms / M, "unit": "leapfrog steps/s", "cores": cores,
+            "kind": "port",
+            "sample": "same N=%d observations, every %d-th cell (%d of %d); %d steps in %.1f s "
+                      "(%.2f steps/s on the sample, scaled by %d/%d); kernel build + weighting "
+                      "of the sample %.1f s" % (xp.size, k, Ms, M, steps, t_run, sps_sample, Ms, M,
+                                                t_build)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2_uniform_100x100x50", choices=list(WORKLOADS))
+    ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        # control plane only (barrier + max of the elapsed time): the chains are independent,
+        # so no tensor of the data path ever crosses ranks.  gloo on CPU tensors keeps
+        # torch's own HIP runtime out of the process.
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import gravinv3dhmc_amd as g
+    mesh, xp, yp, zp, rho = make_problem(args.workload)
+    N, M = xp.size, mesh.size
+    eng = g.Engine(N, M, device=local_rank)
+    info = eng.device_info()
+    t0 = time.time()
+    eng.set_obs(xp, yp, zp)
+    eng.set_cells(mesh.cell_bounds(), 0)
+    eng.build_G()
+    eng.synchronize()
+    t_build = time.time() - t0
+    d_true = eng.forward(rho)                          # noise-free synthetic data, unweighted G
+    t0 = time.time()
+    wm = eng.weight(0.5)
+    t_weight = time.time() - t0
+    dobs = d_true + np.random.default_rng(0).normal(0.0, 0.02 * d_true.max(), N)
+    eng.set_data(dobs)
+    eng.set_reg("Damping", 1.0, 0.01, mesh.shape, 0.001 * wm)
+    low, high = 0.0 * wm, 1.0 * wm
+    eng.chain_init(0.001 * wm, low, high)
+
+    # the reference's RNG stream (legacy global generator), one chain per rank
+    np.random.seed(100 + rank)
+    Sigma, dt, L = 0.001, 0.01, args.traj_len
+
+    def draw(nsteps):
+        return np.random.randn(M) * Sigma, np.random.rand(), nsteps
+
+    def run(total_steps):
+        """Trajectories of L steps until total_steps leapfrog steps are done; the momentum
+        of the next trajectory is drawn on the host while the GPU runs the current one."""
+        done, naccept, ntraj = 0, 0, 0
+        nxt = draw(min(L, total_steps))
+        while done < total_steps:
+            p0, u, n = nxt
+            res = {}
+            th = threading.Thread(target=lambda: res.update(r=eng.chain_trajectory(p0, dt, n, u)))
+            th.start()
+            done += n
+            if done < total_steps:
+                nxt = draw(min(L, total_steps - done))
+            th.join()
+            naccept += int(res["r"][0])
+            ntraj += 1
+        return naccept, ntraj
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    eng.synchronize()
+    barrier()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    naccept, ntraj = run(args.steps)
+    eng.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        sweep_ms = prof["sweep_ms"] / max(1, prof["sweeps"])
+        bytes_sweep = prof["bytes_per_sweep"]          # N*M*8: one read of G
+        achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
+        line = {
+            "metric": "HMC leapfrog steps/sec + G*rho achieved HBM GB/s",
+            "value": args.steps * world / elapsed,
+            "unit": "leapfrog steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "N_obs": int(N), "M_cells": int(M),
+                       "G_bytes": int(N) * int(M) * 8, "regulariser": "Damping",
+                       "chains_per_gpu": 1, "traj_len": L, "trajectories": ntraj,
+                       "accepted": naccept, "parallelism": "chain-parallel x%d (no collective)" % world,
+                       "device": info["name"], "cus": info["cus"],
+                       "G_build_s": round(t_build, 3), "weighting_s": round(t_weight, 3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "sweep_kernel (fused adjoint+update+forward, one read of G)",
+                         "launches": prof["sweeps"], "avg_ms": sweep_ms,
+                         "algorithmic_bytes_per_launch": bytes_sweep,
+                         "reference_formulation_equiv_GBps":
+                             2 * bytes_sweep * args.steps / elapsed / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(mesh, xp, yp, zp, dobs)
+            except Exception as e:  # the baseline is a reported extra, never the product path
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(line))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,861 @@
+// libgravhmc: host side of the C-ABI declared in include/gravhmc.h (HIP, gfx950 only).
+// One context = one GPU + one stream + one inversion problem resident in HBM.
+#include "../../include/gravhmc.h"
+#include "kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ghk;
+
+static thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct gh_ctx {
+    int device = 0;
+    int64_t N = 0, M = 0, ld = 0;
+    int cus = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+
+    // geometry / kernel
+    double *obs[3] = {nullptr, nullptr, nullptr};
+    double *bounds = nullptr;
+    int cell_kind = -1;
+    double ratio = 1.6;
+    bool have_obs = false, have_cells = false, have_G = false, weighted = false;
+    double *G = nullptr;
+    int64_t warn_cells = 0, leaves = 0;
+
+    // sweep configuration
+    int TW = 0, EPT2 = 0;
+    int n_teams = 0, grid = 0;
+    int64_t cols_per_team = 0;
+    size_t lds_bytes = 0;
+
+    // problem vectors
+    double *dobs_c = nullptr, *gfix = nullptr, *mwapr = nullptr, *wm = nullptr, *wm2 = nullptr;
+    double *low = nullptr, *high = nullptr;
+    bool have_data = false, have_fix = false, have_reg = false;
+    int reg_kind = 0, shape[3] = {1, 1, 1};
+    double alpha = 1.0, beta = 0.01;
+
+    // chain state (at x_cur) and work buffers
+    double *x_cur = nullptr, *r_cur = nullptr, *greg_cur = nullptr, *d_cur = nullptr;
+    double *xw[2] = {nullptr, nullptr}, *pw[2] = {nullptr, nullptr};
+    double *r_w = nullptr, *greg_w = nullptr, *d_w = nullptr;
+    double *slab = nullptr, *dpart = nullptr, *regpart = nullptr, *pp_part = nullptr,
+           *pp0_part = nullptr, *scal = nullptr;
+    double *tmpM = nullptr, *tmpN = nullptr;
+    int n_dpart = 0, n_regpart = 0, n_pp0 = 0;
+    double *h_scal = nullptr;  // pinned: 8 scalars + partial sums
+    size_t h_scal_n = 0;
+    bool chain_ready = false;
+    double U_cur[3] = {0, 0, 0};
+
+    // profiling of the sweeps
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_ms_acc = 0.0;
+    int64_t prof_launches = 0;
+};
+
+static int fail(gh_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), e_ == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP,         \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                        __LINE__);                                                          \
+    } while (0)
+
+template <typename T>
+static int dalloc(gh_ctx *c, T **out, size_t count, bool zero = true)
+{
+    if (*out) return GH_OK;
+    void *p = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(c, hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    if (zero) HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    *out = static_cast<T *>(p);
+    return GH_OK;
+}
+
+#define TRY(x)                 \
+    do {                       \
+        int rc_ = (x);         \
+        if (rc_ != GH_OK) return rc_; \
+    } while (0)
+
+static int h2d(gh_ctx *c, double *dst, const double *src, size_t n)
+{
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller-owned pageable memory: do not outlive the call
+    return GH_OK;
+}
+
+static int d2h(gh_ctx *c, double *dst, const double *src, size_t n)
+{
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+// ----------------------------------------------------------------- sweep dispatch
+
+typedef void (*sweep_fn)(SweepArgs);
+typedef void (*weight_fn)(double *, int64_t, int64_t, int64_t, int, double, double *);
+
+template <int TW>
+static sweep_fn pick_sweep(int ept2)
+{
+    switch (ept2) {
+    case 1: return sweep_kernel<TW, 1>;
+    case 2: return sweep_kernel<TW, 2>;
+    case 3: return sweep_kernel<TW, 3>;
+    case 4: return sweep_kernel<TW, 4>;
+    case 5: return sweep_kernel<TW, 5>;
+    case 6: return sweep_kernel<TW, 6>;
+    case 8: return sweep_kernel<TW, 8>;
+    }
+    return nullptr;
+}
+
+template <int TW>
+static weight_fn pick_weight(int ept2)
+{
+    switch (ept2) {
+    case 1: return weight_kernel<TW, 1>;
+    case 2: return weight_kernel<TW, 2>;
+    case 3: return weight_kernel<TW, 3>;
+    case 4: return weight_kernel<TW, 4>;
+    case 5: return weight_kernel<TW, 5>;
+    case 6: return weight_kernel<TW, 6>;
+    case 8: return weight_kernel<TW, 8>;
+    }
+    return nullptr;
+}
+
+static sweep_fn sweep_for(const gh_ctx *c)
+{
+    if (c->TW == 1) return pick_sweep<1>(c->EPT2);
+    if (c->TW == 4) return pick_sweep<4>(c->EPT2);
+    return pick_sweep<16>(c->EPT2);
+}
+
+static weight_fn weight_for(const gh_ctx *c)
+{
+    if (c->TW == 1) return pick_weight<1>(c->EPT2);
+    if (c->TW == 4) return pick_weight<4>(c->EPT2);
+    return pick_weight<16>(c->EPT2);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Choose team width / registers per thread from ld, and the column partition from M.
+static int configure_sweep(gh_ctx *c)
+{
+    const int64_t ld = c->ld;
+    int tw, per;  // rows one unit of EPT2 covers = tw*64*2
+    if (ld <= 1024) tw = 1;
+    else if (ld <= 4096) tw = 4;
+    else if (ld <= 16384) tw = 16;
+    else
+        return fail(c, GH_ERR_UNSUPPORTED,
+                    "N = %lld: more than 16384 observations per device needs row panels "
+                    "(shard rows across GPUs)", (long long)c->N);
+    per = tw * 128;
+    int e = (int)((ld + per - 1) / per);
+    if (e == 7) e = 8;
+    c->TW = tw;
+    c->EPT2 = e;
+    const int wg_teams = (tw == 1) ? 4 : 1;
+    // resident workgroups per CU we size the grid for (register/LDS budget of the kernel)
+    int wg_per_cu = (tw == 16) ? 1 : 4;
+    wg_per_cu = env_int("GRAVHMC_WG_PER_CU", wg_per_cu);
+    int64_t max_teams = (int64_t)c->cus * wg_per_cu * wg_teams;
+    int64_t min_cols = env_int("GRAVHMC_MIN_COLS", tw == 1 ? 2 : 1);
+    int64_t cpt = (c->M + max_teams - 1) / max_teams;
+    if (cpt < min_cols) cpt = min_cols;
+    c->cols_per_team = cpt;
+    c->n_teams = (int)((c->M + cpt - 1) / cpt);
+    c->grid = (c->n_teams + wg_teams - 1) / wg_teams;
+    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : ld + 2 * tw) * sizeof(double);
+    if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
+    sweep_fn f = sweep_for(c);
+    if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    return GH_OK;
+}
+
+static int launch_sweep(gh_ctx *c, SweepArgs &a)
+{
+    a.G = c->G;
+    a.ld = c->ld;
+    a.M = c->M;
+    a.cols_per_team = c->cols_per_team;
+    a.n_teams = c->n_teams;
+    const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
+    sweep_fn f = sweep_for(c);
+    bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), c->lds_bytes, c->stream, a);
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
+    if (c->prof) c->prof_launches += 1;
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+// slab -> d ; regulariser ; residual + scalars.  x: position the forward belongs to.
+static int finalize(gh_ctx *c, const double *x, double *d_out, double *r_out, double *greg_out,
+                    double *scal_out)
+{
+    reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(
+        c->slab, c->grid, c->ld, c->N, c->have_fix ? c->gfix : nullptr, d_out, c->dpart);
+    RegArgs ra;
+    ra.kind = c->reg_kind;
+    ra.M = c->M;
+    ra.nz = c->shape[0];
+    ra.ny = c->shape[1];
+    ra.nx = c->shape[2];
+    ra.alpha = c->alpha;
+    ra.beta = c->beta;
+    ra.x = x;
+    ra.mwapr = c->mwapr;
+    ra.wm2 = c->wm2;
+    ra.greg = greg_out;
+    ra.regpart = c->regpart;
+    reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+    FinishArgs fa;
+    fa.N = c->N;
+    fa.ld = c->ld;
+    fa.n_dpart = c->n_dpart;
+    fa.n_regpart = c->n_regpart;
+    fa.d = d_out;
+    fa.gfix = c->have_fix ? c->gfix : nullptr;
+    fa.dobs_c = c->dobs_c;
+    fa.dpart = c->dpart;
+    fa.regpart = c->regpart;
+    fa.alpha = c->alpha;
+    fa.r = r_out;
+    fa.scal = scal_out;
+    finish_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(fa);
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+// forward sweep of x (device) + finalize
+static int eval_forward(gh_ctx *c, const double *x, double *d_out, double *r_out,
+                        double *greg_out, double *scal_out)
+{
+    SweepArgs a{};
+    a.mode = SW_FWD;
+    a.x_in = x;
+    a.slab = c->slab;
+    TRY(launch_sweep(c, a));
+    return finalize(c, x, d_out, r_out, greg_out, scal_out);
+}
+
+static int ensure_work(gh_ctx *c)
+{
+    const size_t M = (size_t)c->M, ld = (size_t)c->ld;
+    TRY(dalloc(c, &c->x_cur, M));
+    TRY(dalloc(c, &c->r_cur, ld));
+    TRY(dalloc(c, &c->greg_cur, M));
+    TRY(dalloc(c, &c->d_cur, ld));
+    for (int i = 0; i < 2; ++i) {
+        TRY(dalloc(c, &c->xw[i], M));
+        TRY(dalloc(c, &c->pw[i], M));
+    }
+    TRY(dalloc(c, &c->r_w, ld));
+    TRY(dalloc(c, &c->greg_w, M));
+    TRY(dalloc(c, &c->d_w, ld));
+    TRY(dalloc(c, &c->slab, (size_t)c->grid * ld));
+    c->n_dpart = (int)((c->ld + 31) / 32);
+    c->n_regpart = (int)((c->M + 255) / 256);
+    c->n_pp0 = (int)std::min<int64_t>(1024, (c->M + 255) / 256);
+    TRY(dalloc(c, &c->dpart, (size_t)c->n_dpart));
+    TRY(dalloc(c, &c->regpart, (size_t)c->n_regpart));
+    TRY(dalloc(c, &c->pp_part, (size_t)c->n_teams));
+    TRY(dalloc(c, &c->pp0_part, (size_t)c->n_pp0));
+    TRY(dalloc(c, &c->scal, 16));
+    TRY(dalloc(c, &c->tmpM, M));
+    TRY(dalloc(c, &c->tmpN, ld));
+    TRY(dalloc(c, &c->low, M));
+    TRY(dalloc(c, &c->high, M));
+    if (!c->mwapr) {
+        TRY(dalloc(c, &c->mwapr, M));
+    }
+    if (!c->wm2) {
+        TRY(dalloc(c, &c->wm2, M));
+    }
+    if (!c->h_scal) {
+        c->h_scal_n = 16 + (size_t)c->n_teams + (size_t)c->n_pp0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_scal, c->h_scal_n * sizeof(double)));
+    }
+    return GH_OK;
+}
+
+static int need(gh_ctx *c, bool cond, const char *what)
+{
+    if (!cond) return fail(c, GH_ERR_ARG, "%s", what);
+    return GH_OK;
+}
+
+// ------------------------------------------------------------------------- C-ABI
+
+extern "C" {
+
+const char *gh_last_error(const gh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int gh_create(gh_ctx **out, int device, int64_t N, int64_t M)
+{
+    if (!out || N <= 0 || M <= 0) return fail(nullptr, GH_ERR_ARG, "gh_create: bad arguments");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, GH_ERR_HIP, "gh_create: no HIP device available (%s); libgravhmc has no CPU path",
+                    hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, GH_ERR_ARG, "gh_create: device %d out of range (%d devices)", device, ndev);
+    gh_ctx *c = new gh_ctx();
+    c->device = device;
+    c->N = N;
+    c->M = M;
+    c->ld = (N + 15) / 16 * 16;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        int rc = fail(nullptr, GH_ERR_HIP, "gh_create: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    c->cus = prop.multiProcessorCount;
+    int rc = configure_sweep(c);
+    if (rc != GH_OK) {
+        g_create_error = c->err;
+        hipStreamDestroy(c->stream);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return GH_OK;
+}
+
+void gh_destroy(gh_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) hipFree(p);
+    if (c->h_scal) hipHostFree(c->h_scal);
+    for (hipEvent_t ev : c->ev) hipEventDestroy(ev);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gh_device_info(const gh_ctx *c, char *name256, int *cus, int64_t *mem_bytes)
+{
+    if (!c) return GH_ERR_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return GH_ERR_HIP;
+    if (name256) {
+        strncpy(name256, prop.name, 255);
+        name256[255] = 0;
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
+    return GH_OK;
+}
+
+int gh_synchronize(gh_ctx *c)
+{
+    if (!c) return GH_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+int gh_set_obs(gh_ctx *c, const double *a, const double *b, const double *cc)
+{
+    if (!c || !a || !b || !cc) return fail(c, GH_ERR_ARG, "gh_set_obs: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const double *src[3] = {a, b, cc};
+    for (int i = 0; i < 3; ++i) {
+        TRY(dalloc(c, &c->obs[i], (size_t)c->N));
+        TRY(h2d(c, c->obs[i], src[i], (size_t)c->N));
+    }
+    c->have_obs = true;
+    return GH_OK;
+}
+
+int gh_set_cells(gh_ctx *c, const double *bounds6, int kind, double ratio)
+{
+    if (!c || !bounds6) return fail(c, GH_ERR_ARG, "gh_set_cells: null pointer");
+    if (kind != GH_CELL_PRISM && kind != GH_CELL_TESSEROID)
+        return fail(c, GH_ERR_ARG, "gh_set_cells: kind must be 0 (prism) or 1 (tesseroid)");
+    if (kind == GH_CELL_TESSEROID && !(ratio > 0))
+        return fail(c, GH_ERR_ARG, "Invalid ratio %g. Must be > 0.", ratio);
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(dalloc(c, &c->bounds, (size_t)c->M * 6));
+    TRY(h2d(c, c->bounds, bounds6, (size_t)c->M * 6));
+    c->cell_kind = kind;
+    c->ratio = ratio;
+    c->have_cells = true;
+    return GH_OK;
+}
+
+int gh_build_G(gh_ctx *c)
+{
+    if (!c) return GH_ERR_ARG;
+    TRY(need(c, c->have_obs && c->have_cells, "gh_build_G: call gh_set_obs and gh_set_cells first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(dalloc(c, &c->G, (size_t)c->ld * (size_t)c->M, false));
+    const int64_t total = c->ld * c->M;
+    c->warn_cells = 0;
+    c->leaves = 0;
+    if (c->cell_kind == GH_CELL_PRISM) {
+        const int64_t blocks = (total + 255) / 256;
+        if (blocks > 0x7fffffffLL) return fail(c, GH_ERR_UNSUPPORTED, "gh_build_G: matrix too large");
+        prism_gz_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(
+            c->obs[0], c->obs[1], c->obs[2], c->bounds, c->N, c->M, c->ld, c->G);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        double *conv = nullptr;
+        int *err_cell = nullptr;
+        TessStats *stats = nullptr;
+        HIPCHK(c, hipMalloc((void **)&conv, sizeof(double) * 4 * (size_t)c->N));
+        HIPCHK(c, hipMalloc((void **)&err_cell, sizeof(int) * (size_t)c->M));
+        HIPCHK(c, hipMalloc((void **)&stats, sizeof(TessStats)));
+        HIPCHK(c, hipMemsetAsync(err_cell, 0, sizeof(int) * (size_t)c->M, c->stream));
+        HIPCHK(c, hipMemsetAsync(stats, 0, sizeof(TessStats), c->stream));
+        const int64_t N = c->N;
+        tess_convert_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream>>>(
+            c->obs[0], c->obs[1], c->obs[2], N, conv, conv + N, conv + 2 * N, conv + 3 * N);
+        const int64_t blocks = (total + 63) / 64;
+        if (blocks > 0x7fffffffLL) return fail(c, GH_ERR_UNSUPPORTED, "gh_build_G: matrix too large");
+        tess_gz_kernel<<<dim3((unsigned)blocks), dim3(64), 0, c->stream>>>(
+            conv, conv + N, conv + 2 * N, conv + 3 * N, c->bounds, N, c->M, c->ld, c->ratio, c->G,
+            err_cell, stats);
+        HIPCHK(c, hipGetLastError());
+        std::vector<int> herr((size_t)c->M);
+        TessStats hs;
+        HIPCHK(c, hipMemcpyAsync(herr.data(), err_cell, sizeof(int) * (size_t)c->M,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&hs, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(conv);
+        hipFree(err_cell);
+        hipFree(stats);
+        for (int v : herr)
+            if (v != 0) c->warn_cells += 1;
+        c->leaves = (int64_t)hs.leaves;
+        if (hs.overflow) return fail(c, GH_ERR_OVERFLOW, "tesseroid stack overflow (> %d entries)", TESS_STACK);
+    }
+    c->have_G = true;
+    c->weighted = false;
+    c->chain_ready = false;
+    return GH_OK;
+}
+
+int gh_kernel_stats(const gh_ctx *c, int64_t *warn_cells, int64_t *leaves)
+{
+    if (!c) return GH_ERR_ARG;
+    if (warn_cells) *warn_cells = c->warn_cells;
+    if (leaves) *leaves = c->leaves;
+    return GH_OK;
+}
+
+int gh_upload_G(gh_ctx *c, const double *A, int64_t ld, int fortran_order)
+{
+    if (!c || !A) return fail(c, GH_ERR_ARG, "gh_upload_G: null pointer");
+    if (ld < (fortran_order ? c->N : c->M)) return fail(c, GH_ERR_ARG, "gh_upload_G: ld too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(dalloc(c, &c->G, (size_t)c->ld * (size_t)c->M, false));
+    HIPCHK(c, hipMemsetAsync(c->G, 0, sizeof(double) * (size_t)c->ld * (size_t)c->M, c->stream));
+    if (fortran_order) {
+        HIPCHK(c, hipMemcpy2DAsync(c->G, (size_t)c->ld * sizeof(double), A, (size_t)ld * sizeof(double),
+                                   (size_t)c->N * sizeof(double), (size_t)c->M, hipMemcpyHostToDevice,
+                                   c->stream));
+    } else {
+        // row-major N x M: transpose on the host in column panels (setup path, runs once)
+        const int64_t panel = std::max<int64_t>(1, (int64_t)(64 << 20) / (int64_t)(c->N * sizeof(double)));
+        std::vector<double> buf((size_t)std::min(panel, c->M) * (size_t)c->N);
+        for (int64_t j0 = 0; j0 < c->M; j0 += panel) {
+            const int64_t nb = std::min(panel, c->M - j0);
+            for (int64_t i = 0; i < c->N; ++i)
+                for (int64_t j = 0; j < nb; ++j) buf[(size_t)j * c->N + i] = A[i * ld + j0 + j];
+            HIPCHK(c, hipMemcpy2DAsync(c->G + j0 * c->ld, (size_t)c->ld * sizeof(double), buf.data(),
+                                       (size_t)c->N * sizeof(double), (size_t)c->N * sizeof(double),
+                                       (size_t)nb, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_G = true;
+    c->weighted = false;
+    c->chain_ready = false;
+    return GH_OK;
+}
+
+int gh_download_G(gh_ctx *c, double *A, int64_t ld)
+{
+    if (!c || !A) return fail(c, GH_ERR_ARG, "gh_download_G: null pointer");
+    TRY(need(c, c->have_G, "gh_download_G: no kernel matrix resident"));
+    if (ld < c->N) return fail(c, GH_ERR_ARG, "gh_download_G: ld too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(A, (size_t)ld * sizeof(double), c->G, (size_t)c->ld * sizeof(double),
+                               (size_t)c->N * sizeof(double), (size_t)c->M, hipMemcpyDeviceToHost,
+                               c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+int gh_weight(gh_ctx *c, double weightfactor, double *wm_out)
+{
+    if (!c) return GH_ERR_ARG;
+    TRY(need(c, c->have_G, "gh_weight: no kernel matrix resident"));
+    TRY(need(c, !c->weighted, "gh_weight: kernel is already weighted"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(dalloc(c, &c->wm, (size_t)c->M));
+    TRY(dalloc(c, &c->wm2, (size_t)c->M));
+    weight_fn f = weight_for(c);
+    const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
+    hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), 0, c->stream, c->G, c->ld, c->M,
+                       c->cols_per_team, c->n_teams, weightfactor, c->wm);
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> w((size_t)c->M);
+    TRY(d2h(c, w.data(), c->wm, (size_t)c->M));
+    if (wm_out) memcpy(wm_out, w.data(), sizeof(double) * (size_t)c->M);
+    for (auto &v : w) v = v * v;  // diag(WmSquare) = ADiag * ADiag (potential.py:253)
+    TRY(h2d(c, c->wm2, w.data(), (size_t)c->M));
+    c->weighted = true;
+    c->chain_ready = false;
+    return GH_OK;
+}
+
+int gh_set_data(gh_ctx *c, const double *dobs, const double *grav_fix)
+{
+    if (!c || !dobs) return fail(c, GH_ERR_ARG, "gh_set_data: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->N;
+    TRY(dalloc(c, &c->dobs_c, (size_t)c->ld));
+    TRY(dalloc(c, &c->gfix, (size_t)c->ld));
+    // dobs - mean(dobs) (potential.py:706); numpy's mean is a pairwise sum
+    std::vector<double> t(dobs, dobs + N);
+    // pairwise summation with numpy's blocking (8-way unrolled blocks of 128)
+    struct PW {
+        static double sum(const double *a, size_t n)
+        {
+            if (n < 8) {
+                double r = 0.0;
+                for (size_t i = 0; i < n; ++i) r += a[i];
+                return r;
+            }
+            if (n <= 128) {
+                double r[8];
+                for (int k = 0; k < 8; ++k) r[k] = a[k];
+                size_t i = 8;
+                for (; i + 8 <= n; i += 8)
+                    for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+                double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < n; ++i) res += a[i];
+                return res;
+            }
+            size_t n2 = n / 2;
+            n2 -= n2 % 8;
+            return sum(a, n2) + sum(a + n2, n - n2);
+        }
+    };
+    const double mean = PW::sum(t.data(), N) / (double)N;
+    for (auto &v : t) v -= mean;
+    TRY(h2d(c, c->dobs_c, t.data(), N));
+    c->have_fix = grav_fix != nullptr;
+    if (grav_fix) TRY(h2d(c, c->gfix, grav_fix, N));
+    c->have_data = true;
+    c->chain_ready = false;
+    return GH_OK;
+}
+
+int gh_set_reg(gh_ctx *c, int kind, double alpha, double beta, const int shape3[3], const double *mwapr)
+{
+    if (!c || !mwapr) return fail(c, GH_ERR_ARG, "gh_set_reg: null pointer");
+    if (kind < 0 || kind > 3)
+        return fail(c, GH_ERR_ARG, "Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.");
+    if (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV) {
+        if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
+            return fail(c, GH_ERR_ARG, "gh_set_reg: Smoothness/TV need shape nz*ny*nx == M (carved meshes are not supported by the finite-difference operator)");
+    }
+    if (kind == GH_REG_MS) TRY(need(c, c->weighted, "gh_set_reg: MS needs gh_weight first (uses Wm^2)"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(dalloc(c, &c->mwapr, (size_t)c->M));
+    TRY(dalloc(c, &c->wm2, (size_t)c->M));
+    TRY(h2d(c, c->mwapr, mwapr, (size_t)c->M));
+    c->reg_kind = kind;
+    c->alpha = alpha;
+    c->beta = beta;
+    if (shape3) {
+        c->shape[0] = shape3[0];
+        c->shape[1] = shape3[1];
+        c->shape[2] = shape3[2];
+    }
+    c->have_reg = true;
+    c->chain_ready = false;
+    return GH_OK;
+}
+
+int gh_forward(gh_ctx *c, const double *mw, double *dpre)
+{
+    if (!c || !mw || !dpre) return fail(c, GH_ERR_ARG, "gh_forward: null pointer");
+    TRY(need(c, c->have_G, "gh_forward: no kernel matrix resident"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    TRY(h2d(c, c->tmpM, mw, (size_t)c->M));
+    SweepArgs a{};
+    a.mode = SW_FWD;
+    a.x_in = c->tmpM;
+    a.slab = c->slab;
+    TRY(launch_sweep(c, a));
+    reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(c->slab, c->grid, c->ld, c->N,
+                                                                        nullptr, c->tmpN, c->dpart);
+    HIPCHK(c, hipGetLastError());
+    return d2h(c, dpre, c->tmpN, (size_t)c->N);
+}
+
+int gh_adjoint(gh_ctx *c, const double *r, double *g)
+{
+    if (!c || !r || !g) return fail(c, GH_ERR_ARG, "gh_adjoint: null pointer");
+    TRY(need(c, c->have_G, "gh_adjoint: no kernel matrix resident"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    HIPCHK(c, hipMemsetAsync(c->tmpN, 0, sizeof(double) * (size_t)c->ld, c->stream));
+    TRY(h2d(c, c->tmpN, r, (size_t)c->N));
+    SweepArgs a{};
+    a.mode = SW_ADJ | SW_GOUT;
+    a.r = c->tmpN;
+    a.g_out = c->tmpM;
+    TRY(launch_sweep(c, a));
+    TRY(d2h(c, g, c->tmpM, (size_t)c->M));
+    for (int64_t j = 0; j < c->M; ++j) g[j] *= 0.5;  // the sweep writes 2*<G_j, r>
+    return GH_OK;
+}
+
+int gh_misfit_and_grad(gh_ctx *c, const double *x, double out3[3], double *grad, double *dpre)
+{
+    if (!c || !x || !out3 || !grad) return fail(c, GH_ERR_ARG, "gh_misfit_and_grad: null pointer");
+    TRY(need(c, c->have_G && c->have_data && c->have_reg,
+             "gh_misfit_and_grad: needs a kernel matrix, gh_set_data and gh_set_reg"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    TRY(h2d(c, c->xw[0], x, (size_t)c->M));
+    TRY(eval_forward(c, c->xw[0], c->d_w, c->r_w, c->greg_w, c->scal));
+    SweepArgs a{};
+    a.mode = SW_ADJ | SW_GOUT;
+    a.r = c->r_w;
+    a.greg = c->greg_w;
+    a.g_out = c->tmpM;
+    TRY(launch_sweep(c, a));
+    HIPCHK(c, hipMemcpyAsync(c->h_scal, c->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRY(d2h(c, grad, c->tmpM, (size_t)c->M));
+    if (dpre) TRY(d2h(c, dpre, c->d_w, (size_t)c->N));
+    out3[0] = c->h_scal[2];
+    out3[1] = c->h_scal[0];
+    out3[2] = c->h_scal[1];
+    return GH_OK;
+}
+
+int gh_chain_init(gh_ctx *c, const double *x0, const double *low, const double *high)
+{
+    if (!c || !x0 || !low || !high) return fail(c, GH_ERR_ARG, "gh_chain_init: null pointer");
+    TRY(need(c, c->have_G && c->have_data && c->have_reg,
+             "gh_chain_init: needs a kernel matrix, gh_set_data and gh_set_reg"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    TRY(h2d(c, c->x_cur, x0, (size_t)c->M));
+    TRY(h2d(c, c->low, low, (size_t)c->M));
+    TRY(h2d(c, c->high, high, (size_t)c->M));
+    TRY(eval_forward(c, c->x_cur, c->d_cur, c->r_cur, c->greg_cur, c->scal));
+    TRY(d2h(c, c->h_scal, c->scal, 4));
+    c->U_cur[0] = c->h_scal[2];
+    c->U_cur[1] = c->h_scal[0];
+    c->U_cur[2] = c->h_scal[1];
+    c->chain_ready = true;
+    return GH_OK;
+}
+
+int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u, int *accepted,
+                        double out5[5])
+{
+    if (!c || !p0 || !accepted || !out5) return fail(c, GH_ERR_ARG, "gh_chain_trajectory: null pointer");
+    TRY(need(c, c->chain_ready, "gh_chain_trajectory: call gh_chain_init first"));
+    if (L < 1) return fail(c, GH_ERR_ARG, "gh_chain_trajectory: L must be >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t M = (size_t)c->M;
+    // momentum upload + kinetic energy of p0 (hmc.py:95-104)
+    HIPCHK(c, hipMemcpyAsync(c->pw[0], p0, M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    sumsq_kernel<<<dim3(c->n_pp0), dim3(256), 0, c->stream>>>(c->pw[0], c->M, c->pp0_part);
+    const double *x_in = c->x_cur, *r_in = c->r_cur, *greg_in = c->greg_cur;
+    int pin = 0;  // pw[pin] holds the current momentum
+    int xo = 0;   // next x output buffer
+    for (int s = 0; s < L; ++s) {
+        SweepArgs a{};
+        a.mode = SW_ADJ | SW_UPD | SW_FWD;
+        a.r = r_in;
+        a.greg = greg_in;
+        a.x_in = x_in;
+        a.p_in = c->pw[pin];
+        a.x_out = c->xw[xo];
+        a.p_out = c->pw[pin ^ 1];
+        a.low = c->low;
+        a.high = c->high;
+        a.c_p = (s == 0) ? dt * 0.5 : dt;
+        a.dt = dt;
+        a.slab = c->slab;
+        TRY(launch_sweep(c, a));
+        TRY(finalize(c, c->xw[xo], c->d_w, c->r_w, c->greg_w, c->scal));
+        x_in = c->xw[xo];
+        r_in = c->r_w;
+        greg_in = c->greg_w;
+        pin ^= 1;
+        xo ^= 1;
+    }
+    // last half step of the momentum + kinetic energy (hmc.py:151-157)
+    {
+        SweepArgs a{};
+        a.mode = SW_ADJ | SW_PFIN;
+        a.r = r_in;
+        a.greg = greg_in;
+        a.p_in = c->pw[pin];
+        a.p_out = c->pw[pin ^ 1];
+        a.c_p = dt * 0.5;
+        a.pp_part = c->pp_part;
+        TRY(launch_sweep(c, a));
+    }
+    double *h = c->h_scal;
+    HIPCHK(c, hipMemcpyAsync(h, c->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + 16, c->pp_part, (size_t)c->n_teams * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + 16 + c->n_teams, c->pp0_part, (size_t)c->n_pp0 * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double pp1 = 0.0, pp0 = 0.0;
+    for (int t = 0; t < c->n_teams; ++t) pp1 += h[16 + t];
+    for (int t = 0; t < c->n_pp0; ++t) pp0 += h[16 + c->n_teams + t];
+    const double Unew[3] = {h[2], h[0], h[1]};
+    const double Hcur = 0.5 * pp0 + c->U_cur[0];
+    const double Hnew = 0.5 * pp1 + Unew[0];
+    const bool acc = (Hnew < Hcur) || (u < std::exp(-(Hnew - Hcur)));
+    if (acc) {
+        // the proposal lives in xw[xo^1]; make it the chain state by swapping buffers
+        std::swap(c->x_cur, c->xw[xo ^ 1]);
+        std::swap(c->r_cur, c->r_w);
+        std::swap(c->greg_cur, c->greg_w);
+        std::swap(c->d_cur, c->d_w);
+        c->U_cur[0] = Unew[0];
+        c->U_cur[1] = Unew[1];
+        c->U_cur[2] = Unew[2];
+    }
+    *accepted = acc ? 1 : 0;
+    out5[0] = c->U_cur[0];
+    out5[1] = c->U_cur[1];
+    out5[2] = c->U_cur[2];
+    out5[3] = Hcur;
+    out5[4] = Hnew;
+    return GH_OK;
+}
+
+int gh_chain_get_x(gh_ctx *c, double *x)
+{
+    if (!c || !x) return fail(c, GH_ERR_ARG, "gh_chain_get_x: null pointer");
+    TRY(need(c, c->chain_ready, "gh_chain_get_x: call gh_chain_init first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    return d2h(c, x, c->x_cur, (size_t)c->M);
+}
+
+int gh_chain_get_dsyn(gh_ctx *c, double *dsyn)
+{
+    if (!c || !dsyn) return fail(c, GH_ERR_ARG, "gh_chain_get_dsyn: null pointer");
+    TRY(need(c, c->chain_ready, "gh_chain_get_dsyn: call gh_chain_init first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    return d2h(c, dsyn, c->d_cur, (size_t)c->N);
+}
+
+int gh_leapfrog(gh_ctx *c, double *x_inout, const double *p0, double dt, int L, const double *low,
+                const double *high, double u, int *accepted, double out5[5], double *dsyn)
+{
+    TRY(gh_chain_init(c, x_inout, low, high));
+    TRY(gh_chain_trajectory(c, p0, dt, L, u, accepted, out5));
+    TRY(gh_chain_get_x(c, x_inout));
+    if (dsyn) TRY(gh_chain_get_dsyn(c, dsyn));
+    return GH_OK;
+}
+
+int gh_profile_enable(gh_ctx *c, int enable)
+{
+    if (!c) return GH_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (enable && c->ev.empty()) {
+        c->ev.resize(8192);
+        for (auto &e : c->ev) HIPCHK(c, hipEventCreate(&e));
+    }
+    c->prof = enable != 0;
+    c->ev_used = 0;
+    c->prof_ms_acc = 0.0;
+    c->prof_launches = 0;
+    return GH_OK;
+}
+
+int gh_profile_read(gh_ctx *c, double *sweep_ms, int64_t *sweep_launches, int64_t *bytes_per_sweep)
+{
+    if (!c) return GH_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double ms = c->prof_ms_acc;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float t = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+        ms += t;
+    }
+    // launches beyond the event pool are counted but not timed: scale to the timed share
+    const int64_t timed = (int64_t)(c->ev_used / 2);
+    if (sweep_ms) *sweep_ms = ms;
+    if (sweep_launches) *sweep_launches = timed;
+    if (bytes_per_sweep) *bytes_per_sweep = c->N * c->M * (int64_t)sizeof(double);
+    return GH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,656 @@
+// Device kernels of libgravhmc (gfx950 / CDNA4, wave64).  Included once by gravhmc.hip.
+//
+// Data layout in HBM
+//   G      column-major N x M, leading dimension ld = roundup(N, 16) doubles, so every cell's
+//          column starts on a 128-byte line; rows N..ld-1 are zero.  C2: 10^4 x 5*10^5 = 40 GB.
+//   N-vectors (d, r, dobs...) are stored padded to ld with zeros; M-vectors are plain.
+//   slab   [n_teams][ld] partial forward products, one row per team of the sweep.
+//
+// The hot kernel is `sweep_kernel`: ONE pass over G per leapfrog step.  A team (1, 4 or 16
+// waves) owns a contiguous range of columns; for each column j it keeps the column in
+// registers and does
+//     g_j   = 2 * <G_j, r> + greg_j          (adjoint of the step that just finished)
+//     p_j  -= c * g_j ;  x_j += dt * p_j ; clamp-and-reflect     (hmc.py:114-152)
+//     dacc += G_j * x_j                      (forward of the NEXT step, same registers)
+// so the reference's two GEMVs per potential evaluation (potential.py:698,708) cost one read
+// of G.  HBM-bound: 0.5 flop/byte; no MFMA (a single chain is a GEMV).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ghk {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------ reductions (deterministic)
+
+__device__ __forceinline__ double wave_allreduce_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// Block-wide sum, fixed order, result valid in every thread.  red: LDS scratch >= nwaves doubles.
+__device__ __forceinline__ double block_allreduce_sum(double v, double *red, int nwaves)
+{
+    v = wave_allreduce_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < nwaves; ++w) t += red[w];
+    return t;
+}
+
+// ------------------------------------------------------------------------------ the G sweep
+
+enum : int {
+    SW_ADJ = 1,   // dot every column with r
+    SW_UPD = 2,   // leapfrog momentum + position update with clamp-and-reflect
+    SW_FWD = 4,   // accumulate G_j * x_j into the team's forward partial
+    SW_PFIN = 8,  // final half-step momentum update + sum of p^2 (needs SW_ADJ)
+    SW_GOUT = 16  // write the gradient 2*dot + greg to g_out (needs SW_ADJ)
+};
+
+struct SweepArgs {
+    const double *G;
+    int64_t ld;
+    int64_t M;
+    int64_t cols_per_team;
+    int n_teams;
+    int mode;
+    const double *r;      // ld, residual (SW_ADJ)
+    const double *greg;   // M, alpha * grad R(x) or nullptr
+    const double *x_in;   // M: position before the step (SW_UPD) / the vector (SW_FWD only)
+    const double *p_in;   // M: momentum before the step (SW_UPD, SW_PFIN)
+    double *x_out;        // M (SW_UPD)   -- never aliases x_in: other waves of the team may
+    double *p_out;        // M (SW_UPD, SW_PFIN)  still be reading the inputs
+    const double *low, *high;
+    double c_p;           // momentum coefficient for this sweep (dt or dt/2)
+    double dt;            // position step
+    double *g_out;        // M (SW_GOUT)
+    double *slab;         // gridDim.x x ld (SW_FWD)
+    double *pp_part;      // n_teams (SW_PFIN): sum of p_j^2 over the team's columns
+};
+
+template <int EPT2>
+struct ColRegs {
+    double2 v[EPT2];
+    double p, x, lo, hi, gr;  // per-column scalars, prefetched with the column
+};
+
+// TW = waves per team (1, 4, 16).  TW == 1: four independent wave-teams per 256-thread block.
+// EPT2 = double2 elements held per thread: capacity = TW*64*EPT2*2 rows >= ld.
+template <int TW, int EPT2>
+__global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArgs a)
+{
+    constexpr int TEAM_THREADS = TW * 64;
+    constexpr int WG_TEAMS = (TW == 1) ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // LDS: [0, ld) r ; then TW==1: 4 x ld scratch for the cross-wave forward reduce,
+    //      TW>1: 2 x TW doubles for the ping-pong dot reduction.
+    double *r_s = smem;
+    double *scratch = smem + a.ld;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int ttid = (TW == 1) ? lane : tid;  // thread index inside the team
+    const int team = blockIdx.x * WG_TEAMS + ((TW == 1) ? wave : 0);
+    const int64_t ld = a.ld;
+    const int64_t ld2 = ld >> 1;  // in double2 units
+    const int mode = a.mode;
+
+    if (mode & SW_ADJ) {
+        const double2 *r2 = reinterpret_cast<const double2 *>(a.r);
+        double2 *rs2 = reinterpret_cast<double2 *>(r_s);
+        for (int64_t e = tid; e < ld2; e += blockDim.x) rs2[e] = r2[e];
+    }
+    __syncthreads();
+
+    int64_t j0 = (int64_t)team * a.cols_per_team;
+    int64_t j1 = j0 + a.cols_per_team;
+    if (j1 > a.M) j1 = a.M;
+    if (team >= a.n_teams) j0 = j1 = 0;
+
+    ColRegs<EPT2> cur, nxt;
+    double2 dacc[EPT2];
+#pragma unroll
+    for (int k = 0; k < EPT2; ++k) {
+        dacc[k] = make_double2(0.0, 0.0);
+        nxt.v[k] = make_double2(0.0, 0.0);
+    }
+    nxt.p = nxt.x = nxt.lo = nxt.hi = nxt.gr = 0.0;
+    double pp = 0.0;
+
+    auto load_col = [&](ColRegs<EPT2> &c, int64_t j) {
+        const double2 *col = reinterpret_cast<const double2 *>(a.G + j * ld);
+#pragma unroll
+        for (int k = 0; k < EPT2; ++k) {
+            const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
+            c.v[k] = (e < ld2) ? col[e] : make_double2(0.0, 0.0);
+        }
+        c.gr = a.greg ? a.greg[j] : 0.0;
+        c.x = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+        c.p = (mode & (SW_UPD | SW_PFIN)) ? a.p_in[j] : 0.0;
+        if (mode & SW_UPD) {
+            c.lo = a.low[j];
+            c.hi = a.high[j];
+        } else {
+            c.lo = c.hi = 0.0;
+        }
+    };
+
+    // TW > 1: one team per block, so every wave takes the same trip count (barrier inside)
+    if (j0 < j1) load_col(cur, j0);
+    for (int64_t j = j0; j < j1; ++j) {
+        if (j + 1 < j1) load_col(nxt, j + 1);
+        double xj = cur.x;
+        if (mode & SW_ADJ) {
+            const double2 *rs2 = reinterpret_cast<const double2 *>(r_s);
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < EPT2; ++k) {
+                const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
+                if (e < ld2) {
+                    const double2 rv = rs2[e];
+                    s += cur.v[k].x * rv.x;
+                    s += cur.v[k].y * rv.y;
+                }
+            }
+            s = wave_allreduce_sum(s);
+            if (TW > 1) {
+                double *red = scratch + ((j - j0) & 1) * TW;
+                if (lane == 0) red[wave] = s;
+                __syncthreads();
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < TW; ++w) t += red[w];
+                s = t;
+            }
+            const double g = 2.0 * s + cur.gr;
+            if ((mode & SW_GOUT) && ttid == 0) a.g_out[j] = g;
+            if (mode & SW_UPD) {
+                double pj = cur.p - a.c_p * g;
+                xj = cur.x + a.dt * pj;
+                if (xj > cur.hi) {
+                    xj = cur.hi;
+                    pj = -pj;
+                } else if (xj < cur.lo) {
+                    xj = cur.lo;
+                    pj = -pj;
+                }
+                if (ttid == 0) {
+                    a.p_out[j] = pj;
+                    a.x_out[j] = xj;
+                }
+            } else if (mode & SW_PFIN) {
+                const double pj = cur.p - a.c_p * g;
+                if (ttid == 0) a.p_out[j] = pj;
+                pp += pj * pj;
+            }
+        }
+        if (mode & SW_FWD) {
+#pragma unroll
+            for (int k = 0; k < EPT2; ++k) {
+                dacc[k].x += cur.v[k].x * xj;
+                dacc[k].y += cur.v[k].y * xj;
+            }
+        }
+        cur = nxt;
+    }
+
+    if ((mode & SW_PFIN) && ttid == 0 && team < a.n_teams) a.pp_part[team] = pp;
+
+    if (mode & SW_FWD) {
+        if (TW == 1) {
+            // sum the block's four wave-teams through LDS, then one slab row per block
+            double2 *sc2 = reinterpret_cast<double2 *>(scratch);
+#pragma unroll
+            for (int k = 0; k < EPT2; ++k) {
+                const int64_t e = (int64_t)k * 64 + lane;
+                if (e < ld2) sc2[wave * ld2 + e] = dacc[k];
+            }
+            __syncthreads();
+            double2 *out = reinterpret_cast<double2 *>(a.slab + (int64_t)blockIdx.x * ld);
+            for (int64_t e = tid; e < ld2; e += blockDim.x) {
+                const double2 s0 = sc2[e], s1 = sc2[ld2 + e], s2 = sc2[2 * ld2 + e],
+                              s3 = sc2[3 * ld2 + e];
+                double2 t;
+                t.x = ((s0.x + s1.x) + s2.x) + s3.x;
+                t.y = ((s0.y + s1.y) + s2.y) + s3.y;
+                out[e] = t;
+            }
+        } else {
+            double2 *out = reinterpret_cast<double2 *>(a.slab + (int64_t)blockIdx.x * ld);
+#pragma unroll
+            for (int k = 0; k < EPT2; ++k) {
+                const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
+                if (e < ld2) out[e] = dacc[k];
+            }
+        }
+    }
+}
+
+// -------------------------------------------------- finalize: slab -> d, regulariser, residual
+
+// d[i] = sum_t slab[t][i] (fixed order), partial[b] = sum over the block's rows of
+// d[i] + grav_fix[i].  Launch: grid = ceil(ld/32), block = (32, 8).
+__global__ void __launch_bounds__(256) reduce_slab_kernel(const double *slab, int n_rows_slab,
+                                                          int64_t ld, int64_t N,
+                                                          const double *gfix, double *d,
+                                                          double *partial)
+{
+    __shared__ double red[8][33];
+    const int rx = threadIdx.x, ty = threadIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 32 + rx;
+    double acc = 0.0;
+    if (i < ld) {
+        int t = ty;
+        for (; t + 24 < n_rows_slab; t += 32) {
+            const double a0 = slab[(int64_t)t * ld + i];
+            const double a1 = slab[(int64_t)(t + 8) * ld + i];
+            const double a2 = slab[(int64_t)(t + 16) * ld + i];
+            const double a3 = slab[(int64_t)(t + 24) * ld + i];
+            acc += a0;
+            acc += a1;
+            acc += a2;
+            acc += a3;
+        }
+        for (; t < n_rows_slab; t += 8) acc += slab[(int64_t)t * ld + i];
+    }
+    red[ty][rx] = acc;
+    __syncthreads();
+    if (ty == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][rx];
+        double dinv = 0.0;
+        if (i < ld) {
+            d[i] = s;
+            if (i < N) dinv = s + (gfix ? gfix[i] : 0.0);
+        }
+        // 32 active lanes of wave 0: butterfly over 32
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) dinv += __shfl_xor(dinv, off, WAVE);
+        if (rx == 0) partial[blockIdx.x] = dinv;
+    }
+}
+
+struct RegArgs {
+    int kind;
+    int64_t M;
+    int nz, ny, nx;
+    double alpha, beta;
+    const double *x, *mwapr, *wm2;
+    double *greg;     // alpha * grad R
+    double *regpart;  // per-block partial of R
+};
+
+// Regulariser value + gradient at x (potential.py:719-736, 775-810) as a stencil; the
+// finite-difference operator of potential.py:266-361 is never materialised.
+__global__ void __launch_bounds__(256) reg_kernel(RegArgs a)
+{
+    __shared__ double red[4];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double val = 0.0;
+    if (j < a.M) {
+        const double v = a.x[j] - a.mwapr[j];
+        double g = 0.0;
+        if (a.kind == 0) {  // Damping
+            val = v * v;
+            g = 2.0 * v;
+        } else if (a.kind == 2) {  // MS
+            const double v2 = v * v, den = v2 + a.beta, w2 = a.wm2[j];
+            val = (w2 * v2) / den;
+            g = (2.0 * a.beta * w2 * v) / (den * den);
+        } else {  // Smoothness (1) / TV (3)
+            const int64_t nx = a.nx, ny = a.ny, nz = a.nz;
+            const int64_t i = j % nx, jj = (j / nx) % ny, k = j / (nx * ny);
+            const int64_t stride[3] = {1, nx, nx * ny};
+            const bool fwd[3] = {i < nx - 1, jj < ny - 1, k < nz - 1};
+            const bool bwd[3] = {i > 0, jj > 0, k > 0};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (fwd[ax]) {
+                    const int64_t q = j + stride[ax];
+                    const double t = v - (a.x[q] - a.mwapr[q]);
+                    if (a.kind == 1) {
+                        val += t * t;
+                        g += 2.0 * t;
+                    } else {
+                        const double s = sqrt(t * t + a.beta);
+                        val += s;
+                        g += t / s;
+                    }
+                }
+                if (bwd[ax]) {
+                    const int64_t q = j - stride[ax];
+                    const double t = (a.x[q] - a.mwapr[q]) - v;
+                    if (a.kind == 1)
+                        g -= 2.0 * t;
+                    else
+                        g -= t / sqrt(t * t + a.beta);
+                }
+            }
+        }
+        a.greg[j] = a.alpha * g;
+    }
+    const double tot = block_allreduce_sum(val, red, 4);
+    if (threadIdx.x == 0) a.regpart[blockIdx.x] = tot;
+}
+
+struct FinishArgs {
+    int64_t N, ld;
+    int n_dpart, n_regpart;
+    const double *d, *gfix, *dobs_c, *dpart, *regpart;
+    double alpha;
+    double *r;     // ld (zero padded)
+    double *scal;  // [0]=U_data [1]=R [2]=U [3]=mean(dinv)
+};
+
+// Single block: mean removal, residual, data misfit (potential.py:700-706) and U = U_d + alpha R.
+__global__ void __launch_bounds__(1024) finish_kernel(FinishArgs a)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < a.n_dpart; t += 1024) s += a.dpart[t];
+    const double mean = block_allreduce_sum(s, red, 16) / (double)a.N;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < a.ld; i += 1024) {
+        double ri = 0.0;
+        if (i < a.N) {
+            const double dinv = a.d[i] + (a.gfix ? a.gfix[i] : 0.0);
+            ri = (dinv - mean) - a.dobs_c[i];
+            acc += ri * ri;
+        }
+        a.r[i] = ri;
+    }
+    const double ud = block_allreduce_sum(acc, red, 16);
+    double rs = 0.0;
+    for (int t = threadIdx.x; t < a.n_regpart; t += 1024) rs += a.regpart[t];
+    const double R = block_allreduce_sum(rs, red, 16);
+    if (threadIdx.x == 0) {
+        a.scal[0] = ud;
+        a.scal[1] = R;
+        a.scal[2] = ud + a.alpha * R;
+        a.scal[3] = mean;
+    }
+}
+
+// per-block partial sums of v[j]^2
+__global__ void __launch_bounds__(256) sumsq_kernel(const double *v, int64_t M, double *part)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < M; j += (int64_t)gridDim.x * 256)
+        acc += v[j] * v[j];
+    const double t = block_allreduce_sum(acc, red, 4);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// ----------------------------------------------------------------- sensitivity weighting
+
+// One team per column at a time: wm_j = (sum_i G_ij^2)^wf ; G_j *= 1/wm_j (potential.py:232-264).
+template <int TW, int EPT2>
+__global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64)
+weight_kernel(double *G, int64_t ld, int64_t M, int64_t cols_per_team, int n_teams, double wf,
+              double *wm)
+{
+    constexpr int TEAM_THREADS = TW * 64;
+    constexpr int WG_TEAMS = (TW == 1) ? 4 : 1;
+    __shared__ double red[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ttid = (TW == 1) ? lane : tid;
+    const int team = blockIdx.x * WG_TEAMS + ((TW == 1) ? wave : 0);
+    const int64_t ld2 = ld >> 1;
+    int64_t j0 = (int64_t)team * cols_per_team, j1 = j0 + cols_per_team;
+    if (j1 > M) j1 = M;
+    if (team >= n_teams) j0 = j1 = 0;
+    for (int64_t j = j0; j < j1; ++j) {
+        double2 *col = reinterpret_cast<double2 *>(G + j * ld);
+        double2 c[EPT2];
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT2; ++k) {
+            const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
+            c[k] = (e < ld2) ? col[e] : make_double2(0.0, 0.0);
+            s += c[k].x * c[k].x;
+            s += c[k].y * c[k].y;
+        }
+        s = wave_allreduce_sum(s);
+        if (TW > 1) {
+            double *rd = red[(j - j0) & 1];
+            if (lane == 0) rd[wave] = s;
+            __syncthreads();
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < TW; ++w) t += rd[w];
+            s = t;
+        }
+        const double w = (wf == 0.5) ? sqrt(s) : pow(s, wf);
+        if (ttid == 0) wm[j] = w;
+        if (w != 0.0) {
+            const double inv = 1.0 / w;
+#pragma unroll
+            for (int k = 0; k < EPT2; ++k) {
+                const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
+                if (e < ld2) col[e] = make_double2(c[k].x * inv, c[k].y * inv);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------- kernel assembly
+// Strict IEEE evaluation order (no FMA contraction) so the entries track the reference's
+// Cython/C and numba/libm arithmetic as closely as the device math library allows.
+
+__device__ __forceinline__ double safe_atan2_d(double y, double x)
+{
+    // _prism.pyx:16-26 (quadrant folding; the literal is the reference's)
+    const double PI_LIT = 3.1415926535897931159979634685441851615906;
+    if (y == 0) return 0;
+    if (y > 0 && x < 0) return atan2(y, x) - PI_LIT;
+    if (y < 0 && x < 0) return atan2(y, x) + PI_LIT;
+    return atan2(y, x);
+}
+
+__device__ __forceinline__ double safe_log_d(double x)
+{
+    // _prism.pyx:28-34
+    if (x == 0) return 0;
+    return log(x);
+}
+
+// G[i + c*ld] = G*SI2MGAL * sum over the 8 corners (-1)^(i+j+k) kernelz (prism.py:291-316,
+// _prism.pyx:49-50,265-290).  One thread per (obs, cell) entry, obs fastest (coalesced store).
+__global__ void __launch_bounds__(256)
+prism_gz_kernel(const double *__restrict__ xp, const double *__restrict__ yp,
+                const double *__restrict__ zp, const double *__restrict__ bounds6, int64_t N,
+                int64_t M, int64_t ld, double *__restrict__ G)
+{
+#pragma clang fp contract(off)
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ld * M) return;
+    const int64_t c = idx / ld, l = idx - c * ld;
+    if (l >= N) {
+        G[idx] = 0.0;
+        return;
+    }
+    const double *b = bounds6 + 6 * c;
+    const double X[2] = {b[1], b[0]}, Y[2] = {b[3], b[2]}, Z[2] = {b[5], b[4]};
+    const double px = xp[l], py = yp[l], pz = zp[l];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double dz = Z[k] - pz;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double dy = Y[j] - py;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double dx = X[i] - px;
+                const double r = sqrt(dx * dx + dy * dy + dz * dz);
+                const double kern = -(dx * safe_log_d(dy + r) + dy * safe_log_d(dx + r) -
+                                      dz * safe_atan2_d(dx * dy, dz * r));
+                const double sign = ((i + j + k) & 1) ? -1.0 : 1.0;
+                acc += sign * kern;
+            }
+        }
+    }
+    G[idx] = acc * (0.00000006673 * 100000.0);
+}
+
+constexpr int TESS_STACK = 100;  // tesseroid.py:79
+
+struct TessStats {
+    unsigned long long leaves;
+    int overflow;
+};
+
+// Adaptive 2x2x2 Gauss-Legendre tesseroid gz entry (_tesseroid_numba.py:32-71, 75-157,
+// 207-222), one thread per (obs, cell) pair with a private LIFO stack of sub-tesseroids.
+// err_cell[c] accumulates the engine's error codes (non-zero => the reference warns).
+__global__ void __launch_bounds__(64)
+tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinlat_a,
+               const double *__restrict__ coslat_a, const double *__restrict__ radius_a,
+               const double *__restrict__ bounds6, int64_t N, int64_t M, int64_t ld, double ratio,
+               double *__restrict__ G, int *__restrict__ err_cell, TessStats *stats)
+{
+#pragma clang fp contract(off)
+    const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (idx >= ld * M) return;
+    const int64_t c = idx / ld, l = idx - c * ld;
+    if (l >= N) {
+        G[idx] = 0.0;
+        return;
+    }
+    const double MEAN_R = 6378137.0;
+    const double d2r = 3.14159265358979323846 / 180;
+    const double node[2] = {-0.577350269189625731058868041146, 0.577350269189625731058868041146};
+    const double lon = lon_r[l], sinlat = sinlat_a[l], coslat = coslat_a[l], radius = radius_a[l];
+    double stack[TESS_STACK][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) stack[0][q] = bounds6[6 * c + q];
+    int stktop = 0, error_code = 0;
+    unsigned long long nleaf = 0;
+    bool overflow = false;
+    double acc = 0.0;
+    while (stktop >= 0) {
+        const double w = stack[stktop][0], e = stack[stktop][1], s = stack[stktop][2],
+                     n = stack[stktop][3], top = stack[stktop][4], bottom = stack[stktop][5];
+        stktop -= 1;
+        // distance_size
+        const double rt = 0.5 * (top + bottom) + MEAN_R;
+        const double lont = d2r * 0.5 * (w + e);
+        const double latt = d2r * 0.5 * (s + n);
+        const double sinlatt = sin(latt), coslatt = cos(latt);
+        const double cospsi0 = sinlat * sinlatt + coslat * coslatt * cos(lon - lont);
+        const double distance = sqrt(radius * radius + rt * rt - 2 * radius * rt * cospsi0);
+        const double rtop = top + MEAN_R;
+        const double Llon = rtop * acos(sinlatt * sinlatt + (coslatt * coslatt) * cos(d2r * (e - w)));
+        const double Llat =
+            rtop * acos(sin(d2r * n) * sin(d2r * s) + cos(d2r * n) * cos(d2r * s));
+        const double Lr = top - bottom;
+        // divisions
+        int nlon = 1, nlat = 1, nr = 1, err = 0;
+        if (distance <= ratio * Llon) {
+            if (Llon <= 0.1) err = -1; else nlon = 2;
+        }
+        if (distance <= ratio * Llat) {
+            if (Llat <= 0.1) err = -1; else nlat = 2;
+        }
+        if (distance <= ratio * Lr) {
+            if (Lr <= 1e3) err = -1; else nr = 2;
+        }
+        error_code += err;
+        const int new_cells = nlon * nlat * nr;
+        if (new_cells > 1) {
+            if (new_cells + (stktop + 1) > TESS_STACK) {
+                overflow = true;
+                break;
+            }
+            const double dlon = (e - w) / nlon, dlat = (n - s) / nlat, dr = (top - bottom) / nr;
+            for (int i = 0; i < nlon; ++i)
+                for (int j = 0; j < nlat; ++j)
+                    for (int k = 0; k < nr; ++k) {
+                        stktop += 1;
+                        stack[stktop][0] = w + i * dlon;
+                        stack[stktop][1] = w + (i + 1) * dlon;
+                        stack[stktop][2] = s + j * dlat;
+                        stack[stktop][3] = s + (j + 1) * dlat;
+                        stack[stktop][4] = bottom + (k + 1) * dr;
+                        stack[stktop][5] = bottom + k * dr;
+                    }
+        } else {
+            double lonc[2], sinlatc[2], coslatc[2], rc[2];
+            const double dlon = d2r * (e - w), dlat = d2r * (n - s), dr = top - bottom;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                lonc[i] = 0.5 * dlon * node[i] + d2r * 0.5 * (e + w);
+                const double latc = 0.5 * dlat * node[i] + d2r * 0.5 * (n + s);
+                sinlatc[i] = sin(latc);
+                coslatc[i] = cos(latc);
+                rc[i] = (0.5 * dr * node[i] + 0.5 * (top + bottom) + MEAN_R);
+            }
+            const double scale = dlon * dlat * dr * 0.125;
+            const double r_sqr = radius * radius;
+            double result = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double coslon = cos(lon - lonc[i]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double cospsi = sinlat * sinlatc[j] + coslat * coslatc[j] * coslon;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const double l_sqr = r_sqr + rc[k] * rc[k] - 2 * radius * rc[k] * cospsi;
+                        const double kappa = (rc[k] * rc[k]) * coslatc[j];
+                        result += kappa * (rc[k] * cospsi - radius) / (l_sqr * sqrt(l_sqr));
+                    }
+                }
+            }
+            result *= -1;
+            acc += scale * result;
+            nleaf += 1;
+        }
+    }
+    G[idx] = acc * 100000.0 * 0.00000006673;
+    if (error_code != 0) atomicAdd(&err_cell[c], error_code);
+    if (overflow) atomicExch(&stats->overflow, 1);
+    // one atomic per wave for the leaf count
+    unsigned long long tot = nleaf;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, WAVE);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&stats->leaves, tot);
+}
+
+// obs (lon, lat, height) -> (lon rad, sin lat, cos lat, R + h)   (tesseroid.py:109-123)
+__global__ void tess_convert_kernel(const double *lon, const double *lat, const double *h,
+                                    int64_t N, double *lon_r, double *sinlat, double *coslat,
+                                    double *radius)
+{
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double d2r = 3.14159265358979323846 / 180;
+    lon_r[i] = lon[i] * d2r;
+    const double la = lat[i] * d2r;
+    sinlat[i] = sin(la);
+    coslat[i] = cos(la);
+    radius[i] = 6378137.0 + h[i];
+}
+
+// row-major (C order) host layout -> padded column-major device layout
+__global__ void __launch_bounds__(256)
+pad_columns_kernel(const double *src, int64_t N, int64_t M, int64_t lds, double *G, int64_t ld)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ld * M) return;
+    const int64_t c = idx / ld, l = idx - c * ld;
+    G[idx] = (l < N) ? src[c * lds + l] : 0.0;
+}
+
+}  // namespace ghk

@@ -1,0 +1,189 @@
+"""numpy-facing wrapper of one libgravhmc context (one problem resident on one MI355X)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, ptr
+
+
+class DeviceMatrix(object):
+    """Handle of the (weighted) kernel matrix resident in HBM.
+
+    Stands in for the dense ndarray the reference hands around as `Aw`
+    (potential.py:584-589); `np.asarray(handle)` / `.to_numpy()` copies it back,
+    Fortran-ordered N x M, only when somebody really asks for it."""
+
+    def __init__(self, engine):
+        self._engine = engine
+        self.shape = (engine.N, engine.M)
+        self.dtype = np.dtype(np.float64)
+        self.ndim = 2
+
+    def to_numpy(self):
+        return self._engine.download_G()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.to_numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    @property
+    def T(self):
+        return self.to_numpy().T
+
+    def __repr__(self):
+        return "DeviceMatrix(shape=%r, device=%d)" % (self.shape, self._engine.device)
+
+
+class Engine(object):
+    def __init__(self, N, M, device=0):
+        self._lib = _lib.load()
+        self.N, self.M, self.device = int(N), int(M), int(device)
+        h = C.c_void_p()
+        rc = self._lib.gh_create(C.byref(h), self.device, self.N, self.M)
+        check(rc, None)
+        self._h = h
+        self._reg_key = None
+
+    # -- lifetime -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        check(rc, self._h)
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(0), C.c_int64(0)
+        self._chk(self._lib.gh_device_info(self._h, name, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "cus": cus.value, "mem_bytes": mem.value}
+
+    def synchronize(self):
+        self._chk(self._lib.gh_synchronize(self._h))
+
+    # -- kernel matrix ------------------------------------------------------------
+    def set_obs(self, a, b, c):
+        a, b, c = f64(a), f64(b), f64(c)
+        if not (a.shape == b.shape == c.shape == (self.N,)):
+            raise ValueError("Input arrays xp, yp, and zp must have same length!")
+        self._chk(self._lib.gh_set_obs(self._h, ptr(a), ptr(b), ptr(c)))
+
+    def set_cells(self, bounds6, kind, ratio=1.6):
+        b = f64(bounds6)
+        if b.shape != (self.M, 6):
+            raise ValueError("bounds table must be (M, 6)")
+        self._chk(self._lib.gh_set_cells(self._h, ptr(b), int(kind), float(ratio)))
+
+    def build_G(self):
+        self._chk(self._lib.gh_build_G(self._h))
+
+    def kernel_stats(self):
+        w, l = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_kernel_stats(self._h, C.byref(w), C.byref(l)))
+        return {"warn_cells": w.value, "leaves": l.value}
+
+    def upload_G(self, A):
+        A = np.asarray(A, dtype=np.float64)
+        if A.shape != (self.N, self.M):
+            raise ValueError("kernel must be N x M")
+        if A.flags.f_contiguous:
+            self._chk(self._lib.gh_upload_G(self._h, ptr(A), self.N, 1))
+        else:
+            A = np.ascontiguousarray(A)
+            self._chk(self._lib.gh_upload_G(self._h, ptr(A), self.M, 0))
+
+    def download_G(self):
+        A = np.empty((self.M, self.N))
+        self._chk(self._lib.gh_download_G(self._h, ptr(A), self.N))
+        return A.T  # N x M, Fortran-ordered view
+
+    def weight(self, weightfactor=0.5):
+        wm = np.empty(self.M)
+        self._chk(self._lib.gh_weight(self._h, float(weightfactor), ptr(wm)))
+        return wm
+
+    # -- potential ----------------------------------------------------------------
+    def set_data(self, dobs, grav_fix=None):
+        dobs = f64(dobs)
+        if dobs.shape != (self.N,):
+            raise ValueError("dobs must have N entries")
+        gf = f64(grav_fix) if grav_fix is not None else None
+        self._chk(self._lib.gh_set_data(self._h, ptr(dobs), ptr(gf)))
+
+    def set_reg(self, regularization, alpha, beta, shape, mwapr):
+        if regularization not in _lib.REG_KINDS:
+            raise ValueError("Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.")
+        mwapr = f64(mwapr)
+        if mwapr.shape != (self.M,):
+            raise ValueError("mwapr must have M entries")
+        shp = (C.c_int * 3)(*[int(s) for s in shape]) if shape is not None else None
+        self._chk(self._lib.gh_set_reg(self._h, _lib.REG_KINDS[regularization], float(alpha),
+                                       float(beta), shp, ptr(mwapr)))
+
+    def forward(self, mw):
+        mw = f64(mw)
+        d = np.empty(self.N)
+        self._chk(self._lib.gh_forward(self._h, ptr(mw), ptr(d)))
+        return d
+
+    def adjoint(self, r):
+        r = f64(r)
+        g = np.empty(self.M)
+        self._chk(self._lib.gh_adjoint(self._h, ptr(r), ptr(g)))
+        return g
+
+    def misfit_and_grad(self, x):
+        x = f64(x)
+        out3, grad, dpre = np.empty(3), np.empty(self.M), np.empty(self.N)
+        self._chk(self._lib.gh_misfit_and_grad(self._h, ptr(x), ptr(out3), ptr(grad), ptr(dpre)))
+        return out3[0], grad, dpre, out3[1], out3[2]
+
+    # -- chain --------------------------------------------------------------------
+    def chain_init(self, x0, low, high):
+        x0, low, high = f64(x0), f64(low), f64(high)
+        self._chk(self._lib.gh_chain_init(self._h, ptr(x0), ptr(low), ptr(high)))
+
+    def chain_trajectory(self, p0, dt, L, u):
+        p0 = f64(p0)
+        acc = C.c_int(0)
+        out5 = np.empty(5)
+        self._chk(self._lib.gh_chain_trajectory(self._h, ptr(p0), float(dt), int(L), float(u),
+                                                C.byref(acc), ptr(out5)))
+        return bool(acc.value), out5
+
+    def chain_get_x(self):
+        x = np.empty(self.M)
+        self._chk(self._lib.gh_chain_get_x(self._h, ptr(x)))
+        return x
+
+    def chain_get_dsyn(self):
+        d = np.empty(self.N)
+        self._chk(self._lib.gh_chain_get_dsyn(self._h, ptr(d)))
+        return d
+
+    def leapfrog(self, x, p0, dt, L, low, high, u, want_dsyn=True):
+        x = f64(x).copy()
+        p0, low, high = f64(p0), f64(low), f64(high)
+        acc = C.c_int(0)
+        out5 = np.empty(5)
+        dsyn = np.empty(self.N) if want_dsyn else None
+        self._chk(self._lib.gh_leapfrog(self._h, ptr(x), ptr(p0), float(dt), int(L), ptr(low),
+                                        ptr(high), float(u), C.byref(acc), ptr(out5), ptr(dsyn)))
+        return x, bool(acc.value), out5, dsyn
+
+    # -- measurement --------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._lib.gh_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms, n, b = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return {"sweep_ms": ms.value, "sweeps": n.value, "bytes_per_sweep": b.value}

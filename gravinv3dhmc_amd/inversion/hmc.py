@@ -1,0 +1,218 @@
+"""Hamiltonian Monte Carlo sampler whose trajectories run on the GPU.
+
+Host-side mirror of the reference's `inversion.hmc` (inversion/hmc.py:29-403): class
+`HamitonianMC` and function `HMCSample` with the reference's names, arguments, console
+lines and sample-file formats.  The random stream stays NumPy's legacy global generator in
+the reference's draw order (randint for L -> randn(M) for the momentum -> rand() for the
+Metropolis test, hmc.py:297,95,164), so accepted-sample sequences can be compared with the
+reference run for run.
+
+The leapfrog loop itself (hmc.py:85-177) is one call into libgravhmc per trajectory
+(`gh_chain_trajectory`): the chain state lives in HBM, each leapfrog step is one fused sweep
+of the kernel matrix.
+"""
+import os
+import sys
+
+import numpy as np
+from scipy.sparse import coo_matrix
+
+
+class HamitonianMC(object):
+    def __init__(self, UserDefinedModel):
+        if not hasattr(UserDefinedModel, "_engine"):
+            raise TypeError("HamitonianMC needs a device-resident model (GravMagModule); "
+                            "there is no host implementation of the trajectory")
+        self.invert_Mass = None
+        self.model = UserDefinedModel
+        self.dobs = np.zeros(2)
+        self.boundaries = np.zeros((2, 2))
+        self.dt = None
+        self.Lrange = [10, 50]
+        self.seed = None
+        self.myrank = None
+        self.save_folder = None
+        self.cache = {}
+        self._chain_x = None  # identity of the host vector the device chain state mirrors
+
+    def _kinetic(self, p):
+        """Kinetic energy with the (identity) inverse mass matrix (hmc.py:44-50)."""
+        return np.dot(self.invert_Mass @ p, p) * 0.5
+
+    def _misfit_and_grad(self, x, alpha):
+        """One potential evaluation through the drop-in entry point (hmc.py:71-78)."""
+        return self.model.misfit_and_grad(x, self.aprior_model, self.low, self.high,
+                                          self.constraint, self.log_factor, alpha,
+                                          regulization=self.regularization, beta=self.beta)
+
+    def _kernelw(self):
+        return self.model.kernelw()
+
+    # ------------------------------------------------------------------ trajectory
+    def _leapfrog(self, xcur, dt, L, alpha, fignum):
+        """One trajectory (hmc.py:85-177).  Draws the momentum and the Metropolis variate
+        from the global NumPy stream like the reference, runs the L steps on the device.
+        Returns (x, U, dsyn, AcceptFlag, U_data, U_model)."""
+        n = len(xcur)
+        pcur = np.random.randn(n) * self.Sigma
+        if self.constraint != 'mandatory':
+            return self._leapfrog_unfused(xcur, pcur, dt, L, alpha)
+        eng = self.model._engine
+        self.model._use_reg(self.regularization, alpha, self.beta, self.aprior_model)
+        if self._chain_x is None or self._chain_x is not xcur:
+            eng.chain_init(xcur, self.low, self.high)
+        u = np.random.rand()
+        accepted, out5 = eng.chain_trajectory(pcur, dt, L, u)
+        xnew = eng.chain_get_x() if accepted else xcur
+        self._chain_x = xnew
+        return xnew, out5[0], _LazyDsyn(eng), accepted, out5[1], out5[2]
+
+    def _leapfrog_unfused(self, xcur, pcur, dt, L, alpha):
+        """'logarithmic' constraint (x is not the weighted model): the vector updates stay on
+        the host, every potential evaluation is a device call (gh_misfit_and_grad)."""
+        pnew = pcur * 1.0
+        xnew = xcur * 1.0
+        K = self._kinetic(pnew)
+        U, grad, dsyn, U_data, U_model = self._misfit_and_grad(xnew, alpha)
+        Hcur = K + U
+        dsyn_new, Unew, Unew_data, Unew_model = dsyn.copy(), U, U_data, U_model
+        pnew -= dt * grad * 0.5
+        for i in range(L):
+            xnew += dt * pnew
+            Unew, grad, dsyn_new, Unew_data, Unew_model = self._misfit_and_grad(xnew, alpha)
+            if i < L - 1:
+                pnew -= dt * grad
+            else:
+                pnew -= dt * grad * 0.5
+        pnew = -pnew
+        Hnew = self._kinetic(pnew) + Unew
+        AcceptFlag = False
+        u = np.random.rand()
+        if Hnew < Hcur or u < np.exp(-(Hnew - Hcur)):
+            xcur, U, dsyn, AcceptFlag = xnew, Unew, dsyn_new, True
+            U_data, U_model = Unew_data, Unew_model
+        return xcur, U, dsyn, AcceptFlag, U_data, U_model
+
+    # ------------------------------------------------------------------ sample files
+    def _save_models_add(self, x):
+        with open(self.save_folder + "/" + "model" + ".dat", "a") as f:
+            np.savetxt(f, x, fmt='%.8f', delimiter=' ')
+
+    def _save_misfit_add(self, misfit):
+        with open(self.save_folder + "/" + "misfit" + ".dat", "a") as f:
+            np.savetxt(f, misfit, fmt='%.8f', delimiter=' ')
+
+    def _to_mw(self, x):
+        if self.constraint == 'logarithmic':
+            return (self.low + self.high * np.e ** (self.log_factor * x)) / \
+                   (1 + np.e ** (self.log_factor * x))
+        elif self.constraint == 'mandatory':
+            return x
+        raise ValueError("Please choose right boundary constraint(mandatory, logarithmic)!")
+
+    def sample(self, nsamples, ndraws, **kwargs):
+        """Draw until ndraws+nsamples proposals have been ACCEPTED (hmc.py:252-343)."""
+        if not os.path.exists(self.save_folder):
+            os.makedirs(self.save_folder)
+        if os.path.exists(self.save_folder + "/" + "model" + ".dat"):
+            os.remove(self.save_folder + "/" + "model" + ".dat")
+        np.random.seed(self.seed)
+        _, WmInv, _ = self._kernelw()
+        mw = self.initial_model
+        print("initial mw:", mw)
+        print("mw boundaryies:", self.high, self.low)
+        if self.constraint == 'logarithmic':
+            x = (1 / self.log_factor) * np.log((mw - self.low) / (self.high - mw))
+            print("Using logarithmic boundary constraint.")
+        elif self.constraint == 'mandatory':
+            x = mw
+            print("Using mandatory boundary constraint.")
+        else:
+            raise ValueError("Please choose right boundary constraint(mandatory, logarithmic)!")
+        data_size = self.dobs.shape[0]
+        model_size = self.initial_model.shape[0]
+        misfit = np.zeros((1, 7))
+        m_cache = np.zeros((1, len(x)))
+        ncount = 0
+        i = 0
+        alpha = self.RegulFactor
+        self._chain_x = None
+        while i < ndraws + nsamples:
+            L = np.random.randint(self.Lrange[0], self.Lrange[1] + 1)
+            x, U, _, AcceptFlag, U_data, U_model = self._leapfrog(x, self.dt, L, alpha, i)
+            U_data_normed = U_data / data_size
+            U_model_normed = U_model / model_size
+            U_normed = U_data_normed + alpha * U_model_normed
+            if AcceptFlag:
+                if i >= ndraws:
+                    misfit[0, :] = (U, U_data, U_model, U_normed, U_data_normed, U_model_normed,
+                                    alpha)
+                    self._save_misfit_add(misfit)
+                    m = WmInv @ self._to_mw(x)
+                    m_cache[0, :] = m.copy()
+                    self._save_models_add(m_cache)
+                i += 1
+            ncount += 1
+            if i > -1:
+                msg = "chain {}: {:.2%}, misfit(total, data, alpha, model)=({:.7f},{:.7f},{:.2f},{:.7f}) " \
+                      "-- accept ratio {:.2%}\n". \
+                    format(self.myrank, i / (ndraws + nsamples), U_normed, U_data_normed, alpha,
+                           U_model_normed, i / ncount)
+                print(msg)
+                sys.stdout.flush()
+        return x
+
+
+class _LazyDsyn(object):
+    """dsyn of the current chain state, fetched from the device only if somebody reads it
+    (the reference's sample loop discards it, hmc.py:299)."""
+
+    def __init__(self, engine):
+        self._engine = engine
+        self._v = None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._v is None:
+            self._v = self._engine.chain_get_dsyn()
+        return self._v if dtype is None else self._v.astype(dtype)
+
+    def copy(self):
+        return np.array(self)
+
+
+def HMCSample(model, nsamples, ndraws, delta, Lrange,
+              initial_model, aprior_model, boundaries, constraint, log_factor, dobs,
+              adaptiveRegul, RegulRate, RegulFactor, regularization, beta,
+              seed, Sigma, nbest=100, myrank=0, save_folder="mychain",
+              plotsamples=False, im=[0, 0]):
+    """Set up one chain and run it (hmc.py:358-403).  Chains of different ranks are
+    independent: seed + myrank, folder save_folder + str(myrank)."""
+    chain = HamitonianMC(model)
+    chain.myrank = myrank
+    chain.save_folder = save_folder + str(myrank)
+    chain.seed = seed + myrank
+    chain.nbest = nbest
+    nt = boundaries.shape[0]
+    chain.boundaries = boundaries
+    chain.constraint = constraint
+    chain.log_factor = log_factor
+    chain.Lrange = Lrange
+    chain.dt = delta
+    chain.Sigma = Sigma
+    chain.adaptiveRegul = adaptiveRegul
+    chain.RegulRate = RegulRate
+    chain.RegulFactor = RegulFactor
+    chain.regularization = regularization
+    chain.beta = beta
+    row = np.arange(0, nt)
+    chain.invert_Mass = coo_matrix((np.ones(nt), (row, row))).tocsr()
+    _, _, Wm = chain._kernelw()
+    chain.low = Wm @ chain.boundaries[:, 0]
+    chain.high = Wm @ chain.boundaries[:, 1]
+    chain.im = im
+    chain.initial_model = Wm @ initial_model
+    chain.aprior_model = Wm @ aprior_model
+    chain.dobs = dobs
+    chain.plotsamples = plotsamples
+    chain.sample(nsamples, ndraws)
+    return chain

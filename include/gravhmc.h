@@ -1,0 +1,145 @@
+/*
+ * gravhmc.h -- C-ABI of the MI355X-native HMC gravity-inversion hot path (libgravhmc.so).
+ *
+ * The reference (ChuWeiEr/GravInv3DHMC) is pure Python with no FFI/plugin registry; the seam
+ * its sampler uses is the duck-typed model object of inversion/hmc.py:30-32,71-83 (calls
+ * `model.kernelw()` and `model.misfit_and_grad(...)`) and, one level down, the native kernels
+ * `gravmag/_prism.pyx:265-290` (`_prism.gz`) and `gravmag/_tesseroid_numba.py:32-71,335`
+ * (`_tesseroid_numba.gz`).  Every entry point below names the reference interface it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: opaque context, host pointers to caller-owned contiguous float64 buffers, sizes
+ *     as int64_t.  No Python / torch types.  Calls are synchronous on return.
+ *   - every function returns 0 on success or a negative gh_status; the text of the last error
+ *     is available from gh_last_error(ctx) (or gh_last_error(NULL) for gh_create failures).
+ *   - a context is bound to one GPU and one HIP stream and is NOT thread-safe (the reference is
+ *     single-threaded per chain; chains are separate processes, hmc.py:367-369).
+ *   - dense matrices are column-major N x M ("Fortran order": one cell = one contiguous column
+ *     of N observations), the layout the reference ends up with for Aw (potential.py:259).
+ *   - there is no CPU fallback: without a usable HIP device gh_create fails.
+ */
+#ifndef GRAVHMC_H
+#define GRAVHMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gh_ctx gh_ctx;
+
+typedef enum {
+    GH_OK = 0,
+    GH_ERR_ARG = -1,      /* bad argument / call order (ValueError in the reference) */
+    GH_ERR_HIP = -2,      /* HIP runtime error, text in gh_last_error */
+    GH_ERR_NOMEM = -3,    /* device allocation failed */
+    GH_ERR_OVERFLOW = -4, /* tesseroid subdivision stack > 100 entries (OverflowError,
+                             _tesseroid_numba.py:53-54) */
+    GH_ERR_UNSUPPORTED = -5,
+    GH_ERR_COMM = -6      /* collective layer error */
+} gh_status;
+
+enum { GH_CELL_PRISM = 0, GH_CELL_TESSEROID = 1 };
+/* potential.py:827-836 `regulization` strings */
+enum { GH_REG_DAMPING = 0, GH_REG_SMOOTHNESS = 1, GH_REG_MS = 2, GH_REG_TV = 3 };
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* One inversion problem (N observations, M active cells) on GPU `device`. */
+int gh_create(gh_ctx **out, int device, int64_t N, int64_t M);
+void gh_destroy(gh_ctx *ctx);
+const char *gh_last_error(const gh_ctx *ctx);
+/* Device facts for logs/benchmarks: name (<=255 chars), CU count, total memory in bytes. */
+int gh_device_info(const gh_ctx *ctx, char *name256, int *cus, int64_t *mem_bytes);
+
+/* ---- sensitivity matrix G (the reference's `kernel` / `A`) ---------------------------- */
+
+/* Observation points: (x, y, z) in m for prisms, (lon, lat, height) in deg/deg/m for
+ * tesseroids.  Replaces the xp,yp,zp / lon,lat,height arguments of prism.gz (prism.py:911)
+ * and tesseroid.gz (tesseroid.py:421). */
+int gh_set_obs(gh_ctx *ctx, const double *a, const double *b, const double *c);
+/* Active cells in mesh order, M x 6 row-major: x1,x2,y1,y2,z1,z2 (prism) or
+ * w,e,s,n,top,bottom (tesseroid); `ratio` is the tesseroid distance-size ratio
+ * (tesseroid.py:77, 1.6 for gz), ignored for prisms. */
+int gh_set_cells(gh_ctx *ctx, const double *bounds6, int kind, double ratio);
+/* Assemble the dense kernel on the device.  Replaces the Python cell loop + native calls of
+ * prism.py:291-316 -> _prism.pyx:265-290, or tesseroid.py:189-232 -> _tesseroid_numba.py:32-71,
+ * including the unit scaling G*SI2MGAL.  For tesseroids returns GH_ERR_OVERFLOW if any
+ * (obs, cell) pair needed more than 100 stack entries. */
+int gh_build_G(gh_ctx *ctx);
+/* Tesseroid diagnostics of the last gh_build_G: number of cells for which the reference
+ * would emit its "stopped dividing" RuntimeWarning (tesseroid.py:228-229) and the total
+ * number of GLQ leaf evaluations. */
+int gh_kernel_stats(const gh_ctx *ctx, int64_t *warn_cells, int64_t *leaves);
+/* Explicit dense kernel from the host instead of assembling it (A[i + j*ld] if
+ * fortran_order else A[i*ld + j]). */
+int gh_upload_G(gh_ctx *ctx, const double *A, int64_t ld, int fortran_order);
+/* Copy the device matrix back, column-major with leading dimension ld >= N (what
+ * GravMagModule.kernelw() hands out as `Aw`, potential.py:584-589). */
+int gh_download_G(gh_ctx *ctx, double *A, int64_t ld);
+/* Noise-free forward model d = G * rho for the UNWEIGHTED kernel (the `result` output of
+ * prism.gz / tesseroid.gz with mesh densities rho). */
+
+/* Sensitivity weighting, potential.py:232-264: wm_j = (sum_i G_ij^2)^weightfactor, G <- G *
+ * diag(1/wm) in place (columns with zero norm are left untouched, wm_j = 0).  wm_out (M)
+ * receives the diagonal of the reference's Wm. */
+int gh_weight(gh_ctx *ctx, double weightfactor, double *wm_out);
+
+/* ---- potential (inversion/potential.py:688-845) ---------------------------------------- */
+
+/* Observed data and, optionally, the field of fixed cells (`fixed=True, grav_fix=...`,
+ * potential.py:700-703); pass NULL when unused. */
+int gh_set_data(gh_ctx *ctx, const double *dobs, const double *grav_fix_or_null);
+/* Regulariser: kind (GH_REG_*), alpha (hmc RegulFactor), beta (MS/TV), mesh shape
+ * (nz,ny,nx) for Smoothness/TV (must satisfy nz*ny*nx == M), weighted prior
+ * mwapr (M).  Needs gh_weight first for MS (uses wm^2 = diag(WmSquare)). */
+int gh_set_reg(gh_ctx *ctx, int kind, double alpha, double beta, const int shape3[3],
+               const double *mwapr);
+/* d = Aw * mw            (potential.py:698, np.dot(self.Aw, mw)) */
+int gh_forward(gh_ctx *ctx, const double *mw, double *dpre);
+/* g = Aw^T * r           (potential.py:708, np.dot(self.Aw.T, r)) */
+int gh_adjoint(gh_ctx *ctx, const double *r, double *g);
+/* Drop-in for GravMagModule.misfit_and_grad with constraint='mandatory'
+ * (potential.py:812-845): out3 = (misfit, data_value, model_value), grad (M), dpre (N,
+ * without grav_fix). */
+int gh_misfit_and_grad(gh_ctx *ctx, const double *x, double out3[3], double *grad,
+                       double *dpre);
+
+/* ---- HMC chain (inversion/hmc.py:85-177) ----------------------------------------------- */
+
+/* Start (or restart) a chain at weighted model x0 with per-cell bounds low/high (weighted,
+ * hmc.py:391-393).  Evaluates the potential at x0 once and keeps x, residual and gradient
+ * resident on the device. */
+int gh_chain_init(gh_ctx *ctx, const double *x0, const double *low, const double *high);
+/* One trajectory of L leapfrog steps with clamp-and-reflect bounds and the Metropolis test
+ * (HamitonianMC._leapfrog, hmc.py:85-177).  p0 = randn(M)*Sigma and u = rand() are drawn by
+ * the caller in the reference's RNG order (hmc.py:297,95,164).  out5 = (U, U_data, U_model,
+ * Hcur, Hnew) with U.. of the state the chain is left in (proposal if accepted, else the
+ * starting point).  The device executes one fused sweep of G per leapfrog step (adjoint of
+ * step s and forward of step s+1 share the sweep) plus one adjoint-only sweep. */
+int gh_chain_trajectory(gh_ctx *ctx, const double *p0, double dt, int L, double u,
+                        int *accepted, double out5[5]);
+int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
+int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state */);
+/* Stateless convenience with the signature SURVEY 8b lists: init + trajectory + readback. */
+int gh_leapfrog(gh_ctx *ctx, double *x_inout, const double *p0, double dt, int L,
+                const double *low, const double *high, double u, int *accepted,
+                double out5[5], double *dsyn_or_null);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+
+/* HIP-event timing of the G sweeps (the dominant kernel) on the context's stream.
+ * enable != 0 starts recording (and clears the counters).  gh_profile_read sums the recorded
+ * intervals: total milliseconds, number of sweep launches, bytes of G each launch reads. */
+int gh_profile_enable(gh_ctx *ctx, int enable);
+int gh_profile_read(gh_ctx *ctx, double *sweep_ms, int64_t *sweep_launches,
+                    int64_t *bytes_per_sweep);
+/* Block until everything queued on the context's stream has finished. */
+int gh_synchronize(gh_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAVHMC_H */

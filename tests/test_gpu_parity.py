@@ -1,0 +1,441 @@
+"""GPU suite (`-m gpu`): the HIP path, called through the C-ABI (ctypes -> libgravhmc.so),
+against the CPU oracle on the same seeded inputs, against the golden vectors generated from
+the reference, and -- at BASELINE.json's full size -- through size-independent properties.
+
+Tolerances (fp64, stated per test):
+  * kernel entries: |dK| <= 1e-10 * max|K| (device libm vs glibc inside an 8-term
+    alternating sum); forward data d = G rho: <= 1e-10 relative (north_star)
+  * GEMV / potential / trajectories: 1e-11 .. 1e-9 relative (summation order differs)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import gold
+from helpers import c1_inputs, relmax
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(built_lib):
+    import gravinv3dhmc_amd as g
+    return g
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+# ----------------------------------------------------------------------------- assembly
+
+def test_prism_entries_singular_geometries(G):
+    g = gold("prism_cases.npz")
+    eng = G.Engine(g["xp"].size, g["cells"].shape[0])
+    eng.set_obs(g["xp"], g["yp"], g["zp"])
+    eng.set_cells(g["cells"], 0)
+    eng.build_G()
+    K = eng.download_G()
+    assert np.isfinite(K).all()
+    err = np.abs(K - g["K"]).max() / np.abs(g["K"]).max()
+    print("prism singular cases: max |dK|/max|K| = %.3e" % err)
+    assert err < 1e-10
+    eng.close()
+
+
+def test_c1_kernel_and_forward(G, orc):
+    g = gold("c1_spot.npz")
+    mesh, xp, yp, zp = c1_inputs()
+    mesh.addprop('density', g["rho"])
+    gz, K = G.prism.gz(xp, yp, zp, mesh)
+    assert K.shape == (600, 6000) and K.flags.f_contiguous
+    e_entries = np.abs(K[g["ii"], g["jj"]] - g["Kij"]).max() / np.abs(g["Kij"]).max()
+    e_col = relmax(np.sqrt((K ** 2).sum(0)), g["colnorm"])
+    e_gz = np.abs(gz - g["gz"]).max() / np.abs(g["gz"]).max()
+    e_gz_pt = np.abs((gz - g["gz"]) / g["gz"]).max()
+    print("C1: entries %.3e colnorm %.3e d_obs %.3e (pointwise %.3e)" % (e_entries, e_col, e_gz, e_gz_pt))
+    assert e_entries < 1e-10 and e_col < 1e-11
+    assert e_gz_pt < 1e-10          # north_star: reference d_obs to <= 1e-10 relative
+    Ko = orc.prism_gz_kernel(xp, yp, zp, mesh.cell_bounds())
+    assert np.abs(K - Ko).max() / np.abs(Ko).max() < 1e-10
+
+
+def test_tesseroid_entries(G):
+    g = gold("tess_cases.npz")
+    eng = G.Engine(g["lon"].size, g["bounds"].shape[0])
+    eng.set_obs(g["lon"], g["lat"], g["h"])
+    eng.set_cells(g["bounds"], 1, 1.6)
+    eng.build_G()
+    K = eng.download_G()
+    st = eng.kernel_stats()
+    err = np.abs(K - g["K"]).max() / np.abs(g["K"]).max()
+    print("tess coarse-global: %.3e leaves %d (ref %d)" % (err, st["leaves"], int(g["leaves"])))
+    assert err < 1e-10
+    assert st["leaves"] == int(g["leaves"]) and st["warn_cells"] == 0   # same leaf SET
+    d = eng.forward(g["rho"])
+    assert np.abs((d - g["gz"]) / g["gz"]).max() < 1e-10
+    eng.close()
+    # near field / thin cells / poles
+    eng = G.Engine(g["n_lon"].size, g["n_cells"].shape[0])
+    eng.set_obs(g["n_lon"], g["n_lat"], g["n_h"])
+    eng.set_cells(g["n_cells"], 1, 1.6)
+    eng.build_G()
+    K = eng.download_G()
+    st = eng.kernel_stats()
+    err = np.abs(K - g["n_K"]).max() / np.abs(g["n_K"]).max()
+    print("tess near-field: %.3e leaves %d (ref %d)" % (err, st["leaves"], int(g["n_leaves"])))
+    assert err < 1e-10
+    assert st["leaves"] == int(g["n_leaves"])
+    assert st["warn_cells"] == int((g["n_err"] != 0).sum())
+    eng.close()
+
+
+def test_tesseroid_frontend_warns_and_matches(G):
+    g = gold("tess_cases.npz")
+    mesh = G.mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3e6), (-300000, 30, 30))
+    mesh.addprop('density', g["rho"])
+    res, K = G.tesseroid.gz(g["lon"], g["lat"], g["h"], mesh)
+    assert np.abs((res - g["gz"]) / g["gz"]).max() < 1e-10 and K.shape == g["K"].shape
+
+
+# ----------------------------------------------------------------------- GEMV primitives
+
+@pytest.mark.parametrize("N,M", [(1, 1), (17, 5), (42, 120), (600, 257), (625, 1000), (1024, 64),
+                                 (1025, 300), (2500, 123), (4097, 77), (7381, 300), (10000, 513),
+                                 (16384, 40)])
+def test_forward_adjoint_vs_numpy(G, N, M):
+    rng = np.random.default_rng(N * 1000 + M)
+    A = np.asfortranarray(rng.normal(size=(N, M)))
+    x, r = rng.normal(size=M), rng.normal(size=N)
+    eng = G.Engine(N, M)
+    eng.upload_G(A)
+    assert np.array_equal(eng.download_G(), A)
+    d, g = eng.forward(x), eng.adjoint(r)
+    scale_d = np.abs(A) @ np.abs(x)
+    scale_g = np.abs(A.T) @ np.abs(r)
+    assert (np.abs(d - A @ x) / scale_d).max() < 1e-14 * max(1, np.sqrt(M))
+    assert (np.abs(g - A.T @ r) / scale_g).max() < 1e-14 * max(1, np.sqrt(N))
+    # row-major upload path gives the same device matrix
+    eng2 = G.Engine(N, M)
+    eng2.upload_G(np.ascontiguousarray(A))
+    assert np.array_equal(eng2.download_G(), A)
+    eng.close()
+    eng2.close()
+
+
+def test_weighting_vs_oracle(G, orc):
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(333, 211)) * rng.uniform(0.01, 10, size=211)
+    A[:, 7] = 0.0                                     # zero column: left untouched, wm = 0
+    eng = G.Engine(333, 211)
+    eng.upload_G(A)
+    wm = eng.weight(0.5)
+    Aw_o, wm_o = orc.col_weight(A, 0.5)
+    assert relmax(wm, wm_o) < 1e-14 and wm[7] == 0.0
+    assert relmax(eng.download_G(), Aw_o) < 1e-14
+    eng.close()
+    eng = G.Engine(333, 211)
+    eng.upload_G(A)
+    wm = eng.weight(0.3)
+    _, wm_o = orc.col_weight(A, 0.3)
+    assert relmax(wm, wm_o) < 1e-13
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- potential
+
+def _small_engine(G, p, fix=False):
+    eng = G.Engine(*p["Aw"].shape)
+    eng.upload_G(p["Aw"])
+    eng.set_data(p["dobs"], p["gfix"] if fix else None)
+    return eng
+
+
+def test_misfit_and_grad_golden(G):
+    p = gold("potential_small.npz")
+    from gravinv3dhmc_amd import mesher
+    mesh = mesher.PrismMesh(tuple(p["mrange"]), tuple(p["mspacing"]))
+    worst = 0.0
+    for fix, tag in ((False, ""), (True, "_fix")):
+        eng = G.Engine(*p["Aw"].shape)
+        eng.set_obs(p["xp"], p["yp"], p["zp"])
+        eng.set_cells(mesh.cell_bounds(), 0)
+        eng.build_G()
+        wm = eng.weight(0.5)
+        assert relmax(wm, p["wm"]) < 1e-11
+        eng.set_data(p["dobs"], p["gfix"] if fix else None)
+        for reg in ("Damping", "MS", "Smoothness", "TV"):
+            eng.set_reg(reg, float(p["alpha"]), float(p["beta"]), p["shape"], p["mwapr"])
+            for i, x in enumerate(p["xs"]):
+                m, grad, dpre, dv, mv = eng.misfit_and_grad(x)
+                errs = [abs(m - p[reg + tag + "_misfit"][i]) / abs(m),
+                        relmax(grad, p[reg + tag + "_grad"][i]),
+                        relmax(dpre, p[reg + tag + "_dpre"][i]),
+                        abs(dv - p[reg + tag + "_data"][i]) / abs(dv),
+                        abs(mv - p[reg + tag + "_model"][i]) / max(abs(mv), 1e-300)]
+                worst = max(worst, max(errs))
+                assert max(errs) < 1e-10, (reg, tag, i, errs)
+        eng.close()
+    print("misfit_and_grad worst rel err %.3e" % worst)
+
+
+def test_error_behaviour(G):
+    p = gold("potential_small.npz")
+    eng = _small_engine(G, p)
+    with pytest.raises(ValueError):
+        eng.set_reg("Tikhonov", 1.0, 0.01, p["shape"], p["mwapr"])
+    with pytest.raises(ValueError):                      # MS before weighting
+        eng.set_reg("MS", 1.0, 0.01, p["shape"], p["mwapr"])
+    with pytest.raises(ValueError):                      # TV on a shape that is not the mesh
+        eng.set_reg("TV", 1.0, 0.01, (1, 1, 7), p["mwapr"])
+    with pytest.raises(ValueError):                      # potential before the regulariser
+        eng.misfit_and_grad(p["xs"][0])
+    with pytest.raises(ValueError):
+        eng.chain_trajectory(np.zeros(eng.M), 0.01, 5, 0.5)   # chain before chain_init
+    eng.close()
+    with pytest.raises(NotImplementedError):
+        G.Engine(20000, 10)                              # needs row panels / sharding
+    with pytest.raises(ValueError):
+        G.Engine(0, 10)
+
+
+# --------------------------------------------------------------------------- trajectories
+
+def test_leapfrog_golden(G):
+    g = gold("leapfrog_small.npz")
+    p = gold("potential_small.npz")
+    eng = _small_engine(G, p)
+    eng._lib.gh_weight  # noqa: B018  (weights come from the fixture: Aw is already weighted)
+    worst = 0.0
+    for i in range(int(g["n"])):
+        k = lambda s: g["%d_%s" % (i, s)]
+        reg = str(k("reg"))
+        if reg == "MS":
+            continue  # needs wm on the device: covered by test_leapfrog_ms_via_module
+        eng.set_reg(reg, 1.0, 0.001, p["shape"], k("mwapr"))
+        x, acc, out, dsyn = eng.leapfrog(k("x_in"), k("p0"), float(k("dt")), int(k("L")),
+                                         k("low"), k("high"), float(k("u")))
+        assert acc == bool(k("acc")), i
+        errs = [relmax(x, k("x_out")), abs(out[0] - float(k("U"))) / abs(out[0]),
+                abs(out[1] - float(k("Ud"))) / abs(out[1]), relmax(dsyn, k("dsyn"))]
+        worst = max(worst, max(errs))
+        assert max(errs) < 1e-9, (i, reg, errs)
+    print("leapfrog worst rel err %.3e" % worst)
+    eng.close()
+
+
+def _module_small(G, p, **kw):
+    return G.GravMagModule(p["dobs"], tuple(p["mrange"]), tuple(p["mspacing"]),
+                           (p["xp"], p["yp"], p["zp"]), verbose=False, **kw)
+
+
+def test_leapfrog_ms_via_module(G):
+    g = gold("leapfrog_small.npz")
+    p = gold("potential_small.npz")
+    gm = _module_small(G, p)
+    eng = gm._engine
+    n = 0
+    for i in range(int(g["n"])):
+        k = lambda s: g["%d_%s" % (i, s)]
+        if str(k("reg")) != "MS":
+            continue
+        eng.set_reg("MS", 1.0, 0.001, p["shape"], k("mwapr"))
+        x, acc, out, dsyn = eng.leapfrog(k("x_in"), k("p0"), float(k("dt")), int(k("L")),
+                                         k("low"), k("high"), float(k("u")))
+        assert acc == bool(k("acc")), i
+        assert relmax(x, k("x_out")) < 1e-9 and abs(out[0] - float(k("U"))) < 1e-9 * abs(out[0])
+        n += 1
+    assert n == 8
+
+
+def test_module_api_and_drop_in(G, orc):
+    p = gold("potential_small.npz")
+    gm = _module_small(G, p, fixed=True, grav_fix=p["gfix"])
+    Aw, WmInv, Wm = gm.kernelw()
+    assert Aw.shape == (42, 120) and relmax(np.asarray(Aw), p["Aw"]) < 1e-10
+    assert relmax(Wm.diagonal(), p["wm"]) < 1e-11 and gm.mshape == tuple(p["shape"])
+    assert relmax(WmInv @ (Wm @ np.arange(120.0)), np.arange(120.0)) < 1e-15
+    x = p["xs"][1]
+    for reg in ("Damping", "MS", "Smoothness", "TV"):
+        out = gm.misfit_and_grad(x, p["mwapr"], None, None, 'mandatory', 1000, 0.7,
+                                 regulization=reg, beta=0.001)
+        assert abs(out[0] - p[reg + "_fix_misfit"][1]) < 1e-10 * abs(out[0])
+        assert relmax(out[1], p[reg + "_fix_grad"][1]) < 1e-10
+    with pytest.raises(ValueError):
+        gm.misfit_and_grad(x, p["mwapr"], None, None, 'reflective', 1000, 0.7)
+    with pytest.raises(ValueError):
+        gm.misfit_and_grad(x, p["mwapr"], None, None, 'mandatory', 1000, 0.7, regulization="L1")
+    # logarithmic constraint = logistic map on the host, same device evaluation
+    lo, hi = -2.0 * p["wm"], 2.0 * p["wm"]
+    xx = np.linspace(-0.003, 0.003, 120)
+    mw = (lo + hi * np.e ** (1000 * xx)) / (1 + np.e ** (1000 * xx))
+    a = gm.misfit_and_grad(xx, p["mwapr"], lo, hi, 'logarithmic', 1000, 0.7)
+    b = gm.misfit_and_grad(mw, p["mwapr"], None, None, 'mandatory', 1000, 0.7)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+def test_chain_state_matches_stateless_and_is_deterministic(G):
+    p = gold("potential_small.npz")
+    gm = _module_small(G, p)
+    eng = gm._engine
+    wm = p["wm"]
+    M = wm.size
+    eng.set_reg("TV", 1.0, 0.001, p["shape"], 0.001 * wm)
+    low, high = 0.0 * wm, 0.02 * wm
+    rng = np.random.default_rng(11)
+    trajs = [(rng.normal(size=M) * 0.3, int(rng.integers(5, 21)), float(rng.uniform())) for _ in range(12)]
+
+    def run():
+        eng.chain_init(0.001 * wm, low, high)
+        out = []
+        for p0, L, u in trajs:
+            acc, o = eng.chain_trajectory(p0, 0.02, L, u)
+            out.append((acc, o.copy(), eng.chain_get_x()))
+        return out
+
+    a, b = run(), run()
+    n_acc = sum(t[0] for t in a)
+    assert 0 < n_acc < len(trajs)                      # accept and reject both taken
+    for (aa, ao, ax), (ba, bo, bx) in zip(a, b):
+        assert aa == ba and np.array_equal(ao, bo) and np.array_equal(ax, bx)   # bitwise
+    # the chain (device-resident state, cached evaluation) equals stateless gh_leapfrog calls
+    x = 0.001 * wm
+    for (p0, L, u), (acc, o, xs) in zip(trajs, a):
+        x, acc2, o2, _ = eng.leapfrog(x, p0, 0.02, L, low, high, u)
+        assert acc2 == acc and np.array_equal(x, xs) and np.array_equal(o2, o)
+
+
+def test_hmcsample_end_to_end_small(G, tmp_path, capsys):
+    """Whole chains against the reference's own runs (stdout lines + sample files)."""
+    c = gold("chain_small.npz")
+    p = gold("potential_small.npz")
+    M = p["wm"].size
+    for tag in ("a", "b"):
+        dt, Sigma, lo, hi, n = c[tag + "_cfg"]
+        gm = _module_small(G, p)
+        folder = str(tmp_path / ("run_%s_chain" % tag))
+        capsys.readouterr()
+        G.HMCSample(gm, int(n), 0, float(dt), [5, 20], np.full(M, 0.001 + lo), np.full(M, 0.001),
+                    np.c_[np.full(M, lo), np.full(M, hi)], "mandatory", 1000, p["dobs"],
+                    "Fixed", 0.8, 1.0, str(c[tag + "_reg"]), 0.001, 100, float(Sigma), nbest=100,
+                    myrank=0, save_folder=folder)
+        lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain ")]
+        ref_lines = [str(s) for s in c[tag + "_lines"]]
+        assert len(lines) == len(ref_lines)               # same accept/reject sequence
+        assert lines == ref_lines                         # 7 printed decimals, accept ratios
+        mis = np.loadtxt(folder + "0/misfit.dat")
+        mod = np.loadtxt(folder + "0/model.dat")
+        np.testing.assert_allclose(mis, c[tag + "_misfit"], atol=2e-8, rtol=1e-9)
+        np.testing.assert_allclose(mod, c[tag + "_model"], atol=2e-8)
+        gm._engine.close()
+
+
+def test_c1_chain_rows_and_posterior_stats(G, tmp_path, capsys):
+    g = gold("c1_chain.npz")
+    mesh, xp, yp, zp = c1_inputs()
+    gm = G.GravMagModule(g["dobs"], (0, 2000, 0, 3000, 0, 1000), (100, 100, 100), (xp, yp, zp),
+                         verbose=False)
+    M = 6000
+    folder = str(tmp_path / "c1_chain")
+    G.HMCSample(gm, 5, 0, 0.01, [5, 20], np.full(M, 0.001), np.full(M, 0.001),
+                np.c_[np.zeros(M), np.ones(M)], "mandatory", 1000, g["dobs"], "Fixed", 0.8, 1.0,
+                "Damping", 0.001, 100, 0.001, save_folder=folder)
+    capsys.readouterr()
+    mis = np.loadtxt(folder + "0/misfit.dat")
+    np.testing.assert_allclose(mis, g["misfit"], rtol=1e-8, atol=2e-8)
+    mod = np.loadtxt(folder + "0/model.dat")
+    np.testing.assert_allclose(mod[-1], g["model_last"], atol=2e-8)
+
+
+def test_realdata_log_lines_on_gpu(G, tmp_path, capsys):
+    """example/realdata/logout_T0.txt, chain 0: tesseroid assembly on the carved segment mesh,
+    weighting, fixed cells, Damping and the trajectories all on the device."""
+    e = gold("example_inputs.npz")
+    obs, topo = e["real_obs"], e["real_topo"]
+    gm = G.GravMagModule(obs[:, 3], (106.5, 118.5, 16, 28, 2000, -60000),
+                         ([-1000, -2000, -5000], 0.5, 0.5), (obs[:, 0], obs[:, 1], obs[:, 2]),
+                         fixed=True, grav_fix=e["real_gravsea"], mseg=True,
+                         mdivisionsection=[2000, -5000, -15000, -60000], coordinate="spherical",
+                         verbose=False, mtopo=(topo[:, 0], topo[:, 1], topo[:, 2]))
+    assert gm.mshape == (21, 24, 24) and gm._engine.M == 10427
+    keep = np.ones(gm.mesh.size, bool)
+    keep[np.array(gm.mask)] = False
+    M = 10427
+    wm = gm.Wm.diagonal()
+    np.testing.assert_allclose((0.01 * wm)[:3], e["real_T0_initial_mw_head"], rtol=5e-8)
+    np.testing.assert_allclose((0.01 * wm)[-3:], e["real_T0_initial_mw_tail"], rtol=5e-8)
+    capsys.readouterr()
+    G.HMCSample(gm, 6, 0, 0.01, [5, 20], np.full(M, 0.01), e["real_aprior"][keep],
+                np.c_[np.full(M, -0.5), np.full(M, 0.5)], "mandatory", 1000, obs[:, 3], "Fixed",
+                0.8, 1.0, "Damping", 0.01, 100, 0.01, save_folder=str(tmp_path / "real_chain"))
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain 0")]
+    import re
+    pat = re.compile(r"=\(([-\d.]+),([-\d.]+),([-\d.]+),([-\d.]+)\)")
+    got = np.array([[float(v) for v in pat.search(l).groups()] for l in lines])
+    ref = e["real_T0_chain0"][:len(got)]
+    np.testing.assert_allclose(got[:, [0, 1, 3]], ref[:, [0, 1, 3]], rtol=2e-9, atol=2e-7)
+
+
+# ------------------------------------------------- BASELINE full size: size-independent laws
+
+def test_c2_full_size_properties(G):
+    """Config C2 (100x100x50 prisms, N = 10^4, M = 5*10^5, 40 GB G): the oracle cannot run
+    this in seconds, so check laws that hold at any size."""
+    nx = ny = 100
+    nz = int(os.environ.get("GRAVHMC_TEST_C2_NZ", "50"))
+    mesh = G.mesher.PrismMesh((0, 100.0 * nx, 0, 100.0 * ny, 0, 100.0 * nz), (100, 100, 100))
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 100.0 * ny, ny), np.linspace(0, 100.0 * nx, nx))]
+    zp = np.zeros_like(xp)
+    N, M = xp.size, mesh.size
+    eng = G.Engine(N, M)
+    eng.set_obs(xp, yp, zp)
+    eng.set_cells(mesh.cell_bounds(), 0)
+    eng.build_G()
+    rng = np.random.default_rng(0)
+    x, y, r = rng.uniform(0, 1, M), rng.normal(size=M), rng.normal(size=N)
+    # (1) linearity of the forward operator
+    fx, fy = eng.forward(x), eng.forward(y)
+    fz = eng.forward(2.5 * x - 0.75 * y)
+    assert relmax(fz, 2.5 * fx - 0.75 * fy) < 1e-12
+    # (2) adjoint consistency <G x, r> == <x, G^T r>
+    gr = eng.adjoint(r)
+    lhs, rhs = float(fx @ r), float(x @ gr)
+    assert abs(lhs - rhs) <= 1e-11 * (np.abs(fx) @ np.abs(r))
+    # (3) symmetry of the setup: obs grid and mesh are mirror-symmetric in x and in y, so the
+    #     response of a uniform half-space layer is symmetric too
+    ones = eng.forward(np.ones(M)).reshape(nx, ny)
+    assert relmax(ones, ones[::-1, :]) < 1e-10 and relmax(ones, ones[:, ::-1]) < 1e-10
+    # (4) after weighting every column has unit 2-norm: ||Aw e_j|| == 1, and Aw (wm*x) == G x
+    wm = eng.weight(0.5)
+    assert (wm > 0).all()
+    assert relmax(eng.forward(wm * x), fx) < 1e-12
+    for j in (0, M // 3, M - 1):
+        e = np.zeros(M)
+        e[j] = 1.0
+        assert abs(np.linalg.norm(eng.forward(e)) - 1.0) < 1e-12
+    # (5) potential: finite-difference check of the gradient along a random direction, and a
+    #     trajectory that must conserve H to O(dt^2) and be reproducible bit for bit
+    dobs = fx + 0.02 * fx.max() * rng.normal(size=N)
+    eng.set_data(dobs)
+    eng.set_reg("Damping", 1.0, 0.01, mesh.shape, 0.001 * wm)
+    x0 = 0.001 * wm
+    U0, g0, _, _, _ = eng.misfit_and_grad(x0)
+    v = rng.normal(size=M)
+    v /= np.linalg.norm(v)
+    h = 1e-4
+    Up = eng.misfit_and_grad(x0 + h * v)[0]
+    Um = eng.misfit_and_grad(x0 - h * v)[0]
+    assert abs((Up - Um) / (2 * h) - g0 @ v) < 1e-6 * abs(g0 @ v)
+    low, high = 0.0 * wm, 1.0 * wm
+    p0 = rng.normal(size=M) * 0.001
+    eng.chain_init(x0, low, high)
+    acc1, o1 = eng.chain_trajectory(p0, 0.001, 6, 0.5)
+    x1 = eng.chain_get_x()
+    eng.chain_init(x0, low, high)
+    acc2, o2 = eng.chain_trajectory(p0, 0.001, 6, 0.5)
+    assert acc1 == acc2 and np.array_equal(o1, o2) and np.array_equal(x1, eng.chain_get_x())
+    assert abs(o1[4] - o1[3]) < 1e-3 * abs(o1[3])       # H nearly conserved at small dt
+    eng.close()

@@ -1,0 +1,126 @@
+"""CPU suite: host logic (mesher, front-end bookkeeping) and the C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, gold
+
+
+CASES = {
+    "uniform": ("PrismMesh", ((0, 2000, 0, 3000, 0, 1000), (100, 100, 100))),
+    "uniform_odd": ("PrismMesh", ((0, 2050, 0, 3010, 0, 990), (130, 170, 110))),
+    "ratio": ("PrismMesh", ((0, 3000, 0, 3000, 0, 2000), (50, 100, 100), 1.2)),
+    "segment": ("PrismMeshSegment", ((0, 2000, 0, 3000, 0, 2100), ([100, 200, 300], 100, 100),
+                                     [0, 300, 900, 2100])),
+    "tess": ("TesseroidMesh", ((-180, 180, -90, 90, 0, -3e6), (-300000, 30, 30))),
+    "global": ("TesseroidMesh", ((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))),
+    "realdata": ("TesseroidMeshSegment", ((106.5, 118.5, 16, 28, 2000, -60000),
+                                          ([-1000, -2000, -5000], 0.5, 0.5),
+                                          [2000, -5000, -15000, -60000])),
+    "carve_cubic": ("PrismMesh", ((0, 2000, 0, 3000, 0, 1000), (100, 100, 100))),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_mesher_matches_reference_tables(name):
+    """Bounds, masks and node coordinates are bit-identical to the reference's mesher."""
+    from gravinv3dhmc_amd import mesher
+    g = gold("mesher_cases.npz")
+    cls, args = CASES[name]
+    m = getattr(mesher, cls)(*args)
+    if name + "_topo" in g.files:
+        m.carvetopo(*g[name + "_topo"])
+    assert m.shape == tuple(g[name + "_shape"])
+    assert np.array_equal(np.array(m.mask, dtype=np.int64), g[name + "_mask"])
+    if name == "global":
+        b = np.array([m[int(i)].get_bounds() for i in g[name + "_idx"]])
+        assert np.array_equal(m.cell_bounds()[g[name + "_idx"]], g[name + "_bounds"])
+    else:
+        b = m.cell_bounds()
+        # list protocol agrees with the vectorised table
+        it = [c.get_bounds() for c in m if c is not None]
+        assert np.array_equal(np.array(it[:50]), b[:50]) and len(it) == len(b)
+    assert np.array_equal(b, g[name + "_bounds"])
+    for ax in ("xs", "ys", "zs"):
+        assert np.array_equal(getattr(m, "get_" + ax)(), g[name + "_" + ax])
+
+
+def test_mesh_list_protocol():
+    from gravinv3dhmc_amd import mesher
+    m = mesher.PrismMesh((0, 300, 0, 200, 0, 100), (50, 100, 100))
+    assert len(m) == 12 and m.shape == (2, 2, 3)
+    assert m[-1].get_bounds() == m[11].get_bounds()
+    with pytest.raises(IndexError):
+        m[12]
+    m.addprop("density", np.arange(12.0))
+    assert m[5].props["density"] == 5.0
+    assert [c.props["density"] for c in m.get_layer(1)] == list(np.arange(6.0, 12.0))
+    t = mesher.Tesseroid(0, 2, 0, 2, 0, -10)
+    assert len(t.split(2, 2, 2)) == 8 and len(t.half(r=False)) == 4
+
+
+def test_active_cells_skipping_rules():
+    from gravinv3dhmc_amd import mesher
+    from gravinv3dhmc_amd.gravmag._common import active_cells
+    m = mesher.PrismMesh((0, 300, 0, 200, 0, 100), (50, 100, 100))
+    b, rho, idx = active_cells(m, None)           # no density, no override -> nothing
+    assert b.shape == (0, 6)
+    b, rho, idx = active_cells(m, 2.0)
+    assert b.shape == (12, 6) and np.all(rho == 2.0)
+    m.addprop("density", np.arange(12.0))
+    m._carved[[1, 4]] = True
+    m.mask.extend([1, 4])
+    b, rho, idx = active_cells(m, None)
+    assert b.shape == (10, 6) and list(rho[:3]) == [0.0, 2.0, 3.0]
+    cells = [mesher.Prism(0, 1, 0, 1, 0, 1, {"density": 3.0}), None, mesher.Prism(1, 2, 0, 1, 0, 1)]
+    b, rho, _ = active_cells(cells, None)
+    assert b.shape == (1, 6) and rho[0] == 3.0
+
+
+def test_c_abi_exports_every_declared_symbol(built_lib):
+    """The library loads and exports exactly the entry points include/gravhmc.h declares."""
+    from gravinv3dhmc_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gravhmc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gh_[a-z_A-Z0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = ctypes.CDLL(built_lib)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load() is not None
+
+
+def test_no_gpu_fails_loudly(built_lib):
+    """Without a HIP device the product raises; there is no CPU fallback."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import gravinv3dhmc_amd as g\n"
+            "try:\n    g.Engine(10, 10)\nexcept Exception as e:\n    print(type(e).__name__, e)\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
+    assert "GravHmcError" in out and "no CPU path" in out
+
+
+def test_sampler_refuses_host_models():
+    from gravinv3dhmc_amd import HamitonianMC
+
+    class Dummy:
+        def misfit_and_grad(self, *a, **k):
+            return 0.0, np.zeros(3), np.zeros(2), 0.0, 0.0
+
+    with pytest.raises(TypeError):
+        HamitonianMC(Dummy())
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "gravinv3dhmc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("oracle/", "").lower() or f == "__never__", (dirpath, f)

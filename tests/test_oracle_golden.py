@@ -1,0 +1,172 @@
+"""CPU suite: the oracle against the golden vectors generated from the reference
+(oracle/make_golden.py) and against the reference's committed run logs."""
+import numpy as np
+import pytest
+
+from conftest import gold
+from helpers import relmax
+from oracle import oracle
+
+
+def test_prism_entries_bit_exact():
+    g = gold("prism_cases.npz")
+    K = oracle.prism_gz_kernel(g["xp"], g["yp"], g["zp"], g["cells"])
+    assert np.array_equal(K, g["K"])  # same libm, same operation order as _prism.pyx
+
+
+def test_c1_kernel_spot_values():
+    from helpers import c1_inputs
+    g = gold("c1_spot.npz")
+    mesh, xp, yp, zp = c1_inputs()
+    K = oracle.prism_gz_kernel(xp, yp, zp, mesh.cell_bounds())
+    assert np.array_equal(K[g["ii"], g["jj"]], g["Kij"])
+    assert np.array_equal(K[:, 0], g["K_col0"]) and np.array_equal(K[0, :], g["K_row0"])
+    np.testing.assert_allclose(np.sqrt((K ** 2).sum(0)), g["colnorm"], rtol=1e-14)
+    gz = K @ g["rho"]
+    assert relmax(gz, g["gz"]) < 1e-12  # the reference accumulates per corner before scaling
+    # SURVEY 8c scalar goldens
+    assert K[0, 0] == 0.6468726475750967 and K[0, 5999] == 0.00012912876871222398
+    assert abs(np.linalg.norm(K) - 41.533528108117984) < 1e-12
+
+
+def test_uniformgrid_log_initial_mw():
+    """`initial mw` of example/uniformgrid/logout_T1.txt:29-31: 0.001 * column norms with the
+    2-decimal observation file."""
+    from gravinv3dhmc_amd import mesher
+    e = gold("example_inputs.npz")
+    obs = e["uni_obs"]
+    mesh = mesher.PrismMesh((0, 2000, 0, 3000, 0, 1000), (100, 100, 100))
+    K = oracle.prism_gz_kernel(obs[:, 0], obs[:, 1], obs[:, 2], mesh.cell_bounds())
+    _, wm = oracle.col_weight(K)
+    mw = 0.001 * wm
+    np.testing.assert_allclose(mw[:3], e["uni_initial_mw_head"], rtol=5e-9)
+    np.testing.assert_allclose(mw[-3:], e["uni_initial_mw_tail"], rtol=5e-9)
+
+
+def test_tesseroid_entries():
+    g = gold("tess_cases.npz")
+    K, info = oracle.tess_gz_kernel(g["lon"], g["lat"], g["h"], g["bounds"], return_info=True)
+    assert relmax(K, g["K"]) < 1e-13
+    assert info["leaves"] == int(g["leaves"])
+    assert relmax(K @ g["rho"], g["gz"]) < 1e-12
+    Kn, info = oracle.tess_gz_kernel(g["n_lon"], g["n_lat"], g["n_h"], g["n_cells"], return_info=True)
+    assert relmax(Kn, g["n_K"]) < 1e-13
+    assert info["err_cells"] == int((g["n_err"] != 0).sum()) and info["leaves"] == int(g["n_leaves"])
+
+
+def test_weighting_and_potential():
+    g = gold("potential_small.npz")
+    from gravinv3dhmc_amd import mesher
+    mesh = mesher.PrismMesh(tuple(g["mrange"]), tuple(g["mspacing"]))
+    K = oracle.prism_gz_kernel(g["xp"], g["yp"], g["zp"], mesh.cell_bounds())
+    Aw, wm = oracle.col_weight(K)
+    assert relmax(Aw, g["Aw"]) < 1e-15 and relmax(wm, g["wm"]) < 1e-15
+    for reg in ("Damping", "MS", "Smoothness", "TV"):
+        for tag, gf in (("", None), ("_fix", g["gfix"])):
+            P = oracle.Problem(Aw, g["dobs"], g["mwapr"], reg, float(g["alpha"]), float(g["beta"]),
+                               wm=wm, shape=g["shape"], grav_fix=gf)
+            for i, x in enumerate(g["xs"]):
+                m, grad, dpre, dv, mv = P.misfit_and_grad(x)
+                assert abs(m - g[reg + tag + "_misfit"][i]) <= 1e-13 * abs(m)
+                assert relmax(grad, g[reg + tag + "_grad"][i]) < 1e-13
+                assert relmax(dpre, g[reg + tag + "_dpre"][i]) < 1e-13
+                assert abs(dv - g[reg + tag + "_data"][i]) <= 1e-13 * abs(dv)
+                assert abs(mv - g[reg + tag + "_model"][i]) <= 1e-13 * abs(mv)
+
+
+def test_stencil_matches_fd3d_operator():
+    """The regulariser stencil against an explicit copy of the reference's fd3d matrix."""
+    rng = np.random.default_rng(3)
+    shape = (3, 4, 5)
+    M = int(np.prod(shape))
+    R = oracle.fd3d_dense(shape)
+    mw, apr = rng.normal(size=M), rng.normal(size=M)
+    v = mw - apr
+    val, grad = oracle.regulariser("Smoothness", mw, apr, shape=shape)
+    np.testing.assert_allclose(val, (R @ v) @ (R @ v), rtol=1e-13)
+    np.testing.assert_allclose(grad, 2 * R.T @ R @ v, rtol=1e-12, atol=1e-13)
+    t = R @ v
+    s = np.sqrt(t ** 2 + 0.01)
+    val, grad = oracle.regulariser("TV", mw, apr, beta=0.01, shape=shape)
+    np.testing.assert_allclose(val, s.sum(), rtol=1e-13)
+    np.testing.assert_allclose(grad, R.T @ (t / s), rtol=1e-12, atol=1e-13)
+
+
+def test_leapfrog_trajectories():
+    g = gold("leapfrog_small.npz")
+    p = gold("potential_small.npz")
+    n_acc = n_clamp = 0
+    for i in range(int(g["n"])):
+        k = lambda s: g["%d_%s" % (i, s)]
+        P = oracle.Problem(p["Aw"], p["dobs"], k("mwapr"), str(k("reg")), 1.0, 0.001, wm=p["wm"],
+                           shape=p["shape"])
+        x, acc, out, dsyn = P.leapfrog(k("x_in"), k("p0"), float(k("dt")), int(k("L")), k("low"),
+                                       k("high"), float(k("u")))
+        assert acc == bool(k("acc"))
+        assert relmax(x, k("x_out")) < 1e-12
+        assert abs(out[0] - float(k("U"))) <= 1e-12 * abs(out[0])
+        assert abs(out[1] - float(k("Ud"))) <= 1e-12 * abs(out[1])
+        assert relmax(dsyn, k("dsyn")) < 1e-12
+        n_acc += acc
+        n_clamp += bool(((x == k("low")) | (x == k("high"))).any())
+    assert 0 < n_acc < int(g["n"]) and n_clamp > 0  # both branches and the bounds are exercised
+
+
+def _run_chain(P, wm, x, low, high, dt, Lrange, Sigma, seed, n, N, M, alpha=1.0):
+    """The reference's sample loop (hmc.py:295-343) around oracle trajectories."""
+    np.random.seed(seed)
+    rows, i = [], 0
+    while i < n:
+        L = np.random.randint(Lrange[0], Lrange[1] + 1)
+        p0 = np.random.randn(M) * Sigma
+        u = np.random.rand()
+        x, acc, out, _ = P.leapfrog(x, p0, dt, L, low, high, u)
+        rows.append((out[1] / N + alpha * out[2] / M, out[1] / N, out[2] / M, acc))
+        i += acc
+    return np.array(rows), x
+
+
+def test_c1_chain_rows():
+    """First rows of misfit.dat of the reference run on C1 + Damping."""
+    from helpers import c1_inputs
+    g = gold("c1_chain.npz")
+    mesh, xp, yp, zp = c1_inputs()
+    Aw, wm = oracle.col_weight(oracle.prism_gz_kernel(xp, yp, zp, mesh.cell_bounds()))
+    M, N = wm.size, xp.size
+    P = oracle.Problem(Aw, g["dobs"], 0.001 * wm, "Damping", 1.0, 0.001, wm=wm)
+    rows, x = _run_chain(P, wm, 0.001 * wm, 0.0 * wm, 1.0 * wm, 0.01, [5, 20], 0.001, 100, 5, N, M)
+    ref = g["misfit"]
+    np.testing.assert_allclose(rows[:, 1] * N, ref[:, 1], rtol=1e-7)   # files hold 8 decimals
+    np.testing.assert_allclose(rows[:, 2] * M, ref[:, 2], rtol=1e-7)
+    np.testing.assert_allclose(x / wm, g["model_last"], atol=2e-8)
+
+
+def test_realdata_log_lines():
+    """example/realdata/logout_T0.txt chain 0 and 1: tesseroid kernel on the carved segment
+    mesh + weighting + Damping + fixed cells + NumPy legacy RNG, all printed digits."""
+    from gravinv3dhmc_amd import mesher
+    e = gold("example_inputs.npz")
+    obs, topo = e["real_obs"], e["real_topo"]
+    mesh = mesher.TesseroidMeshSegment((106.5, 118.5, 16, 28, 2000, -60000),
+                                       ([-1000, -2000, -5000], 0.5, 0.5),
+                                       [2000, -5000, -15000, -60000])
+    mask = mesh.carvetopo(topo[:, 0], topo[:, 1], topo[:, 2])
+    b = mesh.cell_bounds()
+    assert b.shape == (10427, 6)
+    K = oracle.tess_gz_kernel(obs[:, 0], obs[:, 1], obs[:, 2], b)
+    Aw, wm = oracle.col_weight(K)
+    N, M = Aw.shape
+    init = 0.01 * wm
+    np.testing.assert_allclose(init[:3], e["real_T0_initial_mw_head"], rtol=5e-8)
+    np.testing.assert_allclose(init[-3:], e["real_T0_initial_mw_tail"], rtol=5e-8)
+    keep = np.ones(mesh.size, bool)
+    keep[np.array(mask)] = False
+    prior = e["real_aprior"][keep] * wm            # utils.rho2carve + Wm @ aprior
+    P = oracle.Problem(Aw, obs[:, 3], prior, "Damping", 1.0, 0.01, wm=wm, grav_fix=e["real_gravsea"])
+    for rank, key, n in ((0, "real_T0_chain0", 6), (1, "real_T0_chain1", 3)):
+        rows, _ = _run_chain(P, wm, init, -0.5 * wm, 0.5 * wm, 0.01, [5, 20], 0.01, 100 + rank, n, N, M)
+        ref = e[key][:len(rows)]
+        assert np.all(rows[:, 3] == 1)
+        np.testing.assert_allclose(rows[:, 0], ref[:, 0], atol=6e-8 * 10, rtol=2e-10)
+        np.testing.assert_allclose(rows[:, 1], ref[:, 1], atol=6e-8 * 10, rtol=2e-10)
+        np.testing.assert_allclose(rows[:, 2], ref[:, 3], atol=6e-8 * 10, rtol=2e-10)
