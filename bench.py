@@ -28,15 +28,33 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (nx, ny, nz, anomaly block (ix0, ix1, iy0, iy1, iz0, iz1))  -- SURVEY 8d
-    "c2_uniform_100x100x50": (100, 100, 50, (40, 59, 40, 59, 10, 24)),
-    "c1_uniform_20x30x10": (20, 30, 10, (7, 10, 10, 17, 2, 4)),
+    # name: (nx, ny, nz, anomaly block (ix0, ix1, iy0, iy1, iz0, iz1), dt)  -- SURVEY 8d
+    # dt: the reference's 0.01 (uniformgrid/SetPMTS.txt) is stable at C1; at C2 the potential
+    # is ~80x stiffer (M/N grows), 0.002 keeps the acceptance at the reference's ~100 %.
+    "c2_uniform_100x100x50": (100, 100, 50, (40, 59, 40, 59, 10, 24), 0.002),
+    "c1_uniform_20x30x10": (20, 30, 10, (7, 10, 10, 17, 2, 4), 0.01),
 }
+
+
+def pmc_traffic(workload):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC summary (profiles/rNN/),
+    corrected as MI355X_MICROARCH.md prescribes; None when no profile of this workload exists."""
+    import glob
+    tag = workload.split("_")[0]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", tag + "_pmc_summary.json")),
+                    reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+            k = [v for n, v in ks.items() if "sweep_kernel" in n][0]
+            return k["hbm_read_bytes"] + k["hbm_write_bytes"]
+        except Exception:
+            continue
+    return None
 
 
 def make_problem(name):
     from gravinv3dhmc_amd import mesher
-    nx, ny, nz, blk = WORKLOADS[name]
+    nx, ny, nz, blk, _dt = WORKLOADS[name]
     mesh = mesher.PrismMesh((0, 100.0 * nx, 0, 100.0 * ny, 0, 100.0 * nz), (100, 100, 100))
     yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 100.0 * ny, ny),
                                              np.linspace(0, 100.0 * nx, nx))]
@@ -47,12 +65,19 @@ def make_problem(name):
 
 
 def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=12.0):
-    """The CPU restatement (oracle, kind "port") on a column-subsampled copy of the same
-    workload: same N, every k-th cell, all host cores via OpenMP; steps/s is scaled by the
-    subsampling factor (cost per step is linear in the number of cells)."""
+    """The reference's CPU formulation (NumPy + multi-threaded BLAS dgemv pair per potential
+    evaluation, NumPy leapfrog; oracle/numpy_port.py, kind "port") on a column-subsampled copy
+    of the same workload: same N, every k-th cell; steps/s is scaled by the subsampling factor
+    (cost per step is linear in the number of cells).  The sample kernel is assembled by the
+    C oracle."""
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    from oracle.numpy_port import NumpyProblem
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()
+                     if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        cores = os.cpu_count()
     M = mesh.size
     k = max(1, M // 10000)
     b = mesh.cell_bounds()[::k]
@@ -61,12 +86,13 @@ def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=12.0):
     Aw, wm = oracle.col_weight(K)
     t_build = time.time() - t0
     del K
-    P = oracle.Problem(Aw, dobs, 0.001 * wm, "Damping", 1.0, 0.01, wm=wm)
+    P = NumpyProblem(Aw, dobs, 0.001 * wm, "Damping", 1.0, 0.01, wm=wm)
     Ms = wm.size
     rng = np.random.default_rng(1)
     x = 0.001 * wm
     L, steps, t_run = 10, 0, 0.0
-    while t_run < target_s and steps < 400:
+    P.leapfrog(x, rng.normal(size=Ms) * 0.001, 0.01, 2, 0.0 * wm, 1.0 * wm, 0.5)   # warm-up
+    while t_run < target_s and steps < 2000:
         p0 = rng.normal(size=Ms) * 0.001
         t1 = time.time()
         x, acc, out, _ = P.leapfrog(x, p0, 0.01, L, 0.0 * wm, 1.0 * wm, 0.5)
@@ -75,10 +101,11 @@ def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=12.0):
     sps_sample = steps / t_run
     return {"value": sps_sample * Ms / M, "unit": "leapfrog steps/s", "cores": cores,
             "kind": "port",
-            "sample": "same N=%d observations, every %d-th cell (%d of %d); %d steps in %.1f s "
-                      "(%.2f steps/s on the sample, scaled by %d/%d); kernel build + weighting "
-                      "of the sample %.1f s" % (xp.size, k, Ms, M, steps, t_run, sps_sample, Ms, M,
-                                                t_build)}
+            "sample": "NumPy/OpenBLAS mirror of potential.py:688-845 + hmc.py:85-177; same N=%d "
+                      "observations, every %d-th cell (%d of %d); %d steps in %.1f s (%.2f steps/s "
+                      "on the sample, scaled by %d/%d); %d BLAS threads; sample kernel build + "
+                      "weighting %.1f s" % (xp.size, k, Ms, M, steps, t_run, sps_sample, Ms, M,
+                                            cores, t_build)}
 
 
 def main():
@@ -131,7 +158,7 @@ def main():
 
     # the reference's RNG stream (legacy global generator), one chain per rank
     np.random.seed(100 + rank)
-    Sigma, dt, L = 0.001, 0.01, args.traj_len
+    Sigma, dt, L = 0.001, WORKLOADS[args.workload][4], args.traj_len
 
     def draw(nsteps):
         return np.random.randn(M) * Sigma, np.random.rand(), nsteps
@@ -190,12 +217,12 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "N_obs": int(N), "M_cells": int(M),
                        "G_bytes": int(N) * int(M) * 8, "regulariser": "Damping",
-                       "chains_per_gpu": 1, "traj_len": L, "trajectories": ntraj,
+                       "chains_per_gpu": 1, "dt": dt, "traj_len": L, "trajectories": ntraj,
                        "accepted": naccept, "parallelism": "chain-parallel x%d (no collective)" % world,
                        "device": info["name"], "cus": info["cus"],
                        "G_build_s": round(t_build, 3), "weighting_s": round(t_weight, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic(args.workload),
                          "kernel": "sweep_kernel (fused adjoint+update+forward, one read of G)",
                          "launches": prof["sweeps"], "avg_ms": sweep_ms,
                          "algorithmic_bytes_per_launch": bytes_sweep,

@@ -393,8 +393,8 @@ int gh_device_info(const gh_ctx *c, char *name256, int *cus, int64_t *mem_bytes)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return GH_ERR_HIP;
     if (name256) {
-        strncpy(name256, prop.name, 255);
-        name256[255] = 0;
+        // some ROCm builds leave prop.name empty: fall back to the ISA name
+        snprintf(name256, 256, "%s%s%s", prop.name, prop.name[0] ? " " : "AMD Instinct ", prop.gcnArchName);
     }
     if (cus) *cus = prop.multiProcessorCount;
     if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
@@ -448,8 +448,7 @@ int gh_build_G(gh_ctx *c)
     c->warn_cells = 0;
     c->leaves = 0;
     if (c->cell_kind == GH_CELL_PRISM) {
-        const int64_t blocks = (total + 255) / 256;
-        if (blocks > 0x7fffffffLL) return fail(c, GH_ERR_UNSUPPORTED, "gh_build_G: matrix too large");
+        const int64_t blocks = std::min<int64_t>((total + 255) / 256, 1 << 22);
         prism_gz_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(
             c->obs[0], c->obs[1], c->obs[2], c->bounds, c->N, c->M, c->ld, c->G);
         HIPCHK(c, hipGetLastError());
@@ -466,8 +465,7 @@ int gh_build_G(gh_ctx *c)
         const int64_t N = c->N;
         tess_convert_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream>>>(
             c->obs[0], c->obs[1], c->obs[2], N, conv, conv + N, conv + 2 * N, conv + 3 * N);
-        const int64_t blocks = (total + 63) / 64;
-        if (blocks > 0x7fffffffLL) return fail(c, GH_ERR_UNSUPPORTED, "gh_build_G: matrix too large");
+        const int64_t blocks = std::min<int64_t>((total + 63) / 64, 1 << 24);
         tess_gz_kernel<<<dim3((unsigned)blocks), dim3(64), 0, c->stream>>>(
             conv, conv + N, conv + 2 * N, conv + 3 * N, c->bounds, N, c->M, c->ld, c->ratio, c->G,
             err_cell, stats);

@@ -472,12 +472,13 @@ prism_gz_kernel(const double *__restrict__ xp, const double *__restrict__ yp,
                 int64_t M, int64_t ld, double *__restrict__ G)
 {
 #pragma clang fp contract(off)
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= ld * M) return;
+  // grid-stride: a launch is limited to 2^32 work-items, ld*M reaches 5*10^9 at C2
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < ld * M;
+       idx += (int64_t)gridDim.x * 256) {
     const int64_t c = idx / ld, l = idx - c * ld;
     if (l >= N) {
         G[idx] = 0.0;
-        return;
+        continue;
     }
     const double *b = bounds6 + 6 * c;
     const double X[2] = {b[1], b[0]}, Y[2] = {b[3], b[2]}, Z[2] = {b[5], b[4]};
@@ -501,6 +502,7 @@ prism_gz_kernel(const double *__restrict__ xp, const double *__restrict__ yp,
         }
     }
     G[idx] = acc * (0.00000006673 * 100000.0);
+  }
 }
 
 constexpr int TESS_STACK = 100;  // tesseroid.py:79
@@ -520,12 +522,14 @@ tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinl
                double *__restrict__ G, int *__restrict__ err_cell, TessStats *stats)
 {
 #pragma clang fp contract(off)
-    const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (idx >= ld * M) return;
+  unsigned long long nleaf = 0;
+  bool overflow = false;
+  for (int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x; idx < ld * M;
+       idx += (int64_t)gridDim.x * 64) {
     const int64_t c = idx / ld, l = idx - c * ld;
     if (l >= N) {
         G[idx] = 0.0;
-        return;
+        continue;
     }
     const double MEAN_R = 6378137.0;
     const double d2r = 3.14159265358979323846 / 180;
@@ -535,8 +539,6 @@ tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinl
 #pragma unroll
     for (int q = 0; q < 6; ++q) stack[0][q] = bounds6[6 * c + q];
     int stktop = 0, error_code = 0;
-    unsigned long long nleaf = 0;
-    bool overflow = false;
     double acc = 0.0;
     while (stktop >= 0) {
         const double w = stack[stktop][0], e = stack[stktop][1], s = stack[stktop][2],
@@ -619,6 +621,7 @@ tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinl
     }
     G[idx] = acc * 100000.0 * 0.00000006673;
     if (error_code != 0) atomicAdd(&err_cell[c], error_code);
+  }
     if (overflow) atomicExch(&stats->overflow, 1);
     // one atomic per wave for the leaf count
     unsigned long long tot = nleaf;
@@ -641,16 +644,6 @@ __global__ void tess_convert_kernel(const double *lon, const double *lat, const 
     sinlat[i] = sin(la);
     coslat[i] = cos(la);
     radius[i] = 6378137.0 + h[i];
-}
-
-// row-major (C order) host layout -> padded column-major device layout
-__global__ void __launch_bounds__(256)
-pad_columns_kernel(const double *src, int64_t N, int64_t M, int64_t lds, double *G, int64_t ld)
-{
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= ld * M) return;
-    const int64_t c = idx / ld, l = idx - c * ld;
-    G[idx] = (l < N) ? src[c * lds + l] : 0.0;
 }
 
 }  // namespace ghk

@@ -79,8 +79,8 @@ int gh_upload_G(gh_ctx *ctx, const double *A, int64_t ld, int fortran_order);
 /* Copy the device matrix back, column-major with leading dimension ld >= N (what
  * GravMagModule.kernelw() hands out as `Aw`, potential.py:584-589). */
 int gh_download_G(gh_ctx *ctx, double *A, int64_t ld);
-/* Noise-free forward model d = G * rho for the UNWEIGHTED kernel (the `result` output of
- * prism.gz / tesseroid.gz with mesh densities rho). */
+/* (The `result` output of prism.gz / tesseroid.gz, d = G * rho for the unweighted kernel, is
+ * gh_forward called before gh_weight.) */
 
 /* Sensitivity weighting, potential.py:232-264: wm_j = (sum_i G_ij^2)^weightfactor, G <- G *
  * diag(1/wm) in place (columns with zero norm are left untouched, wm_j = 0).  wm_out (M)

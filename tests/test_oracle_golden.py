@@ -170,3 +170,20 @@ def test_realdata_log_lines():
         np.testing.assert_allclose(rows[:, 0], ref[:, 0], atol=6e-8 * 10, rtol=2e-10)
         np.testing.assert_allclose(rows[:, 1], ref[:, 1], atol=6e-8 * 10, rtol=2e-10)
         np.testing.assert_allclose(rows[:, 2], ref[:, 3], atol=6e-8 * 10, rtol=2e-10)
+
+
+def test_numpy_port_matches_oracle():
+    """The NumPy/BLAS mirror used as bench.py's cpu_baseline equals the pinned C oracle."""
+    from oracle.numpy_port import NumpyProblem
+    p = gold("potential_small.npz")
+    g = gold("leapfrog_small.npz")
+    for i in range(int(g["n"])):
+        k = lambda s: g["%d_%s" % (i, s)]
+        reg = str(k("reg"))
+        if reg not in ("Damping", "MS"):
+            continue
+        P = NumpyProblem(p["Aw"], p["dobs"], k("mwapr"), reg, 1.0, 0.001, wm=p["wm"])
+        x, acc, out, dsyn = P.leapfrog(k("x_in"), k("p0"), float(k("dt")), int(k("L")), k("low"),
+                                       k("high"), float(k("u")))
+        assert acc == bool(k("acc")) and relmax(x, k("x_out")) < 1e-12
+        assert abs(out[0] - float(k("U"))) <= 1e-12 * abs(out[0])
