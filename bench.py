@@ -118,22 +118,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-    dist = None
-    if world > 1:
-        # control plane only (barrier + max of the elapsed time): the chains are independent,
-        # so no tensor of the data path ever crosses ranks.  gloo on CPU tensors keeps
-        # torch's own HIP runtime out of the process.
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # control plane only (barrier + max of the elapsed time): the chains are independent, so
+    # no tensor of the data path ever crosses ranks.  gloo on CPU tensors keeps torch's own HIP
+    # runtime out of the process (gravinv3dhmc_amd/dist.py, covered by tests/test_dist_gloo.py).
+    from gravinv3dhmc_amd.dist import Ranks
+    ranks = Ranks()
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                 "--nproc-per-node %d" % (args.gpus, args.gpus))
 
     import gravinv3dhmc_amd as g
     mesh, xp, yp, zp, rho = make_problem(args.workload)
@@ -181,9 +174,7 @@ def main():
             ntraj += 1
         return naccept, ntraj
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = ranks.barrier
 
     if args.warmup > 0:
         run(args.warmup)
@@ -197,11 +188,7 @@ def main():
     barrier()
     prof = eng.profile_read()
     eng.profile_enable(False)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = ranks.max(elapsed)
 
     if rank == 0:
         sweep_ms = prof["sweep_ms"] / max(1, prof["sweeps"])
@@ -236,8 +223,7 @@ def main():
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line))
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":
