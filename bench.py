@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--workload", default="c2_uniform_100x100x50", choices=list(WORKLOADS))
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks share GPU 0 (rehearsal of the N>1 launch path on a 1-GPU box)")
     args = ap.parse_args()
 
     # control plane only (barrier + max of the elapsed time): the chains are independent, so
@@ -131,7 +133,7 @@ def main():
     import gravinv3dhmc_amd as g
     mesh, xp, yp, zp, rho = make_problem(args.workload)
     N, M = xp.size, mesh.size
-    eng = g.Engine(N, M, device=local_rank)
+    eng = g.Engine(N, M, device=0 if args.rehearse_on_one_gpu else local_rank)
     info = eng.device_info()
     t0 = time.time()
     eng.set_obs(xp, yp, zp)

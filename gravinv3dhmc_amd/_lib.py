@@ -39,6 +39,11 @@ PROTOTYPES = {
     "gh_forward": (C.c_int, [_ctx, _dp, _dp]),
     "gh_adjoint": (C.c_int, [_ctx, _dp, _dp]),
     "gh_misfit_and_grad": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
+    "gh_compress_wavelet": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_int,
+                                      C.POINTER(_i64), C.POINTER(_i64)]),
+    "gh_download_csr": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(C.c_int32), _dp]),
+    "gh_model_coeffs": (C.c_int, [_ctx, _dp, _dp]),
+    "gh_forward_wavelet": (C.c_int, [_ctx, _dp, _dp]),
     "gh_chain_init": (C.c_int, [_ctx, _dp, _dp, _dp]),
     "gh_chain_trajectory": (C.c_int, [_ctx, _dp, C.c_double, C.c_int, C.c_double,
                                       C.POINTER(C.c_int), _dp]),

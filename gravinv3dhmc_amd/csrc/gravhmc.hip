@@ -64,6 +64,23 @@ struct gh_ctx {
     bool chain_ready = false;
     double U_cur[3] = {0, 0, 0};
 
+    // wavelet-compressed forward operator (compressor1D/3D): CSR N x Mp on the device
+    struct Wavelet {
+        bool on = false;
+        int dims = 0, levels = 2;
+        int shape[3] = {1, 1, 1};
+        int X[5][3];      // X[i]: extents of the blocks level i produces (X[0] = model shape)
+        int offd[5][3];   // packed offset of level i's detail pieces (pywt.coeffs_to_array)
+        int D[3] = {1, 1, 1};
+        bool tax[3] = {false, false, true};  // transformed axes
+        int64_t Mp = 0, nnz = 0;
+        double thr = 1e-3;
+        int64_t *indptr = nullptr;
+        int *indices = nullptr;
+        double *data = nullptr;
+        double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
+    } wv;
+
     // profiling of the sweeps
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -238,10 +255,143 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
     return GH_OK;
 }
 
+
+// ------------------------------------------------------------------ wavelet forward
+
+static void wavelet_plan(gh_ctx::Wavelet &w)
+{
+    for (int k = 0; k < 3; ++k) w.X[0][k] = w.shape[k];
+    for (int i = 1; i <= w.levels; ++i)
+        for (int k = 0; k < 3; ++k) w.X[i][k] = w.tax[k] ? (w.X[i - 1][k] + 1) / 2 : w.X[i - 1][k];
+    int a[3];
+    for (int k = 0; k < 3; ++k) a[k] = w.X[w.levels][k];
+    for (int i = w.levels; i >= 1; --i)
+        for (int k = 0; k < 3; ++k) {
+            w.offd[i][k] = a[k];
+            if (w.tax[k]) a[k] += w.X[i][k];
+        }
+    for (int k = 0; k < 3; ++k) w.D[k] = a[k];
+    w.Mp = (int64_t)a[0] * a[1] * a[2];
+}
+
+// Multi-level DWT of `batch` model-shaped vectors x (batch stride xb) into the packed
+// coefficient layout C (batch stride Mp, must be zero-initialised: odd lengths leave gaps).
+static int run_dwt(gh_ctx *c, const double *x, int64_t xb, int64_t batch, double *C, double *S1,
+                   double *S2)
+{
+    const gh_ctx::Wavelet &w = c->wv;
+    const int64_t Cs[3] = {(int64_t)w.D[1] * w.D[2], (int64_t)w.D[2], 1};
+    int axes[3], na = 0;
+    for (int k = 0; k < 3; ++k)
+        if (w.tax[k]) axes[na++] = k;
+    for (int lev = 1; lev <= w.levels; ++lev) {
+        const double *src = (lev == 1) ? x : C;
+        int64_t src_b = (lev == 1) ? xb : w.Mp;
+        int e[3] = {w.X[lev - 1][0], w.X[lev - 1][1], w.X[lev - 1][2]};
+        int64_t ss[3];
+        if (lev == 1) {
+            ss[0] = (int64_t)e[1] * e[2];
+            ss[1] = e[2];
+            ss[2] = 1;
+        } else {
+            ss[0] = Cs[0];
+            ss[1] = Cs[1];
+            ss[2] = Cs[2];
+        }
+        if (na == 1 && lev > 1) {
+            // single pass reading and writing C would overlap: stage the input block
+            const int64_t len = (int64_t)e[0] * e[1] * e[2];  // contiguous: only the last axis varies
+            for (int64_t b = 0; b < batch; ++b)
+                HIPCHK(c, hipMemcpyAsync(S1 + b * w.Mp, C + b * w.Mp, len * sizeof(double),
+                                         hipMemcpyDeviceToDevice, c->stream));
+            src = S1;
+            ss[0] = (int64_t)e[1] * e[2];
+            ss[1] = e[2];
+            ss[2] = 1;
+        }
+        for (int p = 0; p < na; ++p) {
+            const int ax = axes[p];
+            const bool last = (p == na - 1);
+            double *dst = last ? C : ((p & 1) ? S2 : S1);
+            if (!last && dst == src) dst = (dst == S1) ? S2 : S1;
+            DwtArgs a{};
+            a.in = src;
+            a.out = dst;
+            a.batch = batch;
+            a.in_bstride = src_b;
+            a.out_bstride = w.Mp;
+            a.axis = ax;
+            const int h = (e[ax] + 1) / 2;
+            int oe[3] = {e[0], e[1], e[2]};
+            oe[ax] = 2 * h;
+            for (int k = 0; k < 3; ++k) {
+                a.e[k] = e[k];
+                a.in_s[k] = ss[k];
+                a.in_off[k][0] = a.in_off[k][1] = 0;
+                a.in_split[k] = 0x7fffffff;
+            }
+            if (last) {
+                for (int k = 0; k < 3; ++k) {
+                    a.out_s[k] = Cs[k];
+                    a.out_off[k][0] = 0;
+                    if (w.tax[k]) {
+                        a.out_split[k] = w.X[lev][k];
+                        a.out_off[k][1] = w.offd[lev][k];
+                    } else {
+                        a.out_split[k] = 0x7fffffff;
+                        a.out_off[k][1] = 0;
+                    }
+                }
+            } else {
+                a.out_s[0] = (int64_t)oe[1] * oe[2];
+                a.out_s[1] = oe[2];
+                a.out_s[2] = 1;
+                for (int k = 0; k < 3; ++k) {
+                    a.out_off[k][0] = 0;
+                    a.out_off[k][1] = (k == ax) ? h : 0;
+                    a.out_split[k] = 0x7fffffff;
+                }
+            }
+            const int64_t total = (int64_t)oe[0] * oe[1] * oe[2] / 2 * batch;
+            const int64_t blocks = std::min<int64_t>((total + 255) / 256, 1 << 20);
+            dwt_axis_kernel<<<dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, c->stream>>>(a);
+            // the next pass reads what this one wrote: dense block of extents oe
+            src = dst;
+            src_b = w.Mp;
+            e[0] = oe[0];
+            e[1] = oe[1];
+            e[2] = oe[2];
+            ss[0] = a.out_s[0];
+            ss[1] = a.out_s[1];
+            ss[2] = a.out_s[2];
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+// d = Awcp @ W(x): compressor3D.py:47-68 / compressor1D.py:45-60
+static int wavelet_forward(gh_ctx *c, const double *x, double *d_out)
+{
+    gh_ctx::Wavelet &w = c->wv;
+    HIPCHK(c, hipMemsetAsync(w.coeff, 0, sizeof(double) * (size_t)w.Mp, c->stream));
+    TRY(run_dwt(c, x, c->M, 1, w.coeff, w.s1, w.s2));
+    spmv_kernel<<<dim3((unsigned)((c->ld + 3) / 4)), dim3(256), 0, c->stream>>>(
+        w.indptr, w.indices, w.data, w.coeff, c->N, c->ld, d_out);
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
 // slab -> d ; regulariser ; residual + scalars.  x: position the forward belongs to.
 static int finalize(gh_ctx *c, const double *x, double *d_out, double *r_out, double *greg_out,
                     double *scal_out)
 {
+    if (c->wv.on) {
+        // forward through the compressed operator; d_out then acts as a one-row slab
+        TRY(wavelet_forward(c, x, d_out));
+        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(
+            d_out, 1, c->ld, c->N, c->have_fix ? c->gfix : nullptr, d_out, c->dpart);
+    } else
     reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(
         c->slab, c->grid, c->ld, c->N, c->have_fix ? c->gfix : nullptr, d_out, c->dpart);
     RegArgs ra;
@@ -280,11 +430,13 @@ static int finalize(gh_ctx *c, const double *x, double *d_out, double *r_out, do
 static int eval_forward(gh_ctx *c, const double *x, double *d_out, double *r_out,
                         double *greg_out, double *scal_out)
 {
-    SweepArgs a{};
-    a.mode = SW_FWD;
-    a.x_in = x;
-    a.slab = c->slab;
-    TRY(launch_sweep(c, a));
+    if (!c->wv.on) {
+        SweepArgs a{};
+        a.mode = SW_FWD;
+        a.x_in = x;
+        a.slab = c->slab;
+        TRY(launch_sweep(c, a));
+    }
     return finalize(c, x, d_out, r_out, greg_out, scal_out);
 }
 
@@ -696,6 +848,132 @@ int gh_misfit_and_grad(gh_ctx *c, const double *x, double out3[3], double *grad,
     return GH_OK;
 }
 
+int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, int levels,
+                        int64_t *nnz_out, int64_t *ncols_out)
+{
+    if (!c) return GH_ERR_ARG;
+    TRY(need(c, c->have_G && c->weighted, "gh_compress_wavelet: needs the weighted kernel (gh_weight) first"));
+    if (dims != 1 && dims != 3) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: dims must be 1 or 3");
+    if (levels < 1 || levels > 4) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: levels must be 1..4");
+    if (!(thr >= 0)) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: threshold must be >= 0");
+    gh_ctx::Wavelet &w = c->wv;
+    if (w.on || w.indptr) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: already compressed");
+    if (dims == 3) {
+        if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
+            return fail(c, GH_ERR_ARG, "cannot reshape array of size %lld into shape (%d,%d,%d)",
+                        (long long)c->M, shape3 ? shape3[0] : 0, shape3 ? shape3[1] : 0, shape3 ? shape3[2] : 0);
+        for (int k = 0; k < 3; ++k) {
+            w.shape[k] = shape3[k];
+            w.tax[k] = true;
+        }
+    } else {
+        if (c->M > 0x7fffffffLL) return fail(c, GH_ERR_UNSUPPORTED, "model too long");
+        w.shape[0] = w.shape[1] = 1;
+        w.shape[2] = (int)c->M;
+        w.tax[0] = w.tax[1] = false;
+        w.tax[2] = true;
+    }
+    w.dims = dims;
+    w.levels = levels;
+    w.thr = thr;
+    wavelet_plan(w);
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    const int64_t N = c->N, M = c->M, Mp = w.Mp;
+    // row chunks: 4 buffers of chunk x Mp doubles, bounded to ~2 GB in total
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(512 << 20) / (Mp * 8)));
+    double *X = nullptr, *C = nullptr, *S1 = nullptr, *S2 = nullptr;
+    int *count = nullptr;
+    HIPCHK(c, hipMalloc((void **)&X, sizeof(double) * (size_t)(chunk * M)));
+    HIPCHK(c, hipMalloc((void **)&C, sizeof(double) * (size_t)(chunk * Mp)));
+    HIPCHK(c, hipMalloc((void **)&S1, sizeof(double) * (size_t)(chunk * Mp)));
+    HIPCHK(c, hipMalloc((void **)&S2, sizeof(double) * (size_t)(chunk * Mp)));
+    HIPCHK(c, hipMalloc((void **)&count, sizeof(int) * (size_t)N));
+    TRY(dalloc(c, &w.indptr, (size_t)N + 1));
+    std::vector<int> hcount((size_t)N);
+    std::vector<int64_t> hptr((size_t)N + 1, 0);
+    int rc = GH_OK;
+    for (int pass = 0; pass < 2 && rc == GH_OK; ++pass) {
+        if (pass == 1) {
+            HIPCHK(c, hipMemcpyAsync(hcount.data(), count, sizeof(int) * (size_t)N, hipMemcpyDeviceToHost,
+                                     c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int64_t i = 0; i < N; ++i) hptr[i + 1] = hptr[i] + hcount[i];
+            w.nnz = hptr[N];
+            if (w.nnz > 0x7fffffff00LL) return fail(c, GH_ERR_UNSUPPORTED, "too many non-zeros");
+            TRY(dalloc(c, &w.indices, (size_t)std::max<int64_t>(w.nnz, 1), false));
+            TRY(dalloc(c, &w.data, (size_t)std::max<int64_t>(w.nnz, 1), false));
+            HIPCHK(c, hipMemcpyAsync(w.indptr, hptr.data(), sizeof(int64_t) * (size_t)(N + 1),
+                                     hipMemcpyHostToDevice, c->stream));
+        }
+        for (int64_t i0 = 0; i0 < N; i0 += chunk) {
+            const int64_t nr = std::min(chunk, N - i0);
+            gather_rows_kernel<<<dim3((unsigned)((M + 31) / 32), (unsigned)((nr + 31) / 32)), dim3(256), 0,
+                                 c->stream>>>(c->G, c->ld, M, i0, nr, X);
+            HIPCHK(c, hipMemsetAsync(C, 0, sizeof(double) * (size_t)(nr * Mp), c->stream));
+            rc = run_dwt(c, X, M, nr, C, S1, S2);
+            if (rc != GH_OK) break;
+            if (pass == 0)
+                csr_count_kernel<<<dim3((unsigned)nr), dim3(256), 0, c->stream>>>(C, Mp, thr, count + i0);
+            else
+                csr_fill_kernel<<<dim3((unsigned)nr), dim3(256), 0, c->stream>>>(C, Mp, thr, w.indptr, i0,
+                                                                                 w.indices, w.data);
+        }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(X);
+    hipFree(C);
+    hipFree(S1);
+    hipFree(S2);
+    hipFree(count);
+    if (rc != GH_OK) return rc;
+    if (e != hipSuccess) return fail(c, GH_ERR_HIP, "gh_compress_wavelet: %s", hipGetErrorString(e));
+    TRY(dalloc(c, &w.coeff, (size_t)Mp));
+    TRY(dalloc(c, &w.s1, (size_t)Mp));
+    TRY(dalloc(c, &w.s2, (size_t)Mp));
+    w.on = true;
+    c->chain_ready = false;
+    if (nnz_out) *nnz_out = w.nnz;
+    if (ncols_out) *ncols_out = Mp;
+    return GH_OK;
+}
+
+int gh_download_csr(gh_ctx *c, int64_t *indptr, int32_t *indices, double *data)
+{
+    if (!c || !indptr || !indices || !data) return fail(c, GH_ERR_ARG, "gh_download_csr: null pointer");
+    TRY(need(c, c->wv.on, "gh_download_csr: call gh_compress_wavelet first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(indptr, c->wv.indptr, sizeof(int64_t) * (size_t)(c->N + 1), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(indices, c->wv.indices, sizeof(int) * (size_t)c->wv.nnz, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(data, c->wv.data, sizeof(double) * (size_t)c->wv.nnz, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+int gh_model_coeffs(gh_ctx *c, const double *mw, double *coeff)
+{
+    if (!c || !mw || !coeff) return fail(c, GH_ERR_ARG, "gh_model_coeffs: null pointer");
+    TRY(need(c, c->wv.on, "gh_model_coeffs: call gh_compress_wavelet first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(h2d(c, c->tmpM, mw, (size_t)c->M));
+    HIPCHK(c, hipMemsetAsync(c->wv.coeff, 0, sizeof(double) * (size_t)c->wv.Mp, c->stream));
+    TRY(run_dwt(c, c->tmpM, c->M, 1, c->wv.coeff, c->wv.s1, c->wv.s2));
+    return d2h(c, coeff, c->wv.coeff, (size_t)c->wv.Mp);
+}
+
+int gh_forward_wavelet(gh_ctx *c, const double *mw, double *dpre)
+{
+    if (!c || !mw || !dpre) return fail(c, GH_ERR_ARG, "gh_forward_wavelet: null pointer");
+    TRY(need(c, c->wv.on, "gh_forward_wavelet: call gh_compress_wavelet first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(h2d(c, c->tmpM, mw, (size_t)c->M));
+    TRY(wavelet_forward(c, c->tmpM, c->tmpN));
+    return d2h(c, dpre, c->tmpN, (size_t)c->N);
+}
+
 int gh_chain_init(gh_ctx *c, const double *x0, const double *low, const double *high)
 {
     if (!c || !x0 || !low || !high) return fail(c, GH_ERR_ARG, "gh_chain_init: null pointer");
@@ -731,7 +1009,7 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     int xo = 0;   // next x output buffer
     for (int s = 0; s < L; ++s) {
         SweepArgs a{};
-        a.mode = SW_ADJ | SW_UPD | SW_FWD;
+        a.mode = SW_ADJ | SW_UPD | (c->wv.on ? 0 : SW_FWD);
         a.r = r_in;
         a.greg = greg_in;
         a.x_in = x_in;

@@ -146,6 +146,37 @@ class Engine(object):
         self._chk(self._lib.gh_misfit_and_grad(self._h, ptr(x), ptr(out3), ptr(grad), ptr(dpre)))
         return out3[0], grad, dpre, out3[1], out3[2]
 
+    # -- wavelet-compressed forward -----------------------------------------------
+    def compress_wavelet(self, dims, shape=None, thr=1e-3, levels=2):
+        shp = (C.c_int * 3)(*[int(v) for v in shape]) if shape is not None else None
+        nnz, ncols = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_compress_wavelet(self._h, int(dims), shp, float(thr), int(levels),
+                                                C.byref(nnz), C.byref(ncols)))
+        self.wavelet_nnz, self.wavelet_ncols = nnz.value, ncols.value
+        return nnz.value, ncols.value
+
+    def download_csr(self):
+        from scipy.sparse import csr_matrix
+        indptr = np.empty(self.N + 1, dtype=np.int64)
+        indices = np.empty(max(self.wavelet_nnz, 1), dtype=np.int32)
+        data = np.empty(max(self.wavelet_nnz, 1))
+        self._chk(self._lib.gh_download_csr(self._h, indptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            indices.ctypes.data_as(C.POINTER(C.c_int32)), ptr(data)))
+        n = self.wavelet_nnz
+        return csr_matrix((data[:n], indices[:n], indptr), shape=(self.N, self.wavelet_ncols))
+
+    def model_coeffs(self, mw):
+        mw = f64(mw)
+        out = np.empty(self.wavelet_ncols)
+        self._chk(self._lib.gh_model_coeffs(self._h, ptr(mw), ptr(out)))
+        return out
+
+    def forward_wavelet(self, mw):
+        mw = f64(mw)
+        d = np.empty(self.N)
+        self._chk(self._lib.gh_forward_wavelet(self._h, ptr(mw), ptr(d)))
+        return d
+
     # -- chain --------------------------------------------------------------------
     def chain_init(self, x0, low, high):
         x0, low, high = f64(x0), f64(low), f64(high)

@@ -114,8 +114,17 @@ class GravMagModule(object):
         self._say("End of weighting kernel: %.6f s" % (time.time() - start))
         eng.set_data(self.dobs, self.grav_fix if self.fixed else None)
         if wavelet in ('1D', '3D'):
+            # gravmag/compressor1D.py / compressor3D.py: db4, level 2, 'periodization',
+            # threshold 1e-3, CSR -- built and applied on the device
             self._say("Using {} wavelet to compress kernel.".format(wavelet))
-            raise NotImplementedError("wavelet-compressed forward operator is not built yet")
+            eng.compress_wavelet(3 if wavelet == '3D' else 1, self.mshape, 0.001, 2)
+
+    @property
+    def Awcp(self):
+        """Compressed kernel as scipy CSR (copied from the device on request)."""
+        if not self.wavelet:
+            raise AttributeError("Awcp exists only with wavelet='1D' or '3D'")
+        return self._engine.download_csr()
 
     # ------------------------------------------------------------------ weighting
     def sensitivityWeighting(self):

@@ -107,6 +107,25 @@ int gh_adjoint(gh_ctx *ctx, const double *r, double *g);
 int gh_misfit_and_grad(gh_ctx *ctx, const double *x, double out3[3], double *grad,
                        double *dpre);
 
+/* ---- wavelet-compressed forward operator (gravmag/compressor1D.py, compressor3D.py) ------ */
+
+/* Build the compressed kernel on the device: row-wise db4 / 'periodization' DWT of the weighted
+ * kernel (dims = 3: separable over shape3 = (nz,ny,nx) with nz*ny*nx == M; dims = 1: over the
+ * flat model, the variant carved meshes need), hard threshold |c| < thr -> 0, CSR with the
+ * column layout of pywt.coeffs_to_array.  Replaces compressor3D.kernelcompressor (:17-44) /
+ * compressor1D.kernelcompressor (:17-42); the reference uses thr = 1e-3, levels = 2.  After
+ * this call gh_misfit_and_grad and the chain evaluate the FORWARD product as
+ * Awcp @ DWT(mw) (modelcompressor, compressor3D.py:47-68) while the gradient keeps the exact
+ * dense Aw^T (potential.py:693-708).  nnz_out / ncols_out receive the CSR size (N x ncols). */
+int gh_compress_wavelet(gh_ctx *ctx, int dims, const int shape3[3], double thr, int levels,
+                        int64_t *nnz_out, int64_t *ncols_out);
+/* The CSR arrays (what GravMagModule.Awcp holds): indptr N+1, indices/data nnz. */
+int gh_download_csr(gh_ctx *ctx, int64_t *indptr, int32_t *indices, double *data);
+/* Packed wavelet coefficients of a model vector: pywt.coeffs_to_array(wavedec[n](mw))[0]. */
+int gh_model_coeffs(gh_ctx *ctx, const double *mw, double *coeff /* ncols */);
+/* d = Awcp @ DWT(mw)    (modelcompressor) */
+int gh_forward_wavelet(gh_ctx *ctx, const double *mw, double *dpre);
+
 /* ---- HMC chain (inversion/hmc.py:85-177) ----------------------------------------------- */
 
 /* Start (or restart) a chain at weighted model x0 with per-cell bounds low/high (weighted,

