@@ -155,26 +155,25 @@ def main():
     np.random.seed(100 + rank)
     Sigma, dt, L = 0.001, WORKLOADS[args.workload][4], args.traj_len
 
-    def draw(nsteps):
-        return np.random.randn(M) * Sigma, np.random.rand(), nsteps
-
     def run(total_steps):
-        """Trajectories of L steps until total_steps leapfrog steps are done; the momentum
-        of the next trajectory is drawn on the host while the GPU runs the current one."""
-        done, naccept, ntraj = 0, 0, 0
-        nxt = draw(min(L, total_steps))
-        while done < total_steps:
-            p0, u, n = nxt
-            res = {}
-            th = threading.Thread(target=lambda: res.update(r=eng.chain_trajectory(p0, dt, n, u)))
-            th.start()
-            done += n
-            if done < total_steps:
-                nxt = draw(min(L, total_steps - done))
-            th.join()
-            naccept += int(res["r"][0])
-            ntraj += 1
-        return naccept, ntraj
+        """Trajectories of L steps until total_steps leapfrog steps are done, pipelined as the
+        sampler does it (Engine.run_chain): momenta are drawn in the reference's RNG order one
+        trajectory ahead, so the host draw overlaps the GPU and an accepted proposal's last
+        sweep already takes the next trajectory's first step."""
+        plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
+
+        def draws():
+            for n in plan:
+                yield n, np.random.randn(M) * Sigma, np.random.rand()
+
+        stat = {"acc": 0, "traj": 0}
+
+        def on_result(n, acc, out5):
+            stat["acc"] += int(acc)
+            stat["traj"] += 1
+
+        eng.run_chain(draws(), dt, on_result)
+        return stat["acc"], stat["traj"]
 
     barrier = ranks.barrier
 
@@ -207,7 +206,7 @@ def main():
             "config": {"workload": args.workload, "N_obs": int(N), "M_cells": int(M),
                        "G_bytes": int(N) * int(M) * 8, "regulariser": "Damping",
                        "chains_per_gpu": 1, "dt": dt, "traj_len": L, "trajectories": ntraj,
-                       "accepted": naccept, "parallelism": "chain-parallel x%d (no collective)" % world,
+                       "accepted": naccept, "speculative_first_steps": eng.chain_stats(), "parallelism": "chain-parallel x%d (no collective)" % world,
                        "device": info["name"], "cus": info["cus"],
                        "G_build_s": round(t_build, 3), "weighting_s": round(t_weight, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "gh_chain_init": (C.c_int, [_ctx, _dp, _dp, _dp]),
     "gh_chain_trajectory": (C.c_int, [_ctx, _dp, C.c_double, C.c_int, C.c_double,
                                       C.POINTER(C.c_int), _dp]),
+    "gh_chain_prefetch_momentum": (C.c_int, [_ctx, _dp]),
+    "gh_chain_stats": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64)]),
     "gh_chain_get_x": (C.c_int, [_ctx, _dp]),
     "gh_chain_get_dsyn": (C.c_int, [_ctx, _dp]),
     "gh_leapfrog": (C.c_int, [_ctx, _dp, _dp, C.c_double, C.c_int, _dp, _dp, C.c_double,

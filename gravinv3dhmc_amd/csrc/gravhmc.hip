@@ -39,7 +39,8 @@ struct gh_ctx {
     int64_t warn_cells = 0, leaves = 0;
 
     // sweep configuration
-    int TW = 0, EPT2 = 0;
+    int TW = 0, EPT2 = 0, PF = 1;
+    bool NT = false;
     int n_teams = 0, grid = 0;
     int64_t cols_per_team = 0;
     size_t lds_bytes = 0;
@@ -51,15 +52,26 @@ struct gh_ctx {
     int reg_kind = 0, shape[3] = {1, 1, 1};
     double alpha = 1.0, beta = 0.01;
 
-    // chain state (at x_cur) and work buffers
-    double *x_cur = nullptr, *r_cur = nullptr, *greg_cur = nullptr, *d_cur = nullptr;
-    double *xw[2] = {nullptr, nullptr}, *pw[2] = {nullptr, nullptr};
-    double *r_w = nullptr, *greg_w = nullptr, *d_w = nullptr;
+    // chain state: three (r, greg, d, scal) sets and three x buffers rotate between "current
+    // sample", "proposal" and "speculative first step of the next trajectory"; set/buffer 3 is
+    // private to gh_misfit_and_grad.  Swapping indices makes accept/reject free.
+    struct StateSet {
+        double *r = nullptr, *greg = nullptr, *d = nullptr, *scal = nullptr;
+    } st[4];
+    double *xb[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *pb[2] = {nullptr, nullptr};
+    double *pn = nullptr;  // momentum of the NEXT trajectory (gh_chain_prefetch_momentum)
+    int cur = 0, xcur = 0;
+    bool pn_valid = false, spec_valid = false;
+    double pn_probe[3] = {0, 0, 0}, spec_probe[3] = {0, 0, 0};
+    double spec_dt = 0.0, spec_pp0 = 0.0, pn_pp0 = 0.0, spec_U[3] = {0, 0, 0};
+    int spec_set = 0, spec_x = 0, spec_p = 0;
+    int64_t spec_hits = 0, spec_misses = 0;
     double *slab = nullptr, *dpart = nullptr, *regpart = nullptr, *pp_part = nullptr,
-           *pp0_part = nullptr, *scal = nullptr;
+           *ppn_part = nullptr, *pp0_part = nullptr, *scal_all = nullptr;
     double *tmpM = nullptr, *tmpN = nullptr;
     int n_dpart = 0, n_regpart = 0, n_pp0 = 0;
-    double *h_scal = nullptr;  // pinned: 8 scalars + partial sums
+    double *h_scal = nullptr;  // pinned: scalars + partial sums
     size_t h_scal_n = 0;
     bool chain_ready = false;
     double U_cur[3] = {0, 0, 0};
@@ -147,19 +159,26 @@ static int d2h(gh_ctx *c, double *dst, const double *src, size_t n)
 typedef void (*sweep_fn)(SweepArgs);
 typedef void (*weight_fn)(double *, int64_t, int64_t, int64_t, int, double, double *);
 
-template <int TW>
-static sweep_fn pick_sweep(int ept2)
+template <int TW, int PF, bool NT>
+static sweep_fn pick_sweep_e(int ept2)
 {
     switch (ept2) {
-    case 1: return sweep_kernel<TW, 1>;
-    case 2: return sweep_kernel<TW, 2>;
-    case 3: return sweep_kernel<TW, 3>;
-    case 4: return sweep_kernel<TW, 4>;
-    case 5: return sweep_kernel<TW, 5>;
-    case 6: return sweep_kernel<TW, 6>;
-    case 8: return sweep_kernel<TW, 8>;
+    case 1: return sweep_kernel<TW, 1, PF, NT>;
+    case 2: return sweep_kernel<TW, 2, PF, NT>;
+    case 3: return sweep_kernel<TW, 3, PF, NT>;
+    case 4: return sweep_kernel<TW, 4, PF, NT>;
+    case 5: return sweep_kernel<TW, 5, PF, NT>;
+    case 6: return sweep_kernel<TW, 6, PF, NT>;
+    case 8: return sweep_kernel<TW, 8, PF, NT>;
     }
     return nullptr;
+}
+
+template <int TW>
+static sweep_fn pick_sweep(int ept2, int pf, bool nt)
+{
+    if (pf == 2) return nt ? pick_sweep_e<TW, 2, true>(ept2) : pick_sweep_e<TW, 2, false>(ept2);
+    return nt ? pick_sweep_e<TW, 1, true>(ept2) : pick_sweep_e<TW, 1, false>(ept2);
 }
 
 template <int TW>
@@ -179,9 +198,9 @@ static weight_fn pick_weight(int ept2)
 
 static sweep_fn sweep_for(const gh_ctx *c)
 {
-    if (c->TW == 1) return pick_sweep<1>(c->EPT2);
-    if (c->TW == 4) return pick_sweep<4>(c->EPT2);
-    return pick_sweep<16>(c->EPT2);
+    if (c->TW == 1) return pick_sweep<1>(c->EPT2, c->PF, c->NT);
+    if (c->TW == 4) return pick_sweep<4>(c->EPT2, c->PF, c->NT);
+    return pick_sweep<16>(c->EPT2, c->PF, c->NT);
 }
 
 static weight_fn weight_for(const gh_ctx *c)
@@ -214,6 +233,9 @@ static int configure_sweep(gh_ctx *c)
     if (e == 7) e = 8;
     c->TW = tw;
     c->EPT2 = e;
+    c->PF = env_int("GRAVHMC_PF", 1) == 2 ? 2 : 1;
+    // G larger than the Infinity Cache is streamed once per sweep: bypass-friendly loads
+    c->NT = env_int("GRAVHMC_NT", c->ld * c->M * 8 > (int64_t)(512 << 20) ? 1 : 0) != 0;
     const int wg_teams = (tw == 1) ? 4 : 1;
     // resident workgroups per CU we size the grid for (register/LDS budget of the kernel)
     int wg_per_cu = (tw == 16) ? 1 : 4;
@@ -383,9 +405,9 @@ static int wavelet_forward(gh_ctx *c, const double *x, double *d_out)
 }
 
 // slab -> d ; regulariser ; residual + scalars.  x: position the forward belongs to.
-static int finalize(gh_ctx *c, const double *x, double *d_out, double *r_out, double *greg_out,
-                    double *scal_out)
+static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
 {
+    double *d_out = o.d, *r_out = o.r, *greg_out = o.greg, *scal_out = o.scal;
     if (c->wv.on) {
         // forward through the compressed operator; d_out then acts as a one-row slab
         TRY(wavelet_forward(c, x, d_out));
@@ -427,8 +449,7 @@ static int finalize(gh_ctx *c, const double *x, double *d_out, double *r_out, do
 }
 
 // forward sweep of x (device) + finalize
-static int eval_forward(gh_ctx *c, const double *x, double *d_out, double *r_out,
-                        double *greg_out, double *scal_out)
+static int eval_forward(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
 {
     if (!c->wv.on) {
         SweepArgs a{};
@@ -437,23 +458,23 @@ static int eval_forward(gh_ctx *c, const double *x, double *d_out, double *r_out
         a.slab = c->slab;
         TRY(launch_sweep(c, a));
     }
-    return finalize(c, x, d_out, r_out, greg_out, scal_out);
+    return finalize(c, x, o);
 }
 
 static int ensure_work(gh_ctx *c)
 {
     const size_t M = (size_t)c->M, ld = (size_t)c->ld;
-    TRY(dalloc(c, &c->x_cur, M));
-    TRY(dalloc(c, &c->r_cur, ld));
-    TRY(dalloc(c, &c->greg_cur, M));
-    TRY(dalloc(c, &c->d_cur, ld));
-    for (int i = 0; i < 2; ++i) {
-        TRY(dalloc(c, &c->xw[i], M));
-        TRY(dalloc(c, &c->pw[i], M));
+    TRY(dalloc(c, &c->scal_all, 16));
+    for (int i = 0; i < 4; ++i) {
+        TRY(dalloc(c, &c->st[i].r, ld));
+        TRY(dalloc(c, &c->st[i].greg, M));
+        TRY(dalloc(c, &c->st[i].d, ld));
+        c->st[i].scal = c->scal_all + 4 * i;
+        TRY(dalloc(c, &c->xb[i], M));
     }
-    TRY(dalloc(c, &c->r_w, ld));
-    TRY(dalloc(c, &c->greg_w, M));
-    TRY(dalloc(c, &c->d_w, ld));
+    TRY(dalloc(c, &c->pb[0], M));
+    TRY(dalloc(c, &c->pb[1], M));
+    TRY(dalloc(c, &c->pn, M));
     TRY(dalloc(c, &c->slab, (size_t)c->grid * ld));
     c->n_dpart = (int)((c->ld + 31) / 32);
     c->n_regpart = (int)((c->M + 255) / 256);
@@ -461,8 +482,8 @@ static int ensure_work(gh_ctx *c)
     TRY(dalloc(c, &c->dpart, (size_t)c->n_dpart));
     TRY(dalloc(c, &c->regpart, (size_t)c->n_regpart));
     TRY(dalloc(c, &c->pp_part, (size_t)c->n_teams));
+    TRY(dalloc(c, &c->ppn_part, (size_t)c->n_teams));
     TRY(dalloc(c, &c->pp0_part, (size_t)c->n_pp0));
-    TRY(dalloc(c, &c->scal, 16));
     TRY(dalloc(c, &c->tmpM, M));
     TRY(dalloc(c, &c->tmpN, ld));
     TRY(dalloc(c, &c->low, M));
@@ -474,7 +495,7 @@ static int ensure_work(gh_ctx *c)
         TRY(dalloc(c, &c->wm2, M));
     }
     if (!c->h_scal) {
-        c->h_scal_n = 16 + (size_t)c->n_teams + (size_t)c->n_pp0;
+        c->h_scal_n = 16 + 2 * (size_t)c->n_teams + (size_t)c->n_pp0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_scal, c->h_scal_n * sizeof(double)));
     }
     return GH_OK;
@@ -831,17 +852,18 @@ int gh_misfit_and_grad(gh_ctx *c, const double *x, double out3[3], double *grad,
              "gh_misfit_and_grad: needs a kernel matrix, gh_set_data and gh_set_reg"));
     HIPCHK(c, hipSetDevice(c->device));
     TRY(ensure_work(c));
-    TRY(h2d(c, c->xw[0], x, (size_t)c->M));
-    TRY(eval_forward(c, c->xw[0], c->d_w, c->r_w, c->greg_w, c->scal));
+    const gh_ctx::StateSet &o = c->st[3];
+    TRY(h2d(c, c->xb[3], x, (size_t)c->M));
+    TRY(eval_forward(c, c->xb[3], o));
     SweepArgs a{};
     a.mode = SW_ADJ | SW_GOUT;
-    a.r = c->r_w;
-    a.greg = c->greg_w;
+    a.r = o.r;
+    a.greg = o.greg;
     a.g_out = c->tmpM;
     TRY(launch_sweep(c, a));
-    HIPCHK(c, hipMemcpyAsync(c->h_scal, c->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scal, o.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TRY(d2h(c, grad, c->tmpM, (size_t)c->M));
-    if (dpre) TRY(d2h(c, dpre, c->d_w, (size_t)c->N));
+    if (dpre) TRY(d2h(c, dpre, o.d, (size_t)c->N));
     out3[0] = c->h_scal[2];
     out3[1] = c->h_scal[0];
     out3[2] = c->h_scal[1];
@@ -981,16 +1003,48 @@ int gh_chain_init(gh_ctx *c, const double *x0, const double *low, const double *
              "gh_chain_init: needs a kernel matrix, gh_set_data and gh_set_reg"));
     HIPCHK(c, hipSetDevice(c->device));
     TRY(ensure_work(c));
-    TRY(h2d(c, c->x_cur, x0, (size_t)c->M));
+    c->cur = 0;
+    c->xcur = 0;
+    c->spec_valid = c->pn_valid = false;
+    TRY(h2d(c, c->xb[0], x0, (size_t)c->M));
     TRY(h2d(c, c->low, low, (size_t)c->M));
     TRY(h2d(c, c->high, high, (size_t)c->M));
-    TRY(eval_forward(c, c->x_cur, c->d_cur, c->r_cur, c->greg_cur, c->scal));
-    TRY(d2h(c, c->h_scal, c->scal, 4));
+    TRY(eval_forward(c, c->xb[0], c->st[0]));
+    TRY(d2h(c, c->h_scal, c->st[0].scal, 4));
     c->U_cur[0] = c->h_scal[2];
     c->U_cur[1] = c->h_scal[0];
     c->U_cur[2] = c->h_scal[1];
     c->chain_ready = true;
     return GH_OK;
+}
+
+int gh_chain_prefetch_momentum(gh_ctx *c, const double *p0_next)
+{
+    if (!c || !p0_next) return fail(c, GH_ERR_ARG, "gh_chain_prefetch_momentum: null pointer");
+    TRY(need(c, c->chain_ready, "gh_chain_prefetch_momentum: call gh_chain_init first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(h2d(c, c->pn, p0_next, (size_t)c->M));
+    // initial kinetic energy of that trajectory, summed exactly like the non-speculative path
+    sumsq_kernel<<<dim3(c->n_pp0), dim3(256), 0, c->stream>>>(c->pn, c->M, c->pp0_part);
+    {
+        std::vector<double> part((size_t)c->n_pp0);
+        TRY(d2h(c, part.data(), c->pp0_part, (size_t)c->n_pp0));
+        double s = 0.0;
+        for (double v : part) s += v;
+        c->pn_pp0 = s;
+    }
+    c->pn_probe[0] = p0_next[0];
+    c->pn_probe[1] = p0_next[c->M / 2];
+    c->pn_probe[2] = p0_next[c->M - 1];
+    c->pn_valid = true;
+    return GH_OK;
+}
+
+static inline int other_of3(int a, int b)
+{
+    for (int i = 0; i < 3; ++i)
+        if (i != a && i != b) return i;
+    return 0;
 }
 
 int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u, int *accepted,
@@ -1001,70 +1055,128 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     if (L < 1) return fail(c, GH_ERR_ARG, "gh_chain_trajectory: L must be >= 1");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t M = (size_t)c->M;
-    // momentum upload + kinetic energy of p0 (hmc.py:95-104)
-    HIPCHK(c, hipMemcpyAsync(c->pw[0], p0, M * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    sumsq_kernel<<<dim3(c->n_pp0), dim3(256), 0, c->stream>>>(c->pw[0], c->M, c->pp0_part);
-    const double *x_in = c->x_cur, *r_in = c->r_cur, *greg_in = c->greg_cur;
-    int pin = 0;  // pw[pin] holds the current momentum
-    int xo = 0;   // next x output buffer
-    for (int s = 0; s < L; ++s) {
+    const int nt = c->n_teams;
+    // Was the first step of this trajectory already taken speculatively by the previous call's
+    // last sweep (same momentum, same dt, previous proposal accepted)?
+    const bool use_spec = c->spec_valid && c->spec_dt == dt && p0[0] == c->spec_probe[0] &&
+                          p0[c->M / 2] == c->spec_probe[1] && p0[c->M - 1] == c->spec_probe[2];
+    int xin, pin, sin, s0;
+    if (use_spec) {
+        xin = c->spec_x;
+        pin = c->spec_p;
+        sin = c->spec_set;
+        s0 = 1;
+        c->spec_hits += 1;
+    } else {
+        // momentum upload + kinetic energy of p0 (hmc.py:95-104)
+        HIPCHK(c, hipMemcpyAsync(c->pb[0], p0, M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        sumsq_kernel<<<dim3(c->n_pp0), dim3(256), 0, c->stream>>>(c->pb[0], c->M, c->pp0_part);
+        xin = c->xcur;
+        pin = 0;
+        sin = c->cur;
+        s0 = 0;
+        if (c->spec_valid) c->spec_misses += 1;
+    }
+    c->spec_valid = false;
+    for (int s = s0; s < L; ++s) {
+        const int xout = other_of3(c->xcur, xin);
+        const int sout = (sin != c->cur) ? sin : other_of3(c->cur, c->cur);
         SweepArgs a{};
         a.mode = SW_ADJ | SW_UPD | (c->wv.on ? 0 : SW_FWD);
-        a.r = r_in;
-        a.greg = greg_in;
-        a.x_in = x_in;
-        a.p_in = c->pw[pin];
-        a.x_out = c->xw[xo];
-        a.p_out = c->pw[pin ^ 1];
+        a.r = c->st[sin].r;
+        a.greg = c->st[sin].greg;
+        a.x_in = c->xb[xin];
+        a.p_in = c->pb[pin];
+        a.x_out = c->xb[xout];
+        a.p_out = c->pb[pin ^ 1];
         a.low = c->low;
         a.high = c->high;
-        a.c_p = (s == 0) ? dt * 0.5 : dt;
+        a.c_u = (s == 0) ? dt * 0.5 : dt;
         a.dt = dt;
         a.slab = c->slab;
         TRY(launch_sweep(c, a));
-        TRY(finalize(c, c->xw[xo], c->d_w, c->r_w, c->greg_w, c->scal));
-        x_in = c->xw[xo];
-        r_in = c->r_w;
-        greg_in = c->greg_w;
+        TRY(finalize(c, c->xb[xout], c->st[sout]));
+        xin = xout;
         pin ^= 1;
-        xo ^= 1;
+        sin = sout;
     }
-    // last half step of the momentum + kinetic energy (hmc.py:151-157)
+    // Last half step of the momentum + kinetic energy (hmc.py:151-157).  When the caller has
+    // announced the next trajectory's momentum, the same sweep also takes that trajectory's
+    // first leapfrog step from the proposal (valid if the proposal is accepted): the gradient
+    // at the proposal is needed by both, so the extra sweep per trajectory disappears.
+    const bool spec = c->pn_valid;
+    const double probe[3] = {c->pn_probe[0], c->pn_probe[1], c->pn_probe[2]};
+    const double pn_pp0 = c->pn_pp0;
+    const int xs = other_of3(c->xcur, xin), ss = other_of3(c->cur, sin);
     {
         SweepArgs a{};
         a.mode = SW_ADJ | SW_PFIN;
-        a.r = r_in;
-        a.greg = greg_in;
-        a.p_in = c->pw[pin];
-        a.p_out = c->pw[pin ^ 1];
+        a.r = c->st[sin].r;
+        a.greg = c->st[sin].greg;
+        a.p_in = c->pb[pin];
+        a.p_out = c->pb[pin ^ 1];
         a.c_p = dt * 0.5;
         a.pp_part = c->pp_part;
+        if (spec) {
+            a.mode |= SW_SPEC | SW_UPD | (c->wv.on ? 0 : SW_FWD);
+            a.pn_in = c->pn;
+            a.ppn_part = c->ppn_part;
+            a.x_in = c->xb[xin];
+            a.x_out = c->xb[xs];
+            a.low = c->low;
+            a.high = c->high;
+            a.c_u = dt * 0.5;
+            a.dt = dt;
+            a.slab = c->slab;
+        }
         TRY(launch_sweep(c, a));
+        if (spec) TRY(finalize(c, c->xb[xs], c->st[ss]));
     }
     double *h = c->h_scal;
-    HIPCHK(c, hipMemcpyAsync(h, c->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h + 16, c->pp_part, (size_t)c->n_teams * sizeof(double),
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h + 16 + c->n_teams, c->pp0_part, (size_t)c->n_pp0 * sizeof(double),
-                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h, c->st[sin].scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + 16, c->pp_part, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost,
+                             c->stream));
+    if (spec) {
+        HIPCHK(c, hipMemcpyAsync(h + 4, c->st[ss].scal, 4 * sizeof(double), hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipMemcpyAsync(h + 16 + nt, c->ppn_part, (size_t)nt * sizeof(double),
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!use_spec)
+        HIPCHK(c, hipMemcpyAsync(h + 16 + 2 * nt, c->pp0_part, (size_t)c->n_pp0 * sizeof(double),
+                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double pp1 = 0.0, pp0 = 0.0;
-    for (int t = 0; t < c->n_teams; ++t) pp1 += h[16 + t];
-    for (int t = 0; t < c->n_pp0; ++t) pp0 += h[16 + c->n_teams + t];
+    for (int t = 0; t < nt; ++t) pp1 += h[16 + t];
+    if (use_spec)
+        pp0 = c->spec_pp0;
+    else
+        for (int t = 0; t < c->n_pp0; ++t) pp0 += h[16 + 2 * nt + t];
     const double Unew[3] = {h[2], h[0], h[1]};
     const double Hcur = 0.5 * pp0 + c->U_cur[0];
     const double Hnew = 0.5 * pp1 + Unew[0];
     const bool acc = (Hnew < Hcur) || (u < std::exp(-(Hnew - Hcur)));
     if (acc) {
-        // the proposal lives in xw[xo^1]; make it the chain state by swapping buffers
-        std::swap(c->x_cur, c->xw[xo ^ 1]);
-        std::swap(c->r_cur, c->r_w);
-        std::swap(c->greg_cur, c->greg_w);
-        std::swap(c->d_cur, c->d_w);
+        c->xcur = xin;
+        c->cur = sin;
         c->U_cur[0] = Unew[0];
         c->U_cur[1] = Unew[1];
         c->U_cur[2] = Unew[2];
+        if (spec) {
+            c->spec_valid = true;
+            c->spec_dt = dt;
+            c->spec_pp0 = pn_pp0;
+            c->spec_x = xs;
+            c->spec_p = pin ^ 1;
+            c->spec_set = ss;
+            c->spec_probe[0] = probe[0];
+            c->spec_probe[1] = probe[1];
+            c->spec_probe[2] = probe[2];
+        }
+    } else if (spec) {
+        c->spec_misses += 1;  // the speculative step belonged to a rejected proposal
     }
+    c->pn_valid = false;
     *accepted = acc ? 1 : 0;
     out5[0] = c->U_cur[0];
     out5[1] = c->U_cur[1];
@@ -1079,7 +1191,7 @@ int gh_chain_get_x(gh_ctx *c, double *x)
     if (!c || !x) return fail(c, GH_ERR_ARG, "gh_chain_get_x: null pointer");
     TRY(need(c, c->chain_ready, "gh_chain_get_x: call gh_chain_init first"));
     HIPCHK(c, hipSetDevice(c->device));
-    return d2h(c, x, c->x_cur, (size_t)c->M);
+    return d2h(c, x, c->xb[c->xcur], (size_t)c->M);
 }
 
 int gh_chain_get_dsyn(gh_ctx *c, double *dsyn)
@@ -1087,7 +1199,15 @@ int gh_chain_get_dsyn(gh_ctx *c, double *dsyn)
     if (!c || !dsyn) return fail(c, GH_ERR_ARG, "gh_chain_get_dsyn: null pointer");
     TRY(need(c, c->chain_ready, "gh_chain_get_dsyn: call gh_chain_init first"));
     HIPCHK(c, hipSetDevice(c->device));
-    return d2h(c, dsyn, c->d_cur, (size_t)c->N);
+    return d2h(c, dsyn, c->st[c->cur].d, (size_t)c->N);
+}
+
+int gh_chain_stats(gh_ctx *c, int64_t *spec_hits, int64_t *spec_misses)
+{
+    if (!c) return GH_ERR_ARG;
+    if (spec_hits) *spec_hits = c->spec_hits;
+    if (spec_misses) *spec_misses = c->spec_misses;
+    return GH_OK;
 }
 
 int gh_leapfrog(gh_ctx *c, double *x_inout, const double *p0, double dt, int L, const double *low,

@@ -51,7 +51,9 @@ enum : int {
     SW_UPD = 2,   // leapfrog momentum + position update with clamp-and-reflect
     SW_FWD = 4,   // accumulate G_j * x_j into the team's forward partial
     SW_PFIN = 8,  // final half-step momentum update + sum of p^2 (needs SW_ADJ)
-    SW_GOUT = 16  // write the gradient 2*dot + greg to g_out (needs SW_ADJ)
+    SW_GOUT = 16, // write the gradient 2*dot + greg to g_out (needs SW_ADJ)
+    SW_SPEC = 32  // with SW_PFIN|SW_UPD|SW_FWD: the update part is the FIRST step of the next
+                  // trajectory, taken speculatively from its freshly drawn momentum pn_in
 };
 
 struct SweepArgs {
@@ -68,22 +70,28 @@ struct SweepArgs {
     double *x_out;        // M (SW_UPD)   -- never aliases x_in: other waves of the team may
     double *p_out;        // M (SW_UPD, SW_PFIN)  still be reading the inputs
     const double *low, *high;
-    double c_p;           // momentum coefficient for this sweep (dt or dt/2)
+    double c_p;           // momentum coefficient of the SW_PFIN half step (dt/2)
+    double c_u;           // momentum coefficient of the SW_UPD step (dt, or dt/2 for a first step)
     double dt;            // position step
+    const double *pn_in;  // M (SW_SPEC): momentum drawn for the next trajectory
+    double *ppn_part;     // n_teams (SW_SPEC): sum of pn_j^2 (its initial kinetic energy)
     double *g_out;        // M (SW_GOUT)
     double *slab;         // gridDim.x x ld (SW_FWD)
     double *pp_part;      // n_teams (SW_PFIN): sum of p_j^2 over the team's columns
 };
 
+using d2 = double __attribute__((ext_vector_type(2)));
+
 template <int EPT2>
 struct ColRegs {
-    double2 v[EPT2];
-    double p, x, lo, hi, gr;  // per-column scalars, prefetched with the column
+    d2 v[EPT2];
+    double p, x, lo, hi, gr, pn;  // per-column scalars, prefetched with the column
 };
 
 // TW = waves per team (1, 4, 16).  TW == 1: four independent wave-teams per 256-thread block.
 // EPT2 = double2 elements held per thread: capacity = TW*64*EPT2*2 rows >= ld.
-template <int TW, int EPT2>
+// PF = columns prefetched ahead (1 or 2).  NT = non-temporal loads of G (streamed once).
+template <int TW, int EPT2, int PF, bool NT>
 __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArgs a)
 {
     constexpr int TEAM_THREADS = TW * 64;
@@ -100,13 +108,13 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     const int ttid = (TW == 1) ? lane : tid;  // thread index inside the team
     const int team = blockIdx.x * WG_TEAMS + ((TW == 1) ? wave : 0);
     const int64_t ld = a.ld;
-    const int64_t ld2 = ld >> 1;  // in double2 units
+    const int ld2 = (int)(ld >> 1);  // in double2 units
     const int mode = a.mode;
 
     if (mode & SW_ADJ) {
-        const double2 *r2 = reinterpret_cast<const double2 *>(a.r);
-        double2 *rs2 = reinterpret_cast<double2 *>(r_s);
-        for (int64_t e = tid; e < ld2; e += blockDim.x) rs2[e] = r2[e];
+        const d2 *r2 = reinterpret_cast<const d2 *>(a.r);
+        d2 *rs2 = reinterpret_cast<d2 *>(r_s);
+        for (int e = tid; e < ld2; e += blockDim.x) rs2[e] = r2[e];
     }
     __syncthreads();
 
@@ -115,26 +123,25 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     if (j1 > a.M) j1 = a.M;
     if (team >= a.n_teams) j0 = j1 = 0;
 
-    ColRegs<EPT2> cur, nxt;
-    double2 dacc[EPT2];
+    d2 dacc[EPT2];
 #pragma unroll
-    for (int k = 0; k < EPT2; ++k) {
-        dacc[k] = make_double2(0.0, 0.0);
-        nxt.v[k] = make_double2(0.0, 0.0);
-    }
-    nxt.p = nxt.x = nxt.lo = nxt.hi = nxt.gr = 0.0;
-    double pp = 0.0;
+    for (int k = 0; k < EPT2; ++k) dacc[k] = d2{0.0, 0.0};
+    double pp = 0.0, ppn = 0.0;
 
     auto load_col = [&](ColRegs<EPT2> &c, int64_t j) {
-        const double2 *col = reinterpret_cast<const double2 *>(a.G + j * ld);
+        const d2 *col = reinterpret_cast<const d2 *>(a.G + j * ld);
 #pragma unroll
         for (int k = 0; k < EPT2; ++k) {
-            const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
-            c.v[k] = (e < ld2) ? col[e] : make_double2(0.0, 0.0);
+            const int e = k * TEAM_THREADS + ttid;
+            if (e < ld2)
+                c.v[k] = NT ? __builtin_nontemporal_load(col + e) : col[e];
+            else
+                c.v[k] = d2{0.0, 0.0};
         }
         c.gr = a.greg ? a.greg[j] : 0.0;
         c.x = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
         c.p = (mode & (SW_UPD | SW_PFIN)) ? a.p_in[j] : 0.0;
+        c.pn = (mode & SW_SPEC) ? a.pn_in[j] : 0.0;
         if (mode & SW_UPD) {
             c.lo = a.low[j];
             c.hi = a.high[j];
@@ -143,26 +150,24 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
         }
     };
 
-    // TW > 1: one team per block, so every wave takes the same trip count (barrier inside)
-    if (j0 < j1) load_col(cur, j0);
-    for (int64_t j = j0; j < j1; ++j) {
-        if (j + 1 < j1) load_col(nxt, j + 1);
+    // one column: adjoint dot, leapfrog update, forward accumulation.  `it` = j - j0.
+    auto process = [&](const ColRegs<EPT2> &cur, int64_t j, int it) {
         double xj = cur.x;
         if (mode & SW_ADJ) {
-            const double2 *rs2 = reinterpret_cast<const double2 *>(r_s);
+            const d2 *rs2 = reinterpret_cast<const d2 *>(r_s);
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < EPT2; ++k) {
-                const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
+                const int e = k * TEAM_THREADS + ttid;
                 if (e < ld2) {
-                    const double2 rv = rs2[e];
+                    const d2 rv = rs2[e];
                     s += cur.v[k].x * rv.x;
                     s += cur.v[k].y * rv.y;
                 }
             }
             s = wave_allreduce_sum(s);
             if (TW > 1) {
-                double *red = scratch + ((j - j0) & 1) * TW;
+                double *red = scratch + (it & 1) * TW;
                 if (lane == 0) red[wave] = s;
                 __syncthreads();
                 double t = 0.0;
@@ -172,8 +177,15 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
             }
             const double g = 2.0 * s + cur.gr;
             if ((mode & SW_GOUT) && ttid == 0) a.g_out[j] = g;
+            if (mode & SW_PFIN) {
+                const double pf = cur.p - a.c_p * g;
+                pp += pf * pf;
+                if (!(mode & SW_SPEC) && ttid == 0) a.p_out[j] = pf;
+            }
             if (mode & SW_UPD) {
-                double pj = cur.p - a.c_p * g;
+                const double psrc = (mode & SW_SPEC) ? cur.pn : cur.p;
+                ppn += psrc * psrc;
+                double pj = psrc - a.c_u * g;
                 xj = cur.x + a.dt * pj;
                 if (xj > cur.hi) {
                     xj = cur.hi;
@@ -186,10 +198,6 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
                     a.p_out[j] = pj;
                     a.x_out[j] = xj;
                 }
-            } else if (mode & SW_PFIN) {
-                const double pj = cur.p - a.c_p * g;
-                if (ttid == 0) a.p_out[j] = pj;
-                pp += pj * pj;
             }
         }
         if (mode & SW_FWD) {
@@ -199,35 +207,62 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
                 dacc[k].y += cur.v[k].y * xj;
             }
         }
-        cur = nxt;
+    };
+
+    // TW > 1: one team per block, so every wave takes the same trip count (barrier inside)
+    if (PF == 1) {
+        ColRegs<EPT2> b0, b1;
+        if (j0 < j1) load_col(b0, j0);
+        int64_t j = j0;
+        while (j < j1) {
+            if (j + 1 < j1) load_col(b1, j + 1);
+            process(b0, j, (int)(j - j0));
+            if (++j >= j1) break;
+            if (j + 1 < j1) load_col(b0, j + 1);
+            process(b1, j, (int)(j - j0));
+            ++j;
+        }
+    } else {
+        ColRegs<EPT2> b0, b1, b2;
+        if (j0 < j1) load_col(b0, j0);
+        if (j0 + 1 < j1) load_col(b1, j0 + 1);
+        int64_t j = j0;
+        while (j < j1) {
+            if (j + 2 < j1) load_col(b2, j + 2);
+            process(b0, j, (int)(j - j0));
+            if (++j >= j1) break;
+            if (j + 2 < j1) load_col(b0, j + 2);
+            process(b1, j, (int)(j - j0));
+            if (++j >= j1) break;
+            if (j + 2 < j1) load_col(b1, j + 2);
+            process(b2, j, (int)(j - j0));
+            ++j;
+        }
     }
 
     if ((mode & SW_PFIN) && ttid == 0 && team < a.n_teams) a.pp_part[team] = pp;
+    if ((mode & SW_SPEC) && ttid == 0 && team < a.n_teams) a.ppn_part[team] = ppn;
 
     if (mode & SW_FWD) {
         if (TW == 1) {
             // sum the block's four wave-teams through LDS, then one slab row per block
-            double2 *sc2 = reinterpret_cast<double2 *>(scratch);
+            d2 *sc2 = reinterpret_cast<d2 *>(scratch);
 #pragma unroll
             for (int k = 0; k < EPT2; ++k) {
-                const int64_t e = (int64_t)k * 64 + lane;
+                const int e = k * 64 + lane;
                 if (e < ld2) sc2[wave * ld2 + e] = dacc[k];
             }
             __syncthreads();
-            double2 *out = reinterpret_cast<double2 *>(a.slab + (int64_t)blockIdx.x * ld);
-            for (int64_t e = tid; e < ld2; e += blockDim.x) {
-                const double2 s0 = sc2[e], s1 = sc2[ld2 + e], s2 = sc2[2 * ld2 + e],
-                              s3 = sc2[3 * ld2 + e];
-                double2 t;
-                t.x = ((s0.x + s1.x) + s2.x) + s3.x;
-                t.y = ((s0.y + s1.y) + s2.y) + s3.y;
-                out[e] = t;
+            d2 *out = reinterpret_cast<d2 *>(a.slab + (int64_t)blockIdx.x * ld);
+            for (int e = tid; e < ld2; e += blockDim.x) {
+                const d2 s0 = sc2[e], s1 = sc2[ld2 + e], s2 = sc2[2 * ld2 + e], s3 = sc2[3 * ld2 + e];
+                out[e] = ((s0 + s1) + s2) + s3;
             }
         } else {
-            double2 *out = reinterpret_cast<double2 *>(a.slab + (int64_t)blockIdx.x * ld);
+            d2 *out = reinterpret_cast<d2 *>(a.slab + (int64_t)blockIdx.x * ld);
 #pragma unroll
             for (int k = 0; k < EPT2; ++k) {
-                const int64_t e = (int64_t)k * TEAM_THREADS + ttid;
+                const int e = k * TEAM_THREADS + ttid;
                 if (e < ld2) out[e] = dacc[k];
             }
         }

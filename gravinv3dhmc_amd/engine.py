@@ -44,6 +44,7 @@ class Engine(object):
         check(rc, None)
         self._h = h
         self._reg_key = None
+        self._chain_valid = False
 
     # -- lifetime -----------------------------------------------------------------
     def close(self):
@@ -127,6 +128,7 @@ class Engine(object):
         shp = (C.c_int * 3)(*[int(s) for s in shape]) if shape is not None else None
         self._chk(self._lib.gh_set_reg(self._h, _lib.REG_KINDS[regularization], float(alpha),
                                        float(beta), shp, ptr(mwapr)))
+        self._chain_valid = False
 
     def forward(self, mw):
         mw = f64(mw)
@@ -181,6 +183,7 @@ class Engine(object):
     def chain_init(self, x0, low, high):
         x0, low, high = f64(x0), f64(low), f64(high)
         self._chk(self._lib.gh_chain_init(self._h, ptr(x0), ptr(low), ptr(high)))
+        self._chain_valid = True
 
     def chain_trajectory(self, p0, dt, L, u):
         p0 = f64(p0)
@@ -189,6 +192,49 @@ class Engine(object):
         self._chk(self._lib.gh_chain_trajectory(self._h, ptr(p0), float(dt), int(L), float(u),
                                                 C.byref(acc), ptr(out5)))
         return bool(acc.value), out5
+
+    def chain_prefetch_momentum(self, p0_next):
+        p0_next = f64(p0_next)
+        self._chk(self._lib.gh_chain_prefetch_momentum(self._h, ptr(p0_next)))
+
+    def chain_stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_chain_stats(self._h, C.byref(a), C.byref(b)))
+        return {"spec_hits": a.value, "spec_misses": b.value}
+
+    def run_chain(self, draws, dt, on_result, max_trajectories=None):
+        """Pipelined trajectories: `draws` yields (L, p0, u) in RNG-stream order; the momentum
+        of trajectory k+1 is announced before trajectory k runs (speculative first step) and
+        trajectory k+2 is drawn on the host while the GPU works.  `on_result(L, accepted, out5)`
+        returns False to stop."""
+        import threading
+        it = iter(draws)
+        cur = next(it, None)
+        nxt = next(it, None) if cur is not None else None
+        n = 0
+        while cur is not None:
+            if nxt is not None:
+                self.chain_prefetch_momentum(nxt[1])
+            res = {}
+
+            def work(cur=cur):
+                try:
+                    res["r"] = self.chain_trajectory(cur[1], dt, cur[0], cur[2])
+                except BaseException as e:  # re-raised in the caller's thread
+                    res["e"] = e
+
+            th = threading.Thread(target=work)
+            th.start()
+            nn = next(it, None) if nxt is not None else None   # drawn while the GPU runs
+            th.join()
+            if "e" in res:
+                raise res["e"]
+            n += 1
+            if on_result(cur[0], res["r"][0], res["r"][1]) is False:
+                break
+            if max_trajectories is not None and n >= max_trajectories:
+                break
+            cur, nxt = nxt, nn
 
     def chain_get_x(self):
         x = np.empty(self.M)

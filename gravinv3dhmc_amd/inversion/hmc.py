@@ -59,7 +59,7 @@ class HamitonianMC(object):
             return self._leapfrog_unfused(xcur, pcur, dt, L, alpha)
         eng = self.model._engine
         self.model._use_reg(self.regularization, alpha, self.beta, self.aprior_model)
-        if self._chain_x is None or self._chain_x is not xcur:
+        if self._chain_x is None or self._chain_x is not xcur or not eng._chain_valid:
             eng.chain_init(xcur, self.low, self.high)
         u = np.random.rand()
         accepted, out5 = eng.chain_trajectory(pcur, dt, L, u)
@@ -137,29 +137,56 @@ class HamitonianMC(object):
         i = 0
         alpha = self.RegulFactor
         self._chain_x = None
-        while i < ndraws + nsamples:
-            L = np.random.randint(self.Lrange[0], self.Lrange[1] + 1)
-            x, U, _, AcceptFlag, U_data, U_model = self._leapfrog(x, self.dt, L, alpha, i)
+        state = {"x": x, "i": 0, "ncount": 0}
+
+        def record(U, U_data, U_model, AcceptFlag, get_x):
+            """Bookkeeping of one finished trajectory (hmc.py:299-342)."""
             U_data_normed = U_data / data_size
             U_model_normed = U_model / model_size
             U_normed = U_data_normed + alpha * U_model_normed
             if AcceptFlag:
-                if i >= ndraws:
+                state["x"] = get_x()
+                if state["i"] >= ndraws:
                     misfit[0, :] = (U, U_data, U_model, U_normed, U_data_normed, U_model_normed,
                                     alpha)
                     self._save_misfit_add(misfit)
-                    m = WmInv @ self._to_mw(x)
+                    m = WmInv @ self._to_mw(state["x"])
                     m_cache[0, :] = m.copy()
                     self._save_models_add(m_cache)
-                i += 1
-            ncount += 1
-            if i > -1:
-                msg = "chain {}: {:.2%}, misfit(total, data, alpha, model)=({:.7f},{:.7f},{:.2f},{:.7f}) " \
-                      "-- accept ratio {:.2%}\n". \
-                    format(self.myrank, i / (ndraws + nsamples), U_normed, U_data_normed, alpha,
-                           U_model_normed, i / ncount)
-                print(msg)
-                sys.stdout.flush()
+                state["i"] += 1
+            state["ncount"] += 1
+            msg = "chain {}: {:.2%}, misfit(total, data, alpha, model)=({:.7f},{:.7f},{:.2f},{:.7f}) " \
+                  "-- accept ratio {:.2%}\n". \
+                format(self.myrank, state["i"] / (ndraws + nsamples), U_normed, U_data_normed, alpha,
+                       U_model_normed, state["i"] / state["ncount"])
+            print(msg)
+            sys.stdout.flush()
+            return state["i"] < ndraws + nsamples
+
+        if self.constraint == 'mandatory' and ndraws + nsamples > 0:
+            # device-resident chain, trajectories pipelined (see Engine.run_chain): the random
+            # numbers are drawn in the reference's order, only earlier in wall-clock time
+            eng = self.model._engine
+            self.model._use_reg(self.regularization, alpha, self.beta, self.aprior_model)
+            eng.chain_init(x, self.low, self.high)
+            n = len(x)
+
+            def draws():
+                while True:
+                    L = np.random.randint(self.Lrange[0], self.Lrange[1] + 1)
+                    p0 = np.random.randn(n) * self.Sigma
+                    yield L, p0, np.random.rand()
+
+            eng.run_chain(draws(), self.dt,
+                          lambda L, acc, o: record(o[0], o[1], o[2], acc, eng.chain_get_x))
+            self._chain_x = state["x"]
+            return state["x"]
+        while state["i"] < ndraws + nsamples:
+            L = np.random.randint(self.Lrange[0], self.Lrange[1] + 1)
+            xn, U, _, AcceptFlag, U_data, U_model = self._leapfrog(state["x"], self.dt, L, alpha,
+                                                                  state["i"])
+            record(U, U_data, U_model, AcceptFlag, lambda xn=xn: xn)
+        x = state["x"]
         return x
 
 

@@ -137,9 +137,19 @@ int gh_chain_init(gh_ctx *ctx, const double *x0, const double *low, const double
  * the caller in the reference's RNG order (hmc.py:297,95,164).  out5 = (U, U_data, U_model,
  * Hcur, Hnew) with U.. of the state the chain is left in (proposal if accepted, else the
  * starting point).  The device executes one fused sweep of G per leapfrog step (adjoint of
- * step s and forward of step s+1 share the sweep) plus one adjoint-only sweep. */
+ * step s and forward of step s+1 share the sweep) plus one adjoint-only sweep, which
+ * gh_chain_prefetch_momentum can merge into the next trajectory. */
 int gh_chain_trajectory(gh_ctx *ctx, const double *p0, double dt, int L, double u,
                         int *accepted, double out5[5]);
+/* Announce the momentum of the trajectory AFTER the next gh_chain_trajectory call (same RNG
+ * stream, drawn one trajectory ahead).  The last sweep of that call then also takes the
+ * announced trajectory's first leapfrog step from the proposal, so an accepted proposal costs L
+ * sweeps of G instead of L+1.  Purely an execution-order optimisation: results are bit-identical
+ * with and without it; a rejected proposal simply discards the speculative step.  The
+ * announcement is consumed by one gh_chain_trajectory call. */
+int gh_chain_prefetch_momentum(gh_ctx *ctx, const double *p0_next);
+/* How often the speculative first step was used / discarded. */
+int gh_chain_stats(gh_ctx *ctx, int64_t *spec_hits, int64_t *spec_misses);
 int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
 int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state */);
 /* Stateless convenience with the signature SURVEY 8b lists: init + trajectory + readback. */

@@ -543,3 +543,37 @@ def test_segmentgrid_wavelet_log_lines_on_gpu(G, tmp_path, capsys):
     got = np.array([[float(v) for v in pat.search(l).groups()] for l in lines])
     np.testing.assert_allclose(got[:, [0, 1, 3]], e["seg_T0_chain0"][:len(got)][:, [0, 1, 3]],
                                rtol=0, atol=1.01e-7)
+
+
+def test_speculative_chaining_is_bit_identical(G):
+    """gh_chain_prefetch_momentum (the next trajectory's first step rides on the last sweep)
+    changes the execution order only: same bits as plain trajectories, through accepts and
+    rejects, for the dense and the wavelet forward."""
+    p = gold("potential_small.npz")
+    for wavelet in (False, '3D'):
+        gm = _module_small(G, p, wavelet=wavelet)
+        eng = gm._engine
+        wm = p["wm"]
+        M = wm.size
+        eng.set_reg("TV", 1.0, 0.001, p["shape"], 0.001 * wm)
+        low, high = 0.0 * wm, 0.02 * wm
+        rng = np.random.default_rng(5)
+        trajs = [(int(rng.integers(1, 9)), rng.normal(size=M) * 0.3, float(rng.uniform()))
+                 for _ in range(20)]
+        eng.chain_init(0.001 * wm, low, high)
+        plain = []
+        for L, p0, u in trajs:
+            acc, o = eng.chain_trajectory(p0, 0.02, L, u)
+            plain.append((acc, o.copy(), eng.chain_get_x()))
+        assert 0 < sum(a for a, _, _ in plain) < len(trajs)
+        eng.chain_init(0.001 * wm, low, high)
+        before = eng.chain_stats()
+        piped = []
+        eng.run_chain(iter(trajs), 0.02, lambda L, acc, o: piped.append((acc, o.copy(), eng.chain_get_x())))
+        after = eng.chain_stats()
+        assert after["spec_hits"] - before["spec_hits"] > 0
+        assert after["spec_misses"] - before["spec_misses"] > 0       # rejected proposals
+        assert len(piped) == len(plain)
+        for (a1, o1, x1), (a2, o2, x2) in zip(plain, piped):
+            assert a1 == a2 and np.array_equal(o1, o2) and np.array_equal(x1, x2)
+        eng.close()
