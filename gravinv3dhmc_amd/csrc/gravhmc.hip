@@ -233,7 +233,8 @@ static int configure_sweep(gh_ctx *c)
     if (e == 7) e = 8;
     c->TW = tw;
     c->EPT2 = e;
-    c->PF = env_int("GRAVHMC_PF", 1) == 2 ? 2 : 1;
+    // two columns in flight per team where the registers allow it (16-wave teams: 122 VGPRs)
+    c->PF = env_int("GRAVHMC_PF", tw == 16 ? 2 : 1) == 2 ? 2 : 1;
     // G larger than the Infinity Cache is streamed once per sweep: bypass-friendly loads
     c->NT = env_int("GRAVHMC_NT", c->ld * c->M * 8 > (int64_t)(512 << 20) ? 1 : 0) != 0;
     const int wg_teams = (tw == 1) ? 4 : 1;
@@ -247,7 +248,7 @@ static int configure_sweep(gh_ctx *c)
     c->cols_per_team = cpt;
     c->n_teams = (int)((c->M + cpt - 1) / cpt);
     c->grid = (c->n_teams + wg_teams - 1) / wg_teams;
-    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : ld + 2 * tw) * sizeof(double);
+    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : ld + 2 * (tw + 8)) * sizeof(double);
     if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
     sweep_fn f = sweep_for(c);
     if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
@@ -1120,7 +1121,6 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
         if (spec) {
             a.mode |= SW_SPEC | SW_UPD | (c->wv.on ? 0 : SW_FWD);
             a.pn_in = c->pn;
-            a.ppn_part = c->ppn_part;
             a.x_in = c->xb[xin];
             a.x_out = c->xb[xs];
             a.low = c->low;
@@ -1139,8 +1139,6 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     if (spec) {
         HIPCHK(c, hipMemcpyAsync(h + 4, c->st[ss].scal, 4 * sizeof(double), hipMemcpyDeviceToHost,
                                  c->stream));
-        HIPCHK(c, hipMemcpyAsync(h + 16 + nt, c->ppn_part, (size_t)nt * sizeof(double),
-                                 hipMemcpyDeviceToHost, c->stream));
     }
     if (!use_spec)
         HIPCHK(c, hipMemcpyAsync(h + 16 + 2 * nt, c->pp0_part, (size_t)c->n_pp0 * sizeof(double),
@@ -1217,6 +1215,35 @@ int gh_leapfrog(gh_ctx *c, double *x_inout, const double *p0, double dt, int L, 
     TRY(gh_chain_trajectory(c, p0, dt, L, u, accepted, out5));
     TRY(gh_chain_get_x(c, x_inout));
     if (dsyn) TRY(gh_chain_get_dsyn(c, dsyn));
+    return GH_OK;
+}
+
+// Diagnostic (not in the public header): time a pure streaming read of the resident G.
+int gh_debug_stream_read(gh_ctx *c, int blocks, int threads, int nt, int reps, double *ms_out)
+{
+    if (!c || !c->have_G) return GH_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    const int64_t n2 = c->ld * c->M / 2;
+    for (int w = 0; w < 2; ++w) {
+        if (w == 1) HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int r = 0; r < (w ? reps : 1); ++r) {
+            if (nt)
+                stream_read_kernel<true><<<dim3(blocks), dim3(threads), 0, c->stream>>>(c->G, n2, c->tmpN);
+            else
+                stream_read_kernel<false><<<dim3(blocks), dim3(threads), 0, c->stream>>>(c->G, n2, c->tmpN);
+        }
+    }
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&t, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *ms_out = t / reps;
     return GH_OK;
 }
 

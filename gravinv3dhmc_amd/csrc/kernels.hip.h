@@ -74,7 +74,6 @@ struct SweepArgs {
     double c_u;           // momentum coefficient of the SW_UPD step (dt, or dt/2 for a first step)
     double dt;            // position step
     const double *pn_in;  // M (SW_SPEC): momentum drawn for the next trajectory
-    double *ppn_part;     // n_teams (SW_SPEC): sum of pn_j^2 (its initial kinetic energy)
     double *g_out;        // M (SW_GOUT)
     double *slab;         // gridDim.x x ld (SW_FWD)
     double *pp_part;      // n_teams (SW_PFIN): sum of p_j^2 over the team's columns
@@ -85,7 +84,9 @@ using d2 = double __attribute__((ext_vector_type(2)));
 template <int EPT2>
 struct ColRegs {
     d2 v[EPT2];
-    double p, x, lo, hi, gr, pn;  // per-column scalars, prefetched with the column
+    double sc;  // lane l < 6 of the team's first wave: the l-th per-column scalar (x, p, low,
+                // high, greg, pn), prefetched with the column -- ONE load instruction per column
+                // and team instead of one per scalar and wave
 };
 
 // TW = waves per team (1, 4, 16).  TW == 1: four independent wave-teams per 256-thread block.
@@ -98,9 +99,10 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     constexpr int WG_TEAMS = (TW == 1) ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // LDS: [0, ld) r ; then TW==1: 4 x ld scratch for the cross-wave forward reduce,
-    //      TW>1: 2 x TW doubles for the ping-pong dot reduction.
+    //      TW>1: 2 x (TW + 8) doubles: ping-pong slots of the dot reduction + column scalars.
     double *r_s = smem;
     double *scratch = smem + a.ld;
+    constexpr int SLOT = TW + 8;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     d2 dacc[EPT2];
 #pragma unroll
     for (int k = 0; k < EPT2; ++k) dacc[k] = d2{0.0, 0.0};
-    double pp = 0.0, ppn = 0.0;
+    double pp = 0.0;
 
     auto load_col = [&](ColRegs<EPT2> &c, int64_t j) {
         const d2 *col = reinterpret_cast<const d2 *>(a.G + j * ld);
@@ -138,21 +140,22 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
             else
                 c.v[k] = d2{0.0, 0.0};
         }
-        c.gr = a.greg ? a.greg[j] : 0.0;
-        c.x = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
-        c.p = (mode & (SW_UPD | SW_PFIN)) ? a.p_in[j] : 0.0;
-        c.pn = (mode & SW_SPEC) ? a.pn_in[j] : 0.0;
-        if (mode & SW_UPD) {
-            c.lo = a.low[j];
-            c.hi = a.high[j];
-        } else {
-            c.lo = c.hi = 0.0;
+        double sc = 0.0;
+        if (mode & SW_ADJ) {
+            if ((TW == 1 || wave == 0) && lane < 6) {
+                const double *src = lane == 0 ? a.x_in : lane == 1 ? a.p_in : lane == 2 ? a.low
+                                  : lane == 3 ? a.high : lane == 4 ? a.greg : a.pn_in;
+                if (src) sc = src[j];
+            }
+        } else if (mode & SW_FWD) {
+            sc = a.x_in[j];  // forward-only sweep: no reduction to piggy-back on
         }
+        c.sc = sc;
     };
 
     // one column: adjoint dot, leapfrog update, forward accumulation.  `it` = j - j0.
     auto process = [&](const ColRegs<EPT2> &cur, int64_t j, int it) {
-        double xj = cur.x;
+        double xj = cur.sc;
         if (mode & SW_ADJ) {
             const d2 *rs2 = reinterpret_cast<const d2 *>(r_s);
             double s = 0.0;
@@ -166,32 +169,47 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
                 }
             }
             s = wave_allreduce_sum(s);
+            double cx, cp, clo, chi, cgr, cpn;
             if (TW > 1) {
-                double *red = scratch + (it & 1) * TW;
-                if (lane == 0) red[wave] = s;
+                double *slot = scratch + (it & 1) * SLOT;
+                if (lane == 0) slot[wave] = s;
+                if (wave == 0 && lane < 6) slot[TW + lane] = cur.sc;
                 __syncthreads();
                 double t = 0.0;
 #pragma unroll
-                for (int w = 0; w < TW; ++w) t += red[w];
+                for (int w = 0; w < TW; ++w) t += slot[w];
                 s = t;
+                cx = slot[TW + 0];
+                cp = slot[TW + 1];
+                clo = slot[TW + 2];
+                chi = slot[TW + 3];
+                cgr = slot[TW + 4];
+                cpn = slot[TW + 5];
+            } else {
+                cx = __shfl(cur.sc, 0, WAVE);
+                cp = __shfl(cur.sc, 1, WAVE);
+                clo = __shfl(cur.sc, 2, WAVE);
+                chi = __shfl(cur.sc, 3, WAVE);
+                cgr = __shfl(cur.sc, 4, WAVE);
+                cpn = __shfl(cur.sc, 5, WAVE);
             }
-            const double g = 2.0 * s + cur.gr;
+            xj = cx;
+            const double g = 2.0 * s + cgr;
             if ((mode & SW_GOUT) && ttid == 0) a.g_out[j] = g;
             if (mode & SW_PFIN) {
-                const double pf = cur.p - a.c_p * g;
+                const double pf = cp - a.c_p * g;
                 pp += pf * pf;
                 if (!(mode & SW_SPEC) && ttid == 0) a.p_out[j] = pf;
             }
             if (mode & SW_UPD) {
-                const double psrc = (mode & SW_SPEC) ? cur.pn : cur.p;
-                ppn += psrc * psrc;
+                const double psrc = (mode & SW_SPEC) ? cpn : cp;
                 double pj = psrc - a.c_u * g;
-                xj = cur.x + a.dt * pj;
-                if (xj > cur.hi) {
-                    xj = cur.hi;
+                xj = cx + a.dt * pj;
+                if (xj > chi) {
+                    xj = chi;
                     pj = -pj;
-                } else if (xj < cur.lo) {
-                    xj = cur.lo;
+                } else if (xj < clo) {
+                    xj = clo;
                     pj = -pj;
                 }
                 if (ttid == 0) {
@@ -241,7 +259,6 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     }
 
     if ((mode & SW_PFIN) && ttid == 0 && team < a.n_teams) a.pp_part[team] = pp;
-    if ((mode & SW_SPEC) && ttid == 0 && team < a.n_teams) a.ppn_part[team] = ppn;
 
     if (mode & SW_FWD) {
         if (TW == 1) {
@@ -839,6 +856,34 @@ spmv_kernel(const int64_t *indptr, const int *indices, const double *data, const
     }
     s = wave_allreduce_sum(s);
     if (lane == 0) y[row] = s;
+}
+
+// Diagnostic only (gh_debug_stream_read): pure streaming read of G, no reductions/barriers --
+// the ceiling the sweep is compared with on the same device in the same session.
+template <bool NT>
+__global__ void __launch_bounds__(1024) stream_read_kernel(const double *G, int64_t n2, double *out)
+{
+    const d2 *g = reinterpret_cast<const d2 *>(G);
+    d2 acc = d2{0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        d2 a0, a1, a2, a3;
+        if (NT) {
+            a0 = __builtin_nontemporal_load(g + i);
+            a1 = __builtin_nontemporal_load(g + i + stride);
+            a2 = __builtin_nontemporal_load(g + i + 2 * stride);
+            a3 = __builtin_nontemporal_load(g + i + 3 * stride);
+        } else {
+            a0 = g[i];
+            a1 = g[i + stride];
+            a2 = g[i + 2 * stride];
+            a3 = g[i + 3 * stride];
+        }
+        acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; i < n2; i += stride) acc += g[i];
+    if (acc.x + acc.y == 1.2345e300) out[0] = acc.x;  // keep the loads alive
 }
 
 }  // namespace ghk
