@@ -53,10 +53,16 @@ PROTOTYPES = {
     "gh_chain_get_dsyn": (C.c_int, [_ctx, _dp]),
     "gh_leapfrog": (C.c_int, [_ctx, _dp, _dp, C.c_double, C.c_int, _dp, _dp, C.c_double,
                               C.POINTER(C.c_int), _dp, _dp]),
+    "gh_shard_unique_id": (C.c_int, [C.c_void_p]),
+    "gh_shard_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
+    "gh_shard_init_callback": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
+    "gh_shard_allreduce": (C.c_int, [_ctx, _dp, _i64]),
     "gh_profile_enable": (C.c_int, [_ctx, C.c_int]),
     "gh_profile_read": (C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(_i64),
                                   C.POINTER(_i64)]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, _i64)
 
 _LIB = None
 

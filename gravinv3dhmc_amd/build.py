@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", SRC, "-o", LIB + ".tmp"]
+           "-Wno-unused-value", SRC, "-o", LIB + ".tmp", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

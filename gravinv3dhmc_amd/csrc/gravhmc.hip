@@ -3,6 +3,9 @@
 #include "../../include/gravhmc.h"
 #include "kernels.hip.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -75,6 +78,21 @@ struct gh_ctx {
     size_t h_scal_n = 0;
     bool chain_ready = false;
     double U_cur[3] = {0, 0, 0};
+
+    // column-block sharding of ONE chain over several GPUs: this context holds
+    // the cells [m0, m0 + M) of M_global; N-vectors are replicated, the forward partials are
+    // summed across ranks once per potential evaluation.
+    struct Shard {
+        int kind = 0;  // 0 single GPU, 1 RCCL all-reduce on the stream, 2 host callback
+        int rank = 0, world = 1;
+        int64_t M_global = 0, m0 = 0;
+        ncclComm_t comm = nullptr;
+        gh_allreduce_fn cb = nullptr;
+        void *user = nullptr;
+        double *buf = nullptr;    // device: [d partial (ld) | R partial | pad]
+        double *hbuf = nullptr;   // pinned staging for the callback path
+        int64_t collectives = 0;
+    } sh;
 
     // wavelet-compressed forward operator (compressor1D/3D): CSR N x Mp on the device
     struct Wavelet {
@@ -279,6 +297,103 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
 }
 
 
+
+// ------------------------------------------------------------------ collective layer
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// RCCL is bound at run time: the copy already in the process (e.g. the one torch.distributed
+// loaded) wins, else the ROCm installation's.
+static RcclApi *rccl_api(std::string &err)
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+        }
+    }
+    if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.AllReduce) {
+        err = "RCCL (librccl.so) could not be loaded";
+        return nullptr;
+    }
+    return &api;
+}
+
+// In-place sum over ranks of `count` doubles at device pointer `buf`, ordered on the stream.
+static int comm_allreduce(gh_ctx *c, double *buf, int64_t count)
+{
+    gh_ctx::Shard &sh = c->sh;
+    if (sh.kind == 0) return GH_OK;
+    sh.collectives += 1;
+    if (sh.kind == 1) {
+        std::string err;
+        RcclApi *api = rccl_api(err);
+        if (!api) return fail(c, GH_ERR_COMM, "%s", err.c_str());
+        ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, sh.comm, c->stream);
+        if (r != ncclSuccess)
+            return fail(c, GH_ERR_COMM, "ncclAllReduce: %s", api->GetErrorString ? api->GetErrorString(r) : "error");
+        return GH_OK;
+    }
+    // host-staged reducer (e.g. gloo): device -> pinned host -> callback -> device
+    HIPCHK(c, hipMemcpyAsync(sh.hbuf, buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sh.cb(sh.user, sh.hbuf, count) != 0) return fail(c, GH_ERR_COMM, "all-reduce callback failed");
+    HIPCHK(c, hipMemcpyAsync(buf, sh.hbuf, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    return GH_OK;
+}
+
+// The same for a few host scalars (count <= ld).
+static int comm_allreduce_host(gh_ctx *c, double *hv, int64_t count)
+{
+    gh_ctx::Shard &sh = c->sh;
+    if (sh.kind == 0) return GH_OK;
+    if (count > c->ld) return fail(c, GH_ERR_ARG, "gh_shard_allreduce: count too large");
+    if (sh.kind == 2) {
+        sh.collectives += 1;
+        if (sh.cb(sh.user, hv, count) != 0) return fail(c, GH_ERR_COMM, "all-reduce callback failed");
+        return GH_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(sh.buf, hv, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    TRY(comm_allreduce(c, sh.buf, count));
+    HIPCHK(c, hipMemcpyAsync(hv, sh.buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+static int shard_common_init(gh_ctx *c, int rank, int world, int64_t M_global, int64_t m0)
+{
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, GH_ERR_ARG, "gh_shard_init: bad rank/world");
+    if (m0 < 0 || m0 + c->M > M_global) return fail(c, GH_ERR_ARG, "gh_shard_init: cell range outside the model");
+    if (c->wv.on) return fail(c, GH_ERR_UNSUPPORTED, "sharding with the wavelet forward is not supported");
+    c->sh.rank = rank;
+    c->sh.world = world;
+    c->sh.M_global = M_global;
+    c->sh.m0 = m0;
+    TRY(dalloc(c, &c->sh.buf, (size_t)c->ld + 8));
+    if (!c->sh.hbuf) HIPCHK(c, hipHostMalloc((void **)&c->sh.hbuf, sizeof(double) * ((size_t)c->ld + 8)));
+    c->chain_ready = false;
+    return GH_OK;
+}
+
 // ------------------------------------------------------------------ wavelet forward
 
 static void wavelet_plan(gh_ctx::Wavelet &w)
@@ -409,14 +524,6 @@ static int wavelet_forward(gh_ctx *c, const double *x, double *d_out)
 static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
 {
     double *d_out = o.d, *r_out = o.r, *greg_out = o.greg, *scal_out = o.scal;
-    if (c->wv.on) {
-        // forward through the compressed operator; d_out then acts as a one-row slab
-        TRY(wavelet_forward(c, x, d_out));
-        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(
-            d_out, 1, c->ld, c->N, c->have_fix ? c->gfix : nullptr, d_out, c->dpart);
-    } else
-    reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(
-        c->slab, c->grid, c->ld, c->N, c->have_fix ? c->gfix : nullptr, d_out, c->dpart);
     RegArgs ra;
     ra.kind = c->reg_kind;
     ra.M = c->M;
@@ -430,17 +537,43 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
     ra.wm2 = c->wm2;
     ra.greg = greg_out;
     ra.regpart = c->regpart;
-    reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+    const double *gfix = c->have_fix ? c->gfix : nullptr;
+    const double *regpart = c->regpart;
+    int n_regpart = c->n_regpart;
+    if (c->sh.kind != 0) {
+        // sharded cells: local forward partial and local regulariser sum travel in ONE
+        // all-reduce, then every rank finishes the (replicated) data part identically
+        double *buf = c->sh.buf;
+        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(c->slab, c->grid, c->ld, c->N,
+                                                                            nullptr, buf, c->dpart);
+        reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+        sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, buf + c->ld);
+        TRY(comm_allreduce(c, buf, c->ld + 2));
+        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(buf, 1, c->ld, c->N, gfix, d_out,
+                                                                            c->dpart);
+        regpart = buf + c->ld;
+        n_regpart = 1;
+    } else if (c->wv.on) {
+        // forward through the compressed operator; d_out then acts as a one-row slab
+        TRY(wavelet_forward(c, x, d_out));
+        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(d_out, 1, c->ld, c->N, gfix, d_out,
+                                                                            c->dpart);
+        reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+    } else {
+        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(c->slab, c->grid, c->ld, c->N, gfix,
+                                                                            d_out, c->dpart);
+        reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+    }
     FinishArgs fa;
     fa.N = c->N;
     fa.ld = c->ld;
     fa.n_dpart = c->n_dpart;
-    fa.n_regpart = c->n_regpart;
+    fa.n_regpart = n_regpart;
     fa.d = d_out;
-    fa.gfix = c->have_fix ? c->gfix : nullptr;
+    fa.gfix = gfix;
     fa.dobs_c = c->dobs_c;
     fa.dpart = c->dpart;
-    fa.regpart = c->regpart;
+    fa.regpart = regpart;
     fa.alpha = c->alpha;
     fa.r = r_out;
     fa.scal = scal_out;
@@ -554,6 +687,12 @@ void gh_destroy(gh_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->sh.comm) {
+        std::string err;
+        RcclApi *api = rccl_api(err);
+        if (api && api->CommDestroy) api->CommDestroy(c->sh.comm);
+    }
+    if (c->sh.hbuf) hipHostFree(c->sh.hbuf);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_scal) hipHostFree(c->h_scal);
     for (hipEvent_t ev : c->ev) hipEventDestroy(ev);
@@ -788,6 +927,8 @@ int gh_set_reg(gh_ctx *c, int kind, double alpha, double beta, const int shape3[
     if (!c || !mwapr) return fail(c, GH_ERR_ARG, "gh_set_reg: null pointer");
     if (kind < 0 || kind > 3)
         return fail(c, GH_ERR_ARG, "Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.");
+    if (c->sh.kind != 0 && (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV))
+        return fail(c, GH_ERR_UNSUPPORTED, "Smoothness/TV across cell shards need a halo exchange (not built): use Damping or MS");
     if (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV) {
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
             return fail(c, GH_ERR_ARG, "gh_set_reg: Smoothness/TV need shape nz*ny*nx == M (carved meshes are not supported by the finite-difference operator)");
@@ -825,6 +966,7 @@ int gh_forward(gh_ctx *c, const double *mw, double *dpre)
     reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(c->slab, c->grid, c->ld, c->N,
                                                                         nullptr, c->tmpN, c->dpart);
     HIPCHK(c, hipGetLastError());
+    TRY(comm_allreduce(c, c->tmpN, c->ld));
     return d2h(c, dpre, c->tmpN, (size_t)c->N);
 }
 
@@ -881,6 +1023,7 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     if (!(thr >= 0)) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: threshold must be >= 0");
     gh_ctx::Wavelet &w = c->wv;
     if (w.on || w.indptr) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: already compressed");
+    if (c->sh.kind != 0) return fail(c, GH_ERR_UNSUPPORTED, "wavelet forward on a sharded kernel is not supported");
     if (dims == 3) {
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
             return fail(c, GH_ERR_ARG, "cannot reshape array of size %lld into shape (%d,%d,%d)",
@@ -1150,6 +1293,15 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
         pp0 = c->spec_pp0;
     else
         for (int t = 0; t < c->n_pp0; ++t) pp0 += h[16 + 2 * nt + t];
+    double pn_pp0_g = pn_pp0;
+    if (c->sh.kind != 0) {
+        // kinetic energies are sums over cells: combine the ranks' parts (same bits everywhere)
+        double v[3] = {pp1, use_spec ? 0.0 : pp0, spec ? pn_pp0 : 0.0};
+        TRY(comm_allreduce_host(c, v, 3));
+        pp1 = v[0];
+        if (!use_spec) pp0 = v[1];
+        pn_pp0_g = v[2];
+    }
     const double Unew[3] = {h[2], h[0], h[1]};
     const double Hcur = 0.5 * pp0 + c->U_cur[0];
     const double Hnew = 0.5 * pp1 + Unew[0];
@@ -1163,7 +1315,7 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
         if (spec) {
             c->spec_valid = true;
             c->spec_dt = dt;
-            c->spec_pp0 = pn_pp0;
+            c->spec_pp0 = pn_pp0_g;
             c->spec_x = xs;
             c->spec_p = pin ^ 1;
             c->spec_set = ss;
@@ -1245,6 +1397,58 @@ int gh_debug_stream_read(gh_ctx *c, int blocks, int threads, int nt, int reps, d
     hipEventDestroy(e1);
     *ms_out = t / reps;
     return GH_OK;
+}
+
+int gh_shard_unique_id(void *id128)
+{
+    if (!id128) return GH_ERR_ARG;
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(nullptr, GH_ERR_COMM, "%s", err.c_str());
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, GH_ERR_COMM, "ncclGetUniqueId failed");
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof id);
+    return GH_OK;
+}
+
+int gh_shard_init(gh_ctx *c, const void *id128, int rank, int world, int64_t M_global, int64_t m0)
+{
+    if (!c || !id128) return fail(c, GH_ERR_ARG, "gh_shard_init: null pointer");
+    if (c->sh.kind != 0) return fail(c, GH_ERR_ARG, "gh_shard_init: already initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(shard_common_init(c, rank, world, M_global, m0));
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(c, GH_ERR_COMM, "%s", err.c_str());
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclResult_t r = api->CommInitRank(&c->sh.comm, world, id, rank);
+    if (r != ncclSuccess)
+        return fail(c, GH_ERR_COMM, "ncclCommInitRank: %s", api->GetErrorString ? api->GetErrorString(r) : "error");
+    c->sh.kind = 1;
+    return GH_OK;
+}
+
+int gh_shard_init_callback(gh_ctx *c, gh_allreduce_fn fn, void *user, int rank, int world, int64_t M_global,
+                           int64_t m0)
+{
+    if (!c || !fn) return fail(c, GH_ERR_ARG, "gh_shard_init_callback: null pointer");
+    if (c->sh.kind != 0) return fail(c, GH_ERR_ARG, "gh_shard_init: already initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(shard_common_init(c, rank, world, M_global, m0));
+    c->sh.cb = fn;
+    c->sh.user = user;
+    c->sh.kind = 2;
+    return GH_OK;
+}
+
+int gh_shard_allreduce(gh_ctx *c, double *host_buf, int64_t count)
+{
+    if (!c || !host_buf) return fail(c, GH_ERR_ARG, "gh_shard_allreduce: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    return comm_allreduce_host(c, host_buf, count);
 }
 
 int gh_profile_enable(gh_ctx *c, int enable)

@@ -432,6 +432,19 @@ __global__ void __launch_bounds__(1024) finish_kernel(FinishArgs a)
     }
 }
 
+// out[0] = sum of part[0..n) in the same fixed order finish_kernel uses for its partials
+__global__ void __launch_bounds__(1024) sum_kernel(const double *part, int n, double *out)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < n; t += 1024) s += part[t];
+    const double tot = block_allreduce_sum(s, red, 16);
+    if (threadIdx.x == 0) {
+        out[0] = tot;
+        out[1] = 0.0;
+    }
+}
+
 // per-block partial sums of v[j]^2
 __global__ void __launch_bounds__(256) sumsq_kernel(const double *v, int64_t M, double *part)
 {

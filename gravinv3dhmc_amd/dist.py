@@ -57,6 +57,24 @@ class Ranks(object):
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return float(t[0])
 
+    def broadcast_bytes(self, raw, src=0):
+        """Byte string of rank `src` on every rank (e.g. the RCCL unique id)."""
+        if self._dist is None:
+            return raw
+        box = [raw if self.rank == src else None]
+        self._dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def allreduce_array(self, arr):
+        """Element-wise sum over ranks of a float64 numpy array (returns a new array)."""
+        import numpy as np
+        if self._dist is None:
+            return np.array(arr, dtype=np.float64)
+        import torch
+        t = torch.from_numpy(np.array(arr, dtype=np.float64))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return t.numpy()
+
     def gather(self, obj):
         """List of every rank's picklable `obj` on rank 0 (None elsewhere): e.g. posterior
         mean/std of each chain for the multi-chain statistics of plot_real_multichain.py:64-77."""
@@ -83,3 +101,129 @@ def run_chains(model_factory, sample_kwargs, ranks=None):
     chain = HMCSample(model, **kw)
     ranks.barrier()
     return chain
+
+
+# ---------------------------------------------------------------------------------------------
+# One chain sharded over several GPUs: column blocks of G (BASELINE config C5)
+# ---------------------------------------------------------------------------------------------
+
+def column_partition(M, world):
+    """Contiguous, near-equal split of M cells over `world` ranks: list of (m0, m1)."""
+    base, rem = divmod(int(M), int(world))
+    out, m0 = [], 0
+    for g in range(world):
+        m1 = m0 + base + (1 if g < rem else 0)
+        out.append((m0, m1))
+        m0 = m1
+    return out
+
+
+def allgather_slices(ranks, local, parts):
+    """Concatenate every rank's contiguous slice (lengths from `parts`) into the full vector."""
+    import numpy as np
+    if ranks._dist is None:
+        return np.asarray(local, dtype=np.float64)
+    import torch
+    n = max(m1 - m0 for m0, m1 in parts)
+    buf = torch.zeros(n, dtype=torch.float64)
+    buf[: len(local)] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+    outs = [torch.zeros(n, dtype=torch.float64) for _ in range(ranks.world)]
+    ranks._dist.all_gather(outs, buf)
+    return np.concatenate([o.numpy()[: m1 - m0] for o, (m0, m1) in zip(outs, parts)])
+
+
+def _engine_base():
+    from .engine import Engine
+    return Engine
+
+
+def make_sharded_engine(N, M, ranks, device=None, backend="rccl"):
+    """Engine-compatible object whose methods take and return FULL model vectors while the
+    device holds only this rank's cells.  backend: "rccl" (all-reduce on the GPU stream over
+    xGMI) or "gloo" (host-staged through torch.distributed; several ranks per GPU, tests)."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    Engine = _engine_base()
+
+    class ShardedEngine(Engine):
+        def __init__(self):
+            self.ranks = ranks
+            self.parts = column_partition(M, ranks.world)
+            self.m0, self.m1 = self.parts[ranks.rank]
+            self.M_global = int(M)
+            Engine.__init__(self, N, self.m1 - self.m0, ranks.device if device is None else device)
+            self.M_local = self.M
+            lib = self._lib
+            if backend == "rccl":
+                idbuf = C.create_string_buffer(128)
+                if ranks.rank == 0:
+                    _lib.check(lib.gh_shard_unique_id(idbuf), None)
+                raw = ranks.broadcast_bytes(idbuf.raw)
+                idbuf = C.create_string_buffer(raw, 128)
+                self._chk(lib.gh_shard_init(self._h, idbuf, ranks.rank, ranks.world, self.M_global,
+                                            self.m0))
+            else:
+                def _cb(_user, ptr_, count):
+                    try:
+                        arr = np.ctypeslib.as_array(ptr_, shape=(count,))
+                        arr[:] = ranks.allreduce_array(arr)
+                        return 0
+                    except Exception:  # reported by the library as GH_ERR_COMM
+                        return 1
+
+                self._cb = _lib.ALLREDUCE_FN(_cb)
+                self._chk(lib.gh_shard_init_callback(self._h, C.cast(self._cb, C.c_void_p), None,
+                                                     ranks.rank, ranks.world, self.M_global, self.m0))
+
+        # -- marshalling helpers ---------------------------------------------------------
+        def _loc(self, v):
+            v = np.asarray(v, dtype=np.float64)
+            if v.shape[0] == self.M_local and self.M_local != self.M_global:
+                return v
+            if v.shape[0] != self.M_global:
+                raise ValueError("expected a model vector of %d entries" % self.M_global)
+            return np.ascontiguousarray(v[self.m0:self.m1])
+
+        def _full(self, local):
+            return allgather_slices(self.ranks, local, self.parts)
+
+        # -- overrides: full vectors in, full vectors out -----------------------------------
+        def set_cells(self, bounds6, kind, ratio=1.6):
+            b = np.asarray(bounds6, dtype=np.float64)
+            if b.shape[0] == self.M_global:
+                b = b[self.m0:self.m1]
+            Engine.set_cells(self, b, kind, ratio)
+
+        def weight(self, weightfactor=0.5):
+            return self._full(Engine.weight(self, weightfactor))
+
+        def set_reg(self, regularization, alpha, beta, shape, mwapr):
+            Engine.set_reg(self, regularization, alpha, beta, None, self._loc(mwapr))
+
+        def forward(self, mw):
+            return Engine.forward(self, self._loc(mw))
+
+        def adjoint(self, r):
+            return self._full(Engine.adjoint(self, r))
+
+        def misfit_and_grad(self, x):
+            m, g, d, dv, mv = Engine.misfit_and_grad(self, self._loc(x))
+            return m, self._full(g), d, dv, mv
+
+        def chain_init(self, x0, low, high):
+            Engine.chain_init(self, self._loc(x0), self._loc(low), self._loc(high))
+
+        def chain_trajectory(self, p0, dt, L, u):
+            return Engine.chain_trajectory(self, self._loc(p0), dt, L, u)
+
+        def chain_prefetch_momentum(self, p0_next):
+            Engine.chain_prefetch_momentum(self, self._loc(p0_next))
+
+        def chain_get_x(self):
+            return self._full(Engine.chain_get_x(self))
+
+        def download_G(self):
+            raise NotImplementedError("the sharded kernel is never gathered on one host")
+
+    return ShardedEngine()

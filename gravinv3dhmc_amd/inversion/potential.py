@@ -38,12 +38,15 @@ class GravMagModule(object):
     * wavelet: False, '1D' or '3D' (compressed forward operator).
     * mtopo=(x, y, topography) keyword: carve the mesh with a topography surface.
     * device: GPU ordinal (extension; the reference has no such argument).
+    * shard: a `dist.Ranks` object: the cells of ONE model are split in column blocks over the
+      ranks' GPUs (each holds N x M/world of G); shard_backend "rccl" or "gloo".
     """
 
     def __init__(self, dobs, mrange, mspacing, obsurface, fixed=False, grav_fix=[],
                  mratio=1, mseg=False, mdivisionsection=[], weightfactor=0.5,
                  coordinate="cartesian", njobs=1, field="gravity",
-                 mangle=(90, 0), wavelet=False, device=0, verbose=True, **kwargs):
+                 mangle=(90, 0), wavelet=False, device=0, verbose=True, shard=None,
+                 shard_backend="rccl", **kwargs):
         self.dobs = dobs
         self.fixed = fixed
         self.grav_fix = grav_fix
@@ -89,7 +92,13 @@ class GravMagModule(object):
         N = int(np.asarray(self.lonobs).size)
         self._say("Start of calculate kernel")
         start = time.time()
-        eng = Engine(N, bounds.shape[0], device=device)
+        if shard is not None and shard.world > 1:
+            if wavelet:
+                raise NotImplementedError("wavelet forward on a sharded kernel is not supported")
+            from ..dist import make_sharded_engine
+            eng = make_sharded_engine(N, bounds.shape[0], shard, backend=shard_backend)
+        else:
+            eng = Engine(N, bounds.shape[0], device=device)
         eng.set_obs(self.lonobs, self.latobs, self.heightobs)
         if spherical:
             self._say("Number of effective tesseroids", bounds.shape[0])
@@ -156,10 +165,14 @@ class GravMagModule(object):
         key = (regulization, float(alpha), float(beta), mwapr.ctypes.data, mwapr.shape[0],
                float(mwapr[0]), float(mwapr[-1]), float(mwapr.sum()))
         if key != self._engine._reg_key:
-            if regulization in ("Smoothness", "TV") and int(np.prod(self.mshape)) != self._engine.M:
+            m_model = getattr(self._engine, "M_global", self._engine.M)
+            if regulization in ("Smoothness", "TV") and int(np.prod(self.mshape)) != m_model:
                 raise ValueError("Smoothness/TV need the full (uncarved) mesh: shape %r has %d "
                                  "cells, model has %d" % (self.mshape, int(np.prod(self.mshape)),
-                                                          self._engine.M))
+                                                          m_model))
+            if regulization in ("Smoothness", "TV") and hasattr(self._engine, "M_global"):
+                raise NotImplementedError("Smoothness/TV across cell shards need a halo exchange "
+                                          "(not built): use Damping or MS")
             self._engine.set_reg(regulization, alpha, beta, self.mshape, mwapr)
             self._engine._reg_key = key
 

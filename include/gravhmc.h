@@ -157,6 +157,31 @@ int gh_leapfrog(gh_ctx *ctx, double *x_inout, const double *p0, double dt, int L
                 const double *low, const double *high, double u, int *accepted,
                 double out5[5], double *dsyn_or_null);
 
+/* ---- one chain sharded over several GPUs -------------------------- */
+
+/* Column-block sharding: rank g of `world` creates its context with its own cell count
+ * (gh_create(N, M_local)) and passes only its cells / slices of every M-vector; N-vectors
+ * (dobs, grav_fix, dpre) are replicated.  Per potential evaluation the ranks exchange ONE
+ * all-reduce of N+1 doubles (forward partial + regulariser partial); the gradient, the
+ * regulariser gradient and the leapfrog updates stay local, so the fused one-read sweep is
+ * kept.  Damping and MS only (Smoothness/TV would need a halo exchange).  Every rank ends up
+ * with bit-identical scalars, hence identical Metropolis decisions.
+ *
+ * RCCL flavour: rank 0 obtains a 128-byte id with gh_shard_unique_id, the launcher
+ * broadcasts it, every rank calls gh_shard_init (ncclCommInitRank, collective).  The
+ * all-reduce runs on the context's stream over xGMI. */
+int gh_shard_unique_id(void *id128);
+int gh_shard_init(gh_ctx *ctx, const void *id128, int rank, int world, int64_t M_global, int64_t m0);
+/* Host-staged flavour: the all-reduce is delegated to a caller-supplied function that sums
+ * `count` doubles in place across ranks (e.g. torch.distributed over gloo); used where RCCL
+ * cannot run (several ranks on one GPU) and by the tests. */
+typedef int (*gh_allreduce_fn)(void *user, double *host_buf, int64_t count);
+int gh_shard_init_callback(gh_ctx *ctx, gh_allreduce_fn fn, void *user, int rank, int world,
+                           int64_t M_global, int64_t m0);
+/* Sum of `count` (<= N) doubles in place across the ranks of the shard group (host buffers):
+ * lets the host combine per-rank scalars through the same communicator. */
+int gh_shard_allreduce(gh_ctx *ctx, double *host_buf, int64_t count);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 
 /* HIP-event timing of the G sweeps (the dominant kernel) on the context's stream.

@@ -93,3 +93,50 @@ def test_single_process_defaults():
         for k, v in env.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def test_column_partition_and_allgather_single():
+    from gravinv3dhmc_amd.dist import Ranks, allgather_slices, column_partition
+    assert column_partition(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert column_partition(2400000, 8)[-1] == (2100000, 2400000)
+    parts = column_partition(7, 1)
+    env = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        r = Ranks()
+        assert np.array_equal(allgather_slices(r, np.arange(7.0), parts), np.arange(7.0))
+        assert np.array_equal(r.allreduce_array(np.arange(3.0)), np.arange(3.0))
+        assert r.broadcast_bytes(b"abc") == b"abc"
+    finally:
+        for k, v in env.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+SHARD_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from gravinv3dhmc_amd.dist import Ranks, allgather_slices, column_partition
+r = Ranks()
+parts = column_partition(11, r.world)
+m0, m1 = parts[r.rank]
+full = allgather_slices(r, np.arange(m0, m1, dtype=float) * 2.0, parts)
+s = r.allreduce_array(np.full(4, 1.0 + r.rank))
+raw = r.broadcast_bytes(bytes(range(128)) if r.rank == 0 else b"")
+if r.rank == 1:
+    print(json.dumps({"full": full.tolist(), "s": s.tolist(), "raw_ok": raw == bytes(range(128))}))
+r.close()
+'''
+
+
+def test_shard_helpers_two_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(SHARD_WORKER % ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["full"] == [2.0 * i for i in range(11)] and res["s"] == [3.0] * 4 and res["raw_ok"]
