@@ -40,6 +40,10 @@ struct gh_ctx {
     bool have_obs = false, have_cells = false, have_G = false, weighted = false;
     double *G = nullptr;
     int64_t warn_cells = 0, leaves = 0;
+    bool mf = false;          // matrix-free: entries are re-evaluated, G is never stored
+    bool dense_ok = true;     // N fits the register-resident sweep (<= 16384 rows)
+    double *tconv = nullptr;  // tesseroid obs converted to (lon rad, sin lat, cos lat, radius)
+    int64_t mf_cells_per_chunk = 0;
 
     // sweep configuration
     int TW = 0, EPT2 = 0, PF = 1;
@@ -242,10 +246,16 @@ static int configure_sweep(gh_ctx *c)
     if (ld <= 1024) tw = 1;
     else if (ld <= 4096) tw = 4;
     else if (ld <= 16384) tw = 16;
-    else
-        return fail(c, GH_ERR_UNSUPPORTED,
-                    "N = %lld: more than 16384 observations per device needs row panels "
-                    "(shard rows across GPUs)", (long long)c->N);
+    else {
+        // too many rows for the register-resident dense sweep: only the matrix-free path works
+        c->dense_ok = false;
+        c->TW = 16;
+        c->EPT2 = 8;
+        c->n_teams = 1;
+        c->grid = 1;
+        c->cols_per_team = c->M;
+        return GH_OK;
+    }
     per = tw * 128;
     int e = (int)((ld + per - 1) / per);
     if (e == 7) e = 8;
@@ -275,8 +285,55 @@ static int configure_sweep(gh_ctx *c)
     return GH_OK;
 }
 
+static MfGeom mf_geom(const gh_ctx *c)
+{
+    MfGeom g;
+    g.kind = c->cell_kind;
+    g.N = c->N;
+    g.M = c->M;
+    if (c->cell_kind == GH_CELL_TESSEROID) {
+        g.o0 = c->tconv;
+        g.o1 = c->tconv + c->N;
+        g.o2 = c->tconv + 2 * c->N;
+        g.o3 = c->tconv + 3 * c->N;
+    } else {
+        g.o0 = c->obs[0];
+        g.o1 = c->obs[1];
+        g.o2 = c->obs[2];
+        g.o3 = nullptr;
+    }
+    g.bounds6 = c->bounds;
+    g.ratio = c->ratio;
+    return g;
+}
+
+// matrix-free counterpart of one sweep: adjoint/update pass, then forward pass
+static int launch_mf(gh_ctx *c, SweepArgs &a)
+{
+    const MfGeom g = mf_geom(c);
+    const double *wm = c->weighted ? c->wm : nullptr;
+    bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    if (a.mode & SW_ADJ) {
+        if (!wm) return fail(c, GH_ERR_ARG, "matrix-free adjoint needs gh_weight first");
+        mf_adjoint_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(g, a, wm);
+    }
+    if (a.mode & SW_FWD) {
+        const double *x = (a.mode & SW_UPD) ? a.x_out : a.x_in;
+        mf_forward_kernel<<<dim3((unsigned)((c->ld + 255) / 256), (unsigned)c->grid), dim3(256), 0,
+                            c->stream>>>(g, x, wm, c->mf_cells_per_chunk, c->ld, a.slab);
+    }
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
 static int launch_sweep(gh_ctx *c, SweepArgs &a)
 {
+    if (c->mf) return launch_mf(c, a);
     a.G = c->G;
     a.ld = c->ld;
     a.M = c->M;
@@ -751,15 +808,49 @@ int gh_set_cells(gh_ctx *c, const double *bounds6, int kind, double ratio)
     return GH_OK;
 }
 
+int gh_set_matrix_free(gh_ctx *c, int enable)
+{
+    if (!c) return GH_ERR_ARG;
+    if (c->have_G || c->slab) return fail(c, GH_ERR_ARG, "gh_set_matrix_free: call before gh_build_G");
+    c->mf = enable != 0;
+    if (c->mf) {
+        // partition used by the matrix-free passes: one wave per cell (adjoint), chunks of
+        // cells per forward partial
+        c->n_teams = (int)((c->M + 3) / 4);
+        const int64_t chunks = std::min<int64_t>(c->M, std::max<int64_t>(1, (int64_t)c->cus * 16 / std::max<int64_t>(1, (c->ld + 255) / 256)));
+        c->mf_cells_per_chunk = (c->M + chunks - 1) / chunks;
+        c->grid = (int)((c->M + c->mf_cells_per_chunk - 1) / c->mf_cells_per_chunk);
+    }
+    return GH_OK;
+}
+
 int gh_build_G(gh_ctx *c)
 {
     if (!c) return GH_ERR_ARG;
     TRY(need(c, c->have_obs && c->have_cells, "gh_build_G: call gh_set_obs and gh_set_cells first"));
     HIPCHK(c, hipSetDevice(c->device));
-    TRY(dalloc(c, &c->G, (size_t)c->ld * (size_t)c->M, false));
-    const int64_t total = c->ld * c->M;
     c->warn_cells = 0;
     c->leaves = 0;
+    if (c->mf) {
+        if (c->cell_kind == GH_CELL_TESSEROID) {
+            const int64_t N = c->N;
+            TRY(dalloc(c, &c->tconv, (size_t)(4 * N)));
+            tess_convert_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream>>>(
+                c->obs[0], c->obs[1], c->obs[2], N, c->tconv, c->tconv + N, c->tconv + 2 * N,
+                c->tconv + 3 * N);
+            HIPCHK(c, hipGetLastError());
+        }
+        c->have_G = true;
+        c->weighted = false;
+        c->chain_ready = false;
+        return GH_OK;
+    }
+    if (!c->dense_ok)
+        return fail(c, GH_ERR_UNSUPPORTED,
+                    "N = %lld: more than 16384 observations per device: shard the observations or use "
+                    "the matrix-free mode (gh_set_matrix_free)", (long long)c->N);
+    TRY(dalloc(c, &c->G, (size_t)c->ld * (size_t)c->M, false));
+    const int64_t total = c->ld * c->M;
     if (c->cell_kind == GH_CELL_PRISM) {
         const int64_t blocks = std::min<int64_t>((total + 255) / 256, 1 << 22);
         prism_gz_kernel<<<dim3((unsigned)blocks), dim3(256), 0, c->stream>>>(
@@ -815,6 +906,8 @@ int gh_upload_G(gh_ctx *c, const double *A, int64_t ld, int fortran_order)
 {
     if (!c || !A) return fail(c, GH_ERR_ARG, "gh_upload_G: null pointer");
     if (ld < (fortran_order ? c->N : c->M)) return fail(c, GH_ERR_ARG, "gh_upload_G: ld too small");
+    if (c->mf) return fail(c, GH_ERR_ARG, "gh_upload_G: context is matrix-free");
+    if (!c->dense_ok) return fail(c, GH_ERR_UNSUPPORTED, "N = %lld: more than 16384 observations per device", (long long)c->N);
     HIPCHK(c, hipSetDevice(c->device));
     TRY(dalloc(c, &c->G, (size_t)c->ld * (size_t)c->M, false));
     HIPCHK(c, hipMemsetAsync(c->G, 0, sizeof(double) * (size_t)c->ld * (size_t)c->M, c->stream));
@@ -846,7 +939,7 @@ int gh_upload_G(gh_ctx *c, const double *A, int64_t ld, int fortran_order)
 int gh_download_G(gh_ctx *c, double *A, int64_t ld)
 {
     if (!c || !A) return fail(c, GH_ERR_ARG, "gh_download_G: null pointer");
-    TRY(need(c, c->have_G, "gh_download_G: no kernel matrix resident"));
+    TRY(need(c, c->have_G && !c->mf, "gh_download_G: no kernel matrix resident"));
     if (ld < c->N) return fail(c, GH_ERR_ARG, "gh_download_G: ld too small");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy2DAsync(A, (size_t)ld * sizeof(double), c->G, (size_t)c->ld * sizeof(double),
@@ -864,10 +957,15 @@ int gh_weight(gh_ctx *c, double weightfactor, double *wm_out)
     HIPCHK(c, hipSetDevice(c->device));
     TRY(dalloc(c, &c->wm, (size_t)c->M));
     TRY(dalloc(c, &c->wm2, (size_t)c->M));
-    weight_fn f = weight_for(c);
-    const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
-    hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), 0, c->stream, c->G, c->ld, c->M,
-                       c->cols_per_team, c->n_teams, weightfactor, c->wm);
+    if (c->mf) {
+        mf_colnorm_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(mf_geom(c), weightfactor,
+                                                                                        c->wm);
+    } else {
+        weight_fn f = weight_for(c);
+        const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
+        hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), 0, c->stream, c->G, c->ld, c->M,
+                           c->cols_per_team, c->n_teams, weightfactor, c->wm);
+    }
     HIPCHK(c, hipGetLastError());
     std::vector<double> w((size_t)c->M);
     TRY(d2h(c, w.data(), c->wm, (size_t)c->M));
@@ -1024,6 +1122,7 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     gh_ctx::Wavelet &w = c->wv;
     if (w.on || w.indptr) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: already compressed");
     if (c->sh.kind != 0) return fail(c, GH_ERR_UNSUPPORTED, "wavelet forward on a sharded kernel is not supported");
+    if (c->mf) return fail(c, GH_ERR_UNSUPPORTED, "wavelet compression needs the stored kernel (not matrix-free)");
     if (dims == 3) {
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
             return fail(c, GH_ERR_ARG, "cannot reshape array of size %lld into shape (%d,%d,%d)",

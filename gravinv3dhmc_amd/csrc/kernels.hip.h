@@ -529,25 +529,12 @@ __device__ __forceinline__ double safe_log_d(double x)
     return log(x);
 }
 
-// G[i + c*ld] = G*SI2MGAL * sum over the 8 corners (-1)^(i+j+k) kernelz (prism.py:291-316,
-// _prism.pyx:49-50,265-290).  One thread per (obs, cell) entry, obs fastest (coalesced store).
-__global__ void __launch_bounds__(256)
-prism_gz_kernel(const double *__restrict__ xp, const double *__restrict__ yp,
-                const double *__restrict__ zp, const double *__restrict__ bounds6, int64_t N,
-                int64_t M, int64_t ld, double *__restrict__ G)
+// One (observation, prism) entry in mGal per g/cm^3: G*SI2MGAL * sum over the 8 corners of
+// (-1)^(i+j+k) kernelz (prism.py:291-316, _prism.pyx:49-50,265-290).
+__device__ __forceinline__ double prism_entry(double px, double py, double pz, const double *b)
 {
 #pragma clang fp contract(off)
-  // grid-stride: a launch is limited to 2^32 work-items, ld*M reaches 5*10^9 at C2
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < ld * M;
-       idx += (int64_t)gridDim.x * 256) {
-    const int64_t c = idx / ld, l = idx - c * ld;
-    if (l >= N) {
-        G[idx] = 0.0;
-        continue;
-    }
-    const double *b = bounds6 + 6 * c;
     const double X[2] = {b[1], b[0]}, Y[2] = {b[3], b[2]}, Z[2] = {b[5], b[4]};
-    const double px = xp[l], py = yp[l], pz = zp[l];
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -566,8 +553,21 @@ prism_gz_kernel(const double *__restrict__ xp, const double *__restrict__ yp,
             }
         }
     }
-    G[idx] = acc * (0.00000006673 * 100000.0);
-  }
+    return acc * (0.00000006673 * 100000.0);
+}
+
+// Dense assembly: one thread per (obs, cell) entry, obs fastest (coalesced store).
+__global__ void __launch_bounds__(256)
+prism_gz_kernel(const double *__restrict__ xp, const double *__restrict__ yp,
+                const double *__restrict__ zp, const double *__restrict__ bounds6, int64_t N,
+                int64_t M, int64_t ld, double *__restrict__ G)
+{
+    // grid-stride: a launch is limited to 2^32 work-items, ld*M reaches 5*10^9 at C2
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < ld * M;
+         idx += (int64_t)gridDim.x * 256) {
+        const int64_t c = idx / ld, l = idx - c * ld;
+        G[idx] = (l < N) ? prism_entry(xp[l], yp[l], zp[l], bounds6 + 6 * c) : 0.0;
+    }
 }
 
 constexpr int TESS_STACK = 100;  // tesseroid.py:79
@@ -578,32 +578,20 @@ struct TessStats {
 };
 
 // Adaptive 2x2x2 Gauss-Legendre tesseroid gz entry (_tesseroid_numba.py:32-71, 75-157,
-// 207-222), one thread per (obs, cell) pair with a private LIFO stack of sub-tesseroids.
-// err_cell[c] accumulates the engine's error codes (non-zero => the reference warns).
-__global__ void __launch_bounds__(64)
-tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinlat_a,
-               const double *__restrict__ coslat_a, const double *__restrict__ radius_a,
-               const double *__restrict__ bounds6, int64_t N, int64_t M, int64_t ld, double ratio,
-               double *__restrict__ G, int *__restrict__ err_cell, TessStats *stats)
+// 207-222) with a private LIFO stack of sub-tesseroids; mGal per g/cm^3.  err accumulates the
+// engine's error codes (non-zero => the reference warns), nleaf counts GLQ leaves.
+__device__ double tess_entry(double lon, double sinlat, double coslat, double radius,
+                             const double *bounds, double ratio, int &error_code,
+                             unsigned long long &nleaf, bool &overflow)
 {
 #pragma clang fp contract(off)
-  unsigned long long nleaf = 0;
-  bool overflow = false;
-  for (int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x; idx < ld * M;
-       idx += (int64_t)gridDim.x * 64) {
-    const int64_t c = idx / ld, l = idx - c * ld;
-    if (l >= N) {
-        G[idx] = 0.0;
-        continue;
-    }
     const double MEAN_R = 6378137.0;
     const double d2r = 3.14159265358979323846 / 180;
     const double node[2] = {-0.577350269189625731058868041146, 0.577350269189625731058868041146};
-    const double lon = lon_r[l], sinlat = sinlat_a[l], coslat = coslat_a[l], radius = radius_a[l];
     double stack[TESS_STACK][6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) stack[0][q] = bounds6[6 * c + q];
-    int stktop = 0, error_code = 0;
+    for (int q = 0; q < 6; ++q) stack[0][q] = bounds[q];
+    int stktop = 0;
     double acc = 0.0;
     while (stktop >= 0) {
         const double w = stack[stktop][0], e = stack[stktop][1], s = stack[stktop][2],
@@ -684,9 +672,30 @@ tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinl
             nleaf += 1;
         }
     }
-    G[idx] = acc * 100000.0 * 0.00000006673;
-    if (error_code != 0) atomicAdd(&err_cell[c], error_code);
-  }
+    return acc * 100000.0 * 0.00000006673;
+}
+
+// Dense assembly, one thread per (obs, cell) pair.
+__global__ void __launch_bounds__(64)
+tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinlat_a,
+               const double *__restrict__ coslat_a, const double *__restrict__ radius_a,
+               const double *__restrict__ bounds6, int64_t N, int64_t M, int64_t ld, double ratio,
+               double *__restrict__ G, int *__restrict__ err_cell, TessStats *stats)
+{
+    unsigned long long nleaf = 0;
+    bool overflow = false;
+    for (int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x; idx < ld * M;
+         idx += (int64_t)gridDim.x * 64) {
+        const int64_t c = idx / ld, l = idx - c * ld;
+        if (l >= N) {
+            G[idx] = 0.0;
+            continue;
+        }
+        int error_code = 0;
+        G[idx] = tess_entry(lon_r[l], sinlat_a[l], coslat_a[l], radius_a[l], bounds6 + 6 * c, ratio,
+                            error_code, nleaf, overflow);
+        if (error_code != 0) atomicAdd(&err_cell[c], error_code);
+    }
     if (overflow) atomicExch(&stats->overflow, 1);
     // one atomic per wave for the leaf count
     unsigned long long tot = nleaf;
@@ -897,6 +906,115 @@ __global__ void __launch_bounds__(1024) stream_read_kernel(const double *G, int6
     }
     for (; i < n2; i += stride) acc += g[i];
     if (acc.x + acc.y == 1.2345e300) out[0] = acc.x;  // keep the loads alive
+}
+
+// ------------------------------------------------------------------------- matrix-free path
+// G is never stored: every entry is re-evaluated where it is needed (two evaluations per
+// leapfrog step: once for the adjoint/update pass, once for the forward pass), for problems whose
+// kernel matrix does not fit in HBM.  Wavefront reductions only, no MFMA.  The weighted kernel
+// is Aw_ij = K_ij / wm_j with the column norms wm computed by mf_colnorm_kernel.
+
+struct MfGeom {
+    int kind;  // 0 prism, 1 tesseroid
+    int64_t N, M;
+    const double *o0, *o1, *o2, *o3;  // prism: x,y,z,-  tesseroid: lon_r, sinlat, coslat, radius
+    const double *bounds6;
+    double ratio;
+};
+
+__device__ __forceinline__ double mf_entry(const MfGeom &g, int64_t i, const double *b)
+{
+    if (g.kind == 0) return prism_entry(g.o0[i], g.o1[i], g.o2[i], b);
+    int err = 0;
+    unsigned long long nl = 0;
+    bool ov = false;
+    return tess_entry(g.o0[i], g.o1[i], g.o2[i], g.o3[i], b, g.ratio, err, nl, ov);
+}
+
+// wm_j = (sum_i K_ij^2)^wf: one wave per cell, lanes over observations
+__global__ void __launch_bounds__(256) mf_colnorm_kernel(MfGeom g, double wf, double *wm)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= g.M) return;
+    const double *b = g.bounds6 + 6 * j;
+    double s = 0.0;
+    for (int64_t i = lane; i < g.N; i += 64) {
+        const double k = mf_entry(g, i, b);
+        s += k * k;
+    }
+    s = wave_allreduce_sum(s);
+    if (lane == 0) wm[j] = (wf == 0.5) ? sqrt(s) : pow(s, wf);
+}
+
+// Adjoint + leapfrog update for one cell per wave: the matrix-free counterpart of the ADJ /
+// UPD / PFIN / GOUT / SPEC part of sweep_kernel (same arithmetic per column).
+__global__ void __launch_bounds__(256) mf_adjoint_kernel(MfGeom g, SweepArgs a, const double *wm)
+{
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    const int mode = a.mode;
+    double pp = 0.0;
+    if (j < g.M) {
+        const double *b = g.bounds6 + 6 * j;
+        double s = 0.0;
+        for (int64_t i = lane; i < g.N; i += 64) s += mf_entry(g, i, b) * a.r[i];
+        s = wave_allreduce_sum(s);
+        const double w = wm[j];
+        s = (w != 0.0) ? s * (1.0 / w) : s;
+        const double gr = a.greg ? a.greg[j] : 0.0;
+        const double grad = 2.0 * s + gr;
+        if ((mode & SW_GOUT) && lane == 0) a.g_out[j] = grad;
+        if (mode & SW_PFIN) {
+            const double pf = a.p_in[j] - a.c_p * grad;
+            pp = pf * pf;
+            if (!(mode & SW_SPEC) && lane == 0) a.p_out[j] = pf;
+        }
+        if (mode & SW_UPD) {
+            const double psrc = (mode & SW_SPEC) ? a.pn_in[j] : a.p_in[j];
+            double pj = psrc - a.c_u * grad;
+            double xj = a.x_in[j] + a.dt * pj;
+            const double hi = a.high[j], lo = a.low[j];
+            if (xj > hi) {
+                xj = hi;
+                pj = -pj;
+            } else if (xj < lo) {
+                xj = lo;
+                pj = -pj;
+            }
+            if (lane == 0) {
+                a.p_out[j] = pj;
+                a.x_out[j] = xj;
+            }
+        }
+    }
+    if (mode & SW_PFIN) {
+        if (lane == 0) red[wave] = pp;
+        __syncthreads();
+        if (threadIdx.x == 0) a.pp_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+// Forward partials: thread = observation, blockIdx.y = chunk of cells; slab[chunk][i]
+__global__ void __launch_bounds__(256)
+mf_forward_kernel(MfGeom g, const double *x, const double *wm, int64_t cells_per_chunk, int64_t ld,
+                  double *slab)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ld) return;
+    const int64_t j0 = (int64_t)blockIdx.y * cells_per_chunk;
+    int64_t j1 = j0 + cells_per_chunk;
+    if (j1 > g.M) j1 = g.M;
+    double acc = 0.0;
+    if (i < g.N) {
+        for (int64_t j = j0; j < j1; ++j) {
+            const double w = wm ? wm[j] : 1.0;
+            const double xs = (w != 0.0) ? x[j] * (1.0 / w) : x[j];
+            acc += mf_entry(g, i, g.bounds6 + 6 * j) * xs;
+        }
+    }
+    slab[(int64_t)blockIdx.y * ld + i] = acc;
 }
 
 }  // namespace ghk

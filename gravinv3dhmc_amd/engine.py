@@ -83,6 +83,9 @@ class Engine(object):
             raise ValueError("bounds table must be (M, 6)")
         self._chk(self._lib.gh_set_cells(self._h, ptr(b), int(kind), float(ratio)))
 
+    def set_matrix_free(self, on=True):
+        self._chk(self._lib.gh_set_matrix_free(self._h, 1 if on else 0))
+
     def build_G(self):
         self._chk(self._lib.gh_build_G(self._h))
 

@@ -40,13 +40,15 @@ class GravMagModule(object):
     * device: GPU ordinal (extension; the reference has no such argument).
     * shard: a `dist.Ranks` object: the cells of ONE model are split in column blocks over the
       ranks' GPUs (each holds N x M/world of G); shard_backend "rccl" or "gloo".
+    * matrix_free: never store G; re-evaluate the prism / tesseroid entries in every potential
+      evaluation (for kernels larger than HBM; ~100x slower per step than the dense path).
     """
 
     def __init__(self, dobs, mrange, mspacing, obsurface, fixed=False, grav_fix=[],
                  mratio=1, mseg=False, mdivisionsection=[], weightfactor=0.5,
                  coordinate="cartesian", njobs=1, field="gravity",
                  mangle=(90, 0), wavelet=False, device=0, verbose=True, shard=None,
-                 shard_backend="rccl", **kwargs):
+                 shard_backend="rccl", matrix_free=False, **kwargs):
         self.dobs = dobs
         self.fixed = fixed
         self.grav_fix = grav_fix
@@ -99,6 +101,11 @@ class GravMagModule(object):
             eng = make_sharded_engine(N, bounds.shape[0], shard, backend=shard_backend)
         else:
             eng = Engine(N, bounds.shape[0], device=device)
+        if matrix_free:
+            if wavelet:
+                raise NotImplementedError("wavelet compression needs the stored kernel")
+            eng.set_matrix_free(True)
+        self.matrix_free = bool(matrix_free)
         eng.set_obs(self.lonobs, self.latobs, self.heightobs)
         if spherical:
             self._say("Number of effective tesseroids", bounds.shape[0])

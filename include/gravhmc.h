@@ -64,6 +64,10 @@ int gh_set_obs(gh_ctx *ctx, const double *a, const double *b, const double *c);
  * w,e,s,n,top,bottom (tesseroid); `ratio` is the tesseroid distance-size ratio
  * (tesseroid.py:77, 1.6 for gz), ignored for prisms. */
 int gh_set_cells(gh_ctx *ctx, const double *bounds6, int kind, double ratio);
+/* Matrix-free mode (call before gh_build_G): the kernel matrix is never stored; every potential
+ * evaluation re-evaluates the prism / tesseroid entries (two evaluations of each entry per
+ * leapfrog step: adjoint pass, forward pass).  For problems whose G exceeds HBM; any N. */
+int gh_set_matrix_free(gh_ctx *ctx, int enable);
 /* Assemble the dense kernel on the device.  Replaces the Python cell loop + native calls of
  * prism.py:291-316 -> _prism.pyx:265-290, or tesseroid.py:189-232 -> _tesseroid_numba.py:32-71,
  * including the unit scaling G*SI2MGAL.  For tesseroids returns GH_ERR_OVERFLOW if any

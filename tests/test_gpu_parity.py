@@ -196,8 +196,10 @@ def test_error_behaviour(G):
     with pytest.raises(ValueError):
         eng.chain_trajectory(np.zeros(eng.M), 0.01, 5, 0.5)   # chain before chain_init
     eng.close()
+    big = G.Engine(20000, 10)                            # > 16384 rows: matrix-free only
     with pytest.raises(NotImplementedError):
-        G.Engine(20000, 10)                              # needs row panels / sharding
+        big.upload_G(np.zeros((20000, 10)))
+    big.close()
     with pytest.raises(ValueError):
         G.Engine(0, 10)
 
@@ -655,3 +657,78 @@ def test_sharded_chain_two_ranks_one_gpu():
         assert r["ref_rows"] < 1e-7               # and they are the reference's rows (8 decimals)
         assert r["spec"]["spec_hits"] > 0
     print("sharded 2-rank check:", res[0])
+
+
+# ------------------------------------------------------------------------------ matrix-free
+
+def test_matrix_free_prism_matches_dense(G):
+    """gh_set_matrix_free: entries re-evaluated in every pass instead of read from HBM; same
+    potential, gradient and chain as the dense engine (<= 1e-12: summation order differs)."""
+    p = gold("potential_small.npz")
+    dense = _module_small(G, p)
+    mf = _module_small(G, p, matrix_free=True)
+    assert relmax(mf.Wm.diagonal(), dense.Wm.diagonal()) < 1e-13
+    wm = dense.Wm.diagonal()
+    x = p["xs"][1]
+    with pytest.raises(ValueError):
+        np.asarray(mf.Aw)                                 # nothing to copy back
+    assert relmax(mf._engine.forward(x), dense._engine.forward(x)) < 1e-12
+    r = np.random.default_rng(0).normal(size=42)
+    assert relmax(mf._engine.adjoint(r), dense._engine.adjoint(r)) < 1e-12
+    for reg in ("Damping", "MS", "TV"):
+        a = mf.misfit_and_grad(x, p["mwapr"], None, None, "mandatory", 1000, 0.7, regulization=reg, beta=0.001)
+        b = dense.misfit_and_grad(x, p["mwapr"], None, None, "mandatory", 1000, 0.7, regulization=reg, beta=0.001)
+        assert abs(a[0] - b[0]) < 1e-12 * abs(b[0]) and relmax(a[1], b[1]) < 1e-11
+    rng = np.random.default_rng(4)
+    trajs = [(int(rng.integers(1, 9)), rng.normal(size=120) * 0.3, float(rng.uniform())) for _ in range(8)]
+    outs = []
+    for m in (mf, dense):
+        e = m._engine
+        e.set_reg("TV", 1.0, 0.001, p["shape"], 0.001 * wm)
+        e.chain_init(0.001 * wm, 0.0 * wm, 0.02 * wm)
+        res = []
+        e.run_chain(iter(trajs), 0.02, lambda L, acc, o, e=e, res=res: res.append((acc, o.copy(), e.chain_get_x())))
+        outs.append(res)
+    for (a1, o1, x1), (a2, o2, x2) in zip(*outs):
+        assert a1 == a2 and relmax(o1, o2) < 1e-10 and relmax(x1, x2) < 1e-10
+
+
+def test_matrix_free_tesseroid_and_many_rows(G, orc):
+    g = gold("tess_cases.npz")
+    N, M = g["lon"].size, g["bounds"].shape[0]
+    dense, mf = G.Engine(N, M), G.Engine(N, M)
+    mf.set_matrix_free(True)
+    for e in (dense, mf):
+        e.set_obs(g["lon"], g["lat"], g["h"])
+        e.set_cells(g["bounds"], 1, 1.6)
+        e.build_G()
+    assert np.abs((mf.forward(g["rho"]) - g["gz"]) / g["gz"]).max() < 1e-10     # unweighted forward
+    wd, wmf = dense.weight(0.5), mf.weight(0.5)
+    assert relmax(wmf, wd) < 1e-13
+    x = g["rho"] * wd
+    assert relmax(mf.forward(x), dense.forward(x)) < 1e-12
+    r = np.random.default_rng(1).normal(size=N)
+    assert relmax(mf.adjoint(r), dense.adjoint(r)) < 1e-12
+    dense.close()
+    mf.close()
+    # more observations than the dense sweep holds in registers: matrix-free still works
+    N2 = 20000
+    rng = np.random.default_rng(2)
+    xp, yp = rng.uniform(0, 2000, N2), rng.uniform(0, 3000, N2)
+    zp = np.zeros(N2)
+    mesh = G.mesher.PrismMesh((0, 2000, 0, 3000, 0, 1000), (500, 1000, 1000))
+    b = mesh.cell_bounds()
+    M2 = b.shape[0]
+    e = G.Engine(N2, M2)
+    e.set_matrix_free(True)
+    e.set_obs(xp, yp, zp)
+    e.set_cells(b, 0)
+    e.build_G()
+    K = orc.prism_gz_kernel(xp, yp, zp, b)
+    rho = rng.uniform(0, 1, M2)
+    assert relmax(e.forward(rho), K @ rho) < 1e-11
+    wm = e.weight(0.5)
+    assert relmax(wm, np.sqrt((K ** 2).sum(0))) < 1e-12
+    r = rng.normal(size=N2)
+    assert relmax(e.adjoint(r), (K / wm).T @ r) < 1e-11
+    e.close()
