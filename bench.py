@@ -64,6 +64,36 @@ def make_problem(name):
     return mesh, xp, yp, zp, rho.ravel()
 
 
+#: the other BASELINE.json configs, runnable with --workload (parity-test cases, not bench lines)
+EXTRA = {
+    # C3: segmentgrid, wavelet='3D' compressed forward + dense adjoint, TV
+    "c3_segment_wavelet3d_tv": dict(kind=0, reg="TV", alpha=1.0, beta=0.001, dt=0.01, hi=1.0,
+                                    wavelet=3),
+    # C4: global 3 deg tesseroid mesh, 121 x 61 obs at 5000 m, Damping 0.05, bounds [0, 0.8]
+    "c4_global_tesseroid": dict(kind=1, reg="Damping", alpha=0.05, beta=0.01, dt=0.005, hi=0.8,
+                                wavelet=0),
+}
+
+
+def make_extra(name):
+    from gravinv3dhmc_amd import mesher
+    if name == "c3_segment_wavelet3d_tv":
+        mesh = mesher.PrismMeshSegment((0, 2000, 0, 3000, 0, 2100), ([100, 200, 300], 100, 100),
+                                       [0, 300, 900, 2100])
+        yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 3000, 30), np.linspace(0, 2000, 20))]
+        obs = (xp, yp, np.zeros_like(xp))
+        rho = np.zeros(mesh.shape)
+        rho[2:5, 10:18, 7:11] = 1.0
+    else:
+        mesh = mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))
+        lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 3.0), np.arange(-90, 91, 3.0),
+                                                   indexing="ij")]
+        obs = (lon, lat, np.full_like(lon, 5000.0))
+        rho = np.zeros(mesh.shape)
+        rho[1:4, 20:30, 40:60] = 0.3
+    return mesh, obs, rho.ravel()
+
+
 def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=12.0):
     """The reference's CPU formulation (NumPy + multi-threaded BLAS dgemv pair per potential
     evaluation, NumPy leapfrog; oracle/numpy_port.py, kind "port") on a column-subsampled copy
@@ -113,7 +143,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2_uniform_100x100x50", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="c2_uniform_100x100x50",
+                    choices=list(WORKLOADS) + list(EXTRA))
+    ap.add_argument("--matrix-free", action="store_true",
+                    help="never store G: re-evaluate the kernel entries in every pass")
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", action="store_true",
@@ -136,7 +169,13 @@ def main():
                  "--nproc-per-node %d" % (args.gpus, args.gpus))
 
     import gravinv3dhmc_amd as g
-    mesh, xp, yp, zp, rho = make_problem(args.workload)
+    extra = EXTRA.get(args.workload)
+    if extra:
+        mesh, (xp, yp, zp), rho = make_extra(args.workload)
+    else:
+        mesh, xp, yp, zp, rho = make_problem(args.workload)
+        extra = dict(kind=0, reg="Damping", alpha=1.0, beta=0.01, dt=WORKLOADS[args.workload][4],
+                     hi=1.0, wavelet=0)
     N, M = xp.size, mesh.size
     dev = 0 if args.rehearse_on_one_gpu else local_rank
     if args.shard:
@@ -145,9 +184,11 @@ def main():
     else:
         eng = g.Engine(N, M, device=dev)
     info = eng.device_info()
+    if args.matrix_free:
+        eng.set_matrix_free(True)
     t0 = time.time()
     eng.set_obs(xp, yp, zp)
-    eng.set_cells(mesh.cell_bounds(), 0)
+    eng.set_cells(mesh.cell_bounds(), extra["kind"], 1.6)
     eng.build_G()
     eng.synchronize()
     t_build = time.time() - t0
@@ -155,15 +196,18 @@ def main():
     t0 = time.time()
     wm = eng.weight(0.5)
     t_weight = time.time() - t0
-    dobs = d_true + np.random.default_rng(0).normal(0.0, 0.02 * d_true.max(), N)
+    nnz = None
+    if extra["wavelet"]:
+        nnz, _ = eng.compress_wavelet(extra["wavelet"], mesh.shape, 1e-3, 2)
+    dobs = d_true + np.random.default_rng(0).normal(0.0, 0.02 * np.abs(d_true).max(), N)
     eng.set_data(dobs)
-    eng.set_reg("Damping", 1.0, 0.01, mesh.shape, 0.001 * wm)
-    low, high = 0.0 * wm, 1.0 * wm
+    eng.set_reg(extra["reg"], extra["alpha"], extra["beta"], mesh.shape, 0.001 * wm)
+    low, high = 0.0 * wm, extra["hi"] * wm
     eng.chain_init(0.001 * wm, low, high)
 
     # the reference's RNG stream (legacy global generator), one chain per rank
     np.random.seed(100 if args.shard else 100 + rank)   # a sharded chain shares one stream
-    Sigma, dt, L = 0.001, WORKLOADS[args.workload][4], args.traj_len
+    Sigma, dt, L = 0.001, extra["dt"], args.traj_len
 
     def run(total_steps):
         """Trajectories of L steps until total_steps leapfrog steps are done, pipelined as the
@@ -215,7 +259,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "N_obs": int(N), "M_cells": int(M),
-                       "G_bytes": int(N) * int(M) * 8, "regulariser": "Damping",
+                       "G_bytes": int(N) * int(M) * 8, "regulariser": extra["reg"],
+                       "matrix_free": bool(args.matrix_free), "wavelet_nnz": nnz,
                        "chains_per_gpu": 1, "dt": dt, "traj_len": L, "trajectories": ntraj,
                        "accepted": naccept, "speculative_first_steps": eng.chain_stats(), "parallelism": ("1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step"
                                        % (world, args.shard_backend)) if args.shard
@@ -230,7 +275,11 @@ def main():
                          "reference_formulation_equiv_GBps":
                              2 * bytes_sweep * args.steps / elapsed / 1e9},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.matrix_free:
+            line["roofline"].update({"bound": "fp64 transcendental throughput (no stored G)",
+                                     "achieved": None, "frac": None, "traffic": None,
+                                     "pair_evaluations_per_step": 2 * int(N) * int(M)})
+        if not args.no_cpu_baseline and world == 1 and args.workload in WORKLOADS:
             try:
                 line["cpu_baseline"] = cpu_baseline(mesh, xp, yp, zp, dobs)
             except Exception as e:  # the baseline is a reported extra, never the product path
