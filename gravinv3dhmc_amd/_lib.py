@@ -52,6 +52,9 @@ PROTOTYPES = {
     "gh_chain_stats": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64)]),
     "gh_chain_get_x": (C.c_int, [_ctx, _dp]),
     "gh_chain_get_dsyn": (C.c_int, [_ctx, _dp]),
+    "gh_posterior_window": (C.c_int, [_ctx, C.c_int]),
+    "gh_posterior_add": (C.c_int, [_ctx]),
+    "gh_posterior_read": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), _dp, _dp]),
     "gh_leapfrog": (C.c_int, [_ctx, _dp, _dp, C.c_double, C.c_int, _dp, _dp, C.c_double,
                               C.POINTER(C.c_int), _dp, _dp]),
     "gh_shard_unique_id": (C.c_int, [C.c_void_p]),

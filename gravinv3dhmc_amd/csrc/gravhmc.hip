@@ -115,6 +115,11 @@ struct gh_ctx {
         double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
     } wv;
 
+    // ring of the last K accepted samples (posterior statistics without text I/O)
+    double *ring = nullptr, *ring_mean = nullptr, *ring_sd = nullptr;
+    int ring_K = 0, ring_next = 0;
+    int64_t ring_count = 0;
+
     // profiling of the sweeps
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -1456,6 +1461,50 @@ int gh_chain_stats(gh_ctx *c, int64_t *spec_hits, int64_t *spec_misses)
     if (!c) return GH_ERR_ARG;
     if (spec_hits) *spec_hits = c->spec_hits;
     if (spec_misses) *spec_misses = c->spec_misses;
+    return GH_OK;
+}
+
+int gh_posterior_window(gh_ctx *c, int K)
+{
+    if (!c || K < 1) return fail(c, GH_ERR_ARG, "gh_posterior_window: K must be >= 1");
+    if (c->ring) return fail(c, GH_ERR_ARG, "gh_posterior_window: window already allocated");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(dalloc(c, &c->ring, (size_t)K * (size_t)c->M));
+    TRY(dalloc(c, &c->ring_mean, (size_t)c->M));
+    TRY(dalloc(c, &c->ring_sd, (size_t)c->M));
+    c->ring_K = K;
+    c->ring_next = 0;
+    c->ring_count = 0;
+    return GH_OK;
+}
+
+int gh_posterior_add(gh_ctx *c)
+{
+    if (!c) return GH_ERR_ARG;
+    TRY(need(c, c->chain_ready && c->ring, "gh_posterior_add: needs gh_chain_init and gh_posterior_window"));
+    HIPCHK(c, hipSetDevice(c->device));
+    ring_store_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
+        c->xb[c->xcur], c->weighted ? c->wm : nullptr, c->M, c->ring + (size_t)c->ring_next * (size_t)c->M);
+    HIPCHK(c, hipGetLastError());
+    c->ring_next = (c->ring_next + 1) % c->ring_K;
+    c->ring_count += 1;
+    return GH_OK;
+}
+
+int gh_posterior_read(gh_ctx *c, int64_t *n_in_window, int64_t *n_total, double *mean, double *sd)
+{
+    if (!c) return GH_ERR_ARG;
+    TRY(need(c, c->ring != nullptr, "gh_posterior_read: call gh_posterior_window first"));
+    const int nvalid = (int)std::min<int64_t>(c->ring_count, c->ring_K);
+    if (n_in_window) *n_in_window = nvalid;
+    if (n_total) *n_total = c->ring_count;
+    if (nvalid == 0 || (!mean && !sd)) return GH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    ring_stats_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(c->ring, c->M, nvalid,
+                                                                                        c->ring_mean, c->ring_sd);
+    HIPCHK(c, hipGetLastError());
+    if (mean) TRY(d2h(c, mean, c->ring_mean, (size_t)c->M));
+    if (sd) TRY(d2h(c, sd, c->ring_sd, (size_t)c->M));
     return GH_OK;
 }
 

@@ -908,6 +908,38 @@ __global__ void __launch_bounds__(1024) stream_read_kernel(const double *G, int6
     if (acc.x + acc.y == 1.2345e300) out[0] = acc.x;  // keep the loads alive
 }
 
+// ---------------------------------------------------------------- posterior sample window
+// Accepted samples m = x / wm (hmc.py:328) are kept in a ring of the last K models in HBM, so
+// the statistics the reference's plot scripts compute from the tail of model.dat
+// (plot_uniform.py:44-55,103-104: np.mean / np.std over the last 100 rows) need no text I/O.
+
+__global__ void __launch_bounds__(256)
+ring_store_kernel(const double *x, const double *wm, int64_t M, double *slot)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const double w = wm ? wm[j] : 1.0;
+    slot[j] = x[j] * (1.0 / w);  // WmInv @ mw: the reference multiplies by the stored reciprocal
+}
+
+// two-pass mean / population std over the K' valid slots, per cell (numpy's definition)
+__global__ void __launch_bounds__(256)
+ring_stats_kernel(const double *ring, int64_t M, int nvalid, double *mean, double *sd)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    double s = 0.0;
+    for (int k = 0; k < nvalid; ++k) s += ring[(int64_t)k * M + j];
+    const double mu = s / (double)nvalid;
+    double q = 0.0;
+    for (int k = 0; k < nvalid; ++k) {
+        const double d = ring[(int64_t)k * M + j] - mu;
+        q += d * d;
+    }
+    mean[j] = mu;
+    sd[j] = sqrt(q / (double)nvalid);
+}
+
 // ------------------------------------------------------------------------- matrix-free path
 // G is never stored: every entry is re-evaluated where it is needed (two evaluations per
 // leapfrog step: once for the adjoint/update pass, once for the forward pass), for problems whose

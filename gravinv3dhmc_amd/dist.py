@@ -223,6 +223,12 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl"):
         def chain_get_x(self):
             return self._full(Engine.chain_get_x(self))
 
+        def posterior_read(self, want_arrays=True):
+            out = Engine.posterior_read(self, want_arrays)
+            if want_arrays:
+                out["mean"], out["std"] = self._full(out["mean"]), self._full(out["std"])
+            return out
+
         def download_G(self):
             raise NotImplementedError("the sharded kernel is never gathered on one host")
 

@@ -249,6 +249,21 @@ class Engine(object):
         self._chk(self._lib.gh_chain_get_dsyn(self._h, ptr(d)))
         return d
 
+    # -- posterior window ---------------------------------------------------------
+    def posterior_window(self, K=100):
+        self._chk(self._lib.gh_posterior_window(self._h, int(K)))
+        self._has_window = True
+
+    def posterior_add(self):
+        self._chk(self._lib.gh_posterior_add(self._h))
+
+    def posterior_read(self, want_arrays=True):
+        n, tot = C.c_int64(0), C.c_int64(0)
+        mean = np.empty(self.M) if want_arrays else None
+        sd = np.empty(self.M) if want_arrays else None
+        self._chk(self._lib.gh_posterior_read(self._h, C.byref(n), C.byref(tot), ptr(mean), ptr(sd)))
+        return {"n": n.value, "total": tot.value, "mean": mean, "std": sd}
+
     def leapfrog(self, x, p0, dt, L, low, high, u, want_dsyn=True):
         x = f64(x).copy()
         p0, low, high = f64(p0), f64(low), f64(high)

@@ -33,6 +33,12 @@ class HamitonianMC(object):
         self.myrank = None
         self.save_folder = None
         self.cache = {}
+        #: where accepted models go: "text" = the reference's model.dat ('%.8f' rows, hmc.py:328-332);
+        #: "binary" = float64 rows appended to model.bin (no formatting cost: at 5*10^5 cells one text
+        #: row is 5.5 MB and takes longer to format than the trajectory that produced it);
+        #: "none" = only the device-side window of the last `posterior_last` models is kept.
+        self.sample_sink = "text"
+        self.posterior_last = 100
         self._chain_x = None  # identity of the host vector the device chain state mirrors
 
     def _kinetic(self, p):
@@ -139,20 +145,35 @@ class HamitonianMC(object):
         self._chain_x = None
         state = {"x": x, "i": 0, "ncount": 0}
 
+        window = self.constraint == 'mandatory' and self.posterior_last > 0
+        if window and not getattr(self.model._engine, "_has_window", False):
+            self.model._engine.posterior_window(self.posterior_last)
+        if self.sample_sink not in ("text", "binary", "none"):
+            raise ValueError("sample_sink must be 'text', 'binary' or 'none'")
+        if self.sample_sink == "binary" and os.path.exists(self.save_folder + "/model.bin"):
+            os.remove(self.save_folder + "/model.bin")
+
         def record(U, U_data, U_model, AcceptFlag, get_x):
             """Bookkeeping of one finished trajectory (hmc.py:299-342)."""
             U_data_normed = U_data / data_size
             U_model_normed = U_model / model_size
             U_normed = U_data_normed + alpha * U_model_normed
             if AcceptFlag:
-                state["x"] = get_x()
+                if self.sample_sink != "none" or self.constraint != 'mandatory':
+                    state["x"] = get_x()
                 if state["i"] >= ndraws:
                     misfit[0, :] = (U, U_data, U_model, U_normed, U_data_normed, U_model_normed,
                                     alpha)
                     self._save_misfit_add(misfit)
-                    m = WmInv @ self._to_mw(state["x"])
-                    m_cache[0, :] = m.copy()
-                    self._save_models_add(m_cache)
+                    if self.sample_sink == "text":
+                        m = WmInv @ self._to_mw(state["x"])
+                        m_cache[0, :] = m.copy()
+                        self._save_models_add(m_cache)
+                    elif self.sample_sink == "binary":
+                        with open(self.save_folder + "/model.bin", "ab") as f:
+                            np.ascontiguousarray(WmInv @ self._to_mw(state["x"])).tofile(f)
+                    if window:
+                        self.model._engine.posterior_add()
                 state["i"] += 1
             state["ncount"] += 1
             msg = "chain {}: {:.2%}, misfit(total, data, alpha, model)=({:.7f},{:.7f},{:.2f},{:.7f}) " \
@@ -211,7 +232,7 @@ def HMCSample(model, nsamples, ndraws, delta, Lrange,
               initial_model, aprior_model, boundaries, constraint, log_factor, dobs,
               adaptiveRegul, RegulRate, RegulFactor, regularization, beta,
               seed, Sigma, nbest=100, myrank=0, save_folder="mychain",
-              plotsamples=False, im=[0, 0]):
+              plotsamples=False, im=[0, 0], sample_sink="text", posterior_last=100):
     """Set up one chain and run it (hmc.py:358-403).  Chains of different ranks are
     independent: seed + myrank, folder save_folder + str(myrank)."""
     chain = HamitonianMC(model)
@@ -241,5 +262,7 @@ def HMCSample(model, nsamples, ndraws, delta, Lrange,
     chain.aprior_model = Wm @ aprior_model
     chain.dobs = dobs
     chain.plotsamples = plotsamples
+    chain.sample_sink = sample_sink
+    chain.posterior_last = posterior_last
     chain.sample(nsamples, ndraws)
     return chain

@@ -156,6 +156,16 @@ int gh_chain_prefetch_momentum(gh_ctx *ctx, const double *p0_next);
 int gh_chain_stats(gh_ctx *ctx, int64_t *spec_hits, int64_t *spec_misses);
 int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
 int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state */);
+/* Posterior statistics without text I/O.  The reference appends every accepted
+ * model as a '%.8f' text row to model.dat (hmc.py:328-332) and its plot scripts take np.mean /
+ * np.std over the last 100 rows (plot_uniform.py:44-55,103-104).  gh_posterior_window reserves a
+ * ring of the last K models m = WmInv @ mw in HBM; gh_posterior_add stores the chain's current
+ * state (call it for every accepted, post-burn-in sample); gh_posterior_read returns the
+ * per-cell mean and population standard deviation over the window. */
+int gh_posterior_window(gh_ctx *ctx, int K);
+int gh_posterior_add(gh_ctx *ctx);
+int gh_posterior_read(gh_ctx *ctx, int64_t *n_in_window, int64_t *n_total, double *mean /* M or NULL */,
+                      double *sd /* M or NULL */);
 /* Stateless convenience with the signature SURVEY 8b lists: init + trajectory + readback. */
 int gh_leapfrog(gh_ctx *ctx, double *x_inout, const double *p0, double dt, int L,
                 const double *low, const double *high, double u, int *accepted,

@@ -732,3 +732,50 @@ def test_matrix_free_tesseroid_and_many_rows(G, orc):
     r = rng.normal(size=N2)
     assert relmax(e.adjoint(r), (K / wm).T @ r) < 1e-11
     e.close()
+
+
+# ----------------------------------------------------------- sample sink / posterior statistics
+
+def test_posterior_window_and_sample_sinks(G, orc, tmp_path, capsys):
+    """Device-side ring of accepted models against np.mean/np.std over the tail of model.dat
+    (plot_uniform.py:44-55,103-104); binary and 'none' sinks; RMSD / RMSM (plot_uniform.py:152-153)."""
+    from gravinv3dhmc_amd import posterior
+    p = gold("potential_small.npz")
+    M = p["wm"].size
+    args = lambda: (np.full(M, 0.001), np.full(M, 0.001), np.c_[np.zeros(M), np.ones(M)], "mandatory",
+                    1000, p["dobs"], "Fixed", 0.8, 1.0, "Damping", 0.001, 100, 0.001)
+    runs = {}
+    for sink in ("text", "binary", "none"):
+        gm = _module_small(G, p)
+        folder = str(tmp_path / ("sink_%s_chain" % sink))
+        G.HMCSample(gm, 14, 2, 0.01, [5, 20], *args(), save_folder=folder, sample_sink=sink,
+                    posterior_last=10)
+        runs[sink] = (gm, folder + "0")
+    capsys.readouterr()
+    gm, folder = runs["text"]
+    rows = np.loadtxt(folder + "/model.dat")
+    assert rows.shape == (14, M)                       # ndraws = 2 burn-in samples are not written
+    st = gm._engine.posterior_read()
+    assert st["n"] == 10 and st["total"] == 14
+    mean, sd, n = posterior.stats_from_file(folder + "/model.dat", last=10)
+    np.testing.assert_allclose(st["mean"], mean, atol=1e-8)
+    np.testing.assert_allclose(st["std"], sd, atol=1e-8)
+    # binary sink: same models without the text formatting, same device statistics
+    gmb, fb = runs["binary"]
+    raw = np.fromfile(fb + "/model.bin").reshape(-1, M)
+    np.testing.assert_allclose(raw, rows, atol=5.1e-9)
+    assert not os.path.exists(fb + "/model.dat")
+    stb = gmb._engine.posterior_read()
+    assert np.array_equal(stb["mean"], st["mean"]) and np.array_equal(stb["std"], st["std"])
+    gmn, fn = runs["none"]
+    assert not os.path.exists(fn + "/model.dat") and not os.path.exists(fn + "/model.bin")
+    assert np.array_equal(gmn._engine.posterior_read()["mean"], st["mean"])
+    assert np.loadtxt(fn + "/misfit.dat").shape == (14, 7)
+    # summary numbers
+    rho_true = np.zeros(M)
+    rho_true[40:50] = 1.0
+    sm = posterior.summarize(gm, p["dobs"], rho_true)
+    Aw = np.asarray(gm.Aw)
+    d_mean = Aw @ (gm.Wm.diagonal() * st["mean"])
+    assert abs(sm["RMSD"] - np.sqrt(np.linalg.norm(p["dobs"] - d_mean) ** 2 / 42)) < 1e-12
+    assert abs(sm["RMSM"] - np.sqrt(np.linalg.norm(rho_true - st["mean"]) ** 2 / M)) < 1e-15
