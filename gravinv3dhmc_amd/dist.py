@@ -223,6 +223,12 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl"):
         def chain_get_x(self):
             return self._full(Engine.chain_get_x(self))
 
+        def _loc_vec(self, v):
+            return self._loc(v)
+
+        def _full_vec(self, v):
+            return self._full(v)
+
         def posterior_read(self, want_arrays=True):
             out = Engine.posterior_read(self, want_arrays)
             if want_arrays:

@@ -205,39 +205,84 @@ class Engine(object):
         self._chk(self._lib.gh_chain_stats(self._h, C.byref(a), C.byref(b)))
         return {"spec_hits": a.value, "spec_misses": b.value}
 
-    def run_chain(self, draws, dt, on_result, max_trajectories=None):
-        """Pipelined trajectories: `draws` yields (L, p0, u) in RNG-stream order; the momentum
-        of trajectory k+1 is announced before trajectory k runs (speculative first step) and
-        trajectory k+2 is drawn on the host while the GPU works.  `on_result(L, accepted, out5)`
-        returns False to stop."""
+    def _run_batch(self, batch, lookahead, dt, stop_at, record_from, want_x):
+        """One gh_chain_run call over a list of (L, p0, u); returns per-trajectory results."""
+        K = len(batch)
+        Ls = (C.c_int * K)(*[int(b[0]) for b in batch])
+        p0s = np.ascontiguousarray(np.stack([self._loc_vec(b[1]) for b in batch]))
+        us = np.ascontiguousarray([float(b[2]) for b in batch], dtype=np.float64)
+        look = self._loc_vec(lookahead[1]) if lookahead is not None else None
+        acc = (C.c_int * K)()
+        out5 = np.empty((K, 5))
+        xs = np.empty((K, p0s.shape[1])) if want_x else None
+        n_run = C.c_int(0)
+        self._chk(self._lib.gh_chain_run(self._h, K, Ls, ptr(p0s), ptr(us), float(dt), ptr(look),
+                                         int(stop_at), int(record_from), acc, ptr(out5), ptr(xs),
+                                         C.byref(n_run)))
+        return [(bool(acc[k]), out5[k].copy(), xs[k].copy() if (want_x and acc[k]) else None)
+                for k in range(n_run.value)]
+
+    def default_batch(self):
+        """Trajectories per gh_chain_run call: enough to hide the Python round trip, few enough
+        that the host draw of the next batch still overlaps the GPU (C2: 1, C1: 32)."""
+        return int(max(1, min(32, (2 << 20) // (8 * max(1, self.M)))))
+
+    def _loc_vec(self, v):
+        return f64(v)
+
+    def _full_vec(self, v):
+        return v
+
+    def run_chain(self, draws, dt, on_result, stop_at_accepts=0, record_from=0, want_x=False,
+                  batch=None):
+        """Pipelined trajectories: `draws` yields (L, p0, u) in RNG-stream order.  Batches of
+        trajectories run inside one library call (gh_chain_run: momentum of trajectory k+1
+        announced before trajectory k, so an accepted proposal's last sweep already takes the
+        next first step) while the next batch is drawn on the host.
+        `on_result(L, accepted, out5, x)` is called per finished trajectory (x = chain state after
+        an accepted trajectory if want_x, else None) and may return False to stop."""
         import threading
+        if batch is None:
+            batch = self.default_batch()
         it = iter(draws)
-        cur = next(it, None)
-        nxt = next(it, None) if cur is not None else None
-        n = 0
-        while cur is not None:
-            if nxt is not None:
-                self.chain_prefetch_momentum(nxt[1])
+
+        def take(n):
+            out = []
+            for _ in range(n):
+                d = next(it, None)
+                if d is None:
+                    break
+                out.append(d)
+            return out
+
+        cur = take(batch)
+        look = take(1) if cur else []
+        while cur:
             res = {}
 
-            def work(cur=cur):
+            def work(cur=cur, look=look):
                 try:
-                    res["r"] = self.chain_trajectory(cur[1], dt, cur[0], cur[2])
+                    res["r"] = self._run_batch(cur, look[0] if look else None, dt, stop_at_accepts,
+                                               record_from, want_x)
                 except BaseException as e:  # re-raised in the caller's thread
                     res["e"] = e
 
             th = threading.Thread(target=work)
             th.start()
-            nn = next(it, None) if nxt is not None else None   # drawn while the GPU runs
+            # the lookahead trajectory opens the next batch; the rest is drawn while the GPU runs
+            nxt = (look + take(batch - 1)) if look else []
+            nlook = take(1) if nxt else []
             th.join()
             if "e" in res:
                 raise res["e"]
-            n += 1
-            if on_result(cur[0], res["r"][0], res["r"][1]) is False:
+            stop = False
+            for (L, _p0, _u), (acc, o, x) in zip(cur, res["r"]):
+                if on_result(L, acc, o, self._full_vec(x) if x is not None else None) is False:
+                    stop = True
+                    break
+            if stop or len(res["r"]) < len(cur):
                 break
-            if max_trajectories is not None and n >= max_trajectories:
-                break
-            cur, nxt = nxt, nn
+            cur, look = nxt, nlook
 
     def chain_get_x(self):
         x = np.empty(self.M)

@@ -153,14 +153,17 @@ class HamitonianMC(object):
         if self.sample_sink == "binary" and os.path.exists(self.save_folder + "/model.bin"):
             os.remove(self.save_folder + "/model.bin")
 
+        fused = self.constraint == 'mandatory' and ndraws + nsamples > 0
+
         def record(U, U_data, U_model, AcceptFlag, get_x):
             """Bookkeeping of one finished trajectory (hmc.py:299-342)."""
             U_data_normed = U_data / data_size
             U_model_normed = U_model / model_size
             U_normed = U_data_normed + alpha * U_model_normed
             if AcceptFlag:
-                if self.sample_sink != "none" or self.constraint != 'mandatory':
-                    state["x"] = get_x()
+                xs_ = get_x()
+                if xs_ is not None:
+                    state["x"] = xs_
                 if state["i"] >= ndraws:
                     misfit[0, :] = (U, U_data, U_model, U_normed, U_data_normed, U_model_normed,
                                     alpha)
@@ -172,7 +175,7 @@ class HamitonianMC(object):
                     elif self.sample_sink == "binary":
                         with open(self.save_folder + "/model.bin", "ab") as f:
                             np.ascontiguousarray(WmInv @ self._to_mw(state["x"])).tofile(f)
-                    if window:
+                    if window and not fused:
                         self.model._engine.posterior_add()
                 state["i"] += 1
             state["ncount"] += 1
@@ -199,7 +202,9 @@ class HamitonianMC(object):
                     yield L, p0, np.random.rand()
 
             eng.run_chain(draws(), self.dt,
-                          lambda L, acc, o: record(o[0], o[1], o[2], acc, eng.chain_get_x))
+                          lambda L, acc, o, xs: record(o[0], o[1], o[2], acc, lambda: xs),
+                          stop_at_accepts=ndraws + nsamples, record_from=ndraws,
+                          want_x=self.sample_sink != "none")
             self._chain_x = state["x"]
             return state["x"]
         while state["i"] < ndraws + nsamples:

@@ -152,6 +152,17 @@ int gh_chain_trajectory(gh_ctx *ctx, const double *p0, double dt, int L, double 
  * with and without it; a rejected proposal simply discards the speculative step.  The
  * announcement is consumed by one gh_chain_trajectory call. */
 int gh_chain_prefetch_momentum(gh_ctx *ctx, const double *p0_next);
+/* K trajectories in one call (the body of HamitonianMC.sample's loop, hmc.py:295-343, without
+ * a Python round trip per trajectory): L[k], p0s[k*M..], us[k] in RNG-stream order;
+ * p0_lookahead (or NULL) is the momentum of the trajectory after the batch so the speculative
+ * first step also crosses batch boundaries.  Accepted proposals are counted since
+ * gh_chain_init; the run stops early once `stop_at_accepts` (> 0) have been accepted, and the
+ * posterior window (if any) receives every accepted state beyond the first `record_from`
+ * (the sampler's ndraws burn-in).  accepted[k], out5s[5k..] as gh_chain_trajectory; x_out (K*M or
+ * NULL) receives the chain state after each ACCEPTED trajectory k; n_run = trajectories done. */
+int gh_chain_run(gh_ctx *ctx, int K, const int *L, const double *p0s, const double *us, double dt,
+                 const double *p0_lookahead, int64_t stop_at_accepts, int64_t record_from,
+                 int *accepted, double *out5s, double *x_out, int *n_run);
 /* How often the speculative first step was used / discarded. */
 int gh_chain_stats(gh_ctx *ctx, int64_t *spec_hits, int64_t *spec_misses);
 int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
