@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2_uniform_100x100x50",
                     choices=list(WORKLOADS) + list(EXTRA))
+    ap.add_argument("--chains-per-gpu", type=int, default=1,
+                    help="independent chains batched on each GPU against ONE copy of G through the "
+                         "fp64 MFMA path (1..16); value then counts the steps of all chains")
     ap.add_argument("--matrix-free", action="store_true",
                     help="never store G: re-evaluate the kernel entries in every pass")
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
@@ -205,53 +208,90 @@ def main():
     low, high = 0.0 * wm, extra["hi"] * wm
     eng.chain_init(0.001 * wm, low, high)
 
-    # the reference's RNG stream (legacy global generator), one chain per rank
-    np.random.seed(100 if args.shard else 100 + rank)   # a sharded chain shares one stream
     Sigma, dt, L = 0.001, extra["dt"], args.traj_len
-
-    def prepare(total_steps):
-        """Trajectories of L steps until total_steps leapfrog steps are done, pipelined as the
-        sampler does it (Engine.run_chain): momenta are drawn in the reference's RNG order one
-        trajectory ahead, so the host draw overlaps the GPU and an accepted proposal's last
-        sweep already takes the next trajectory's first step."""
-        plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
-
-        def draws():
-            for n in plan:
-                yield n, np.random.randn(M) * Sigma, np.random.rand()
-
-        # a sampler in steady state has its next batch drawn while the GPU was busy: draw the
-        # first batch (+ its lookahead) before the clock starts, the rest overlaps as usual
-        import itertools
-        gen = draws()
-        head = list(itertools.islice(gen, eng.default_batch() + 1))
-        return plan, itertools.chain(head, gen)
-
-    def run(prepared):
-        plan, gen = prepared
-
-        stat = {"acc": 0, "traj": 0}
-
-        def on_result(n, acc, out5, x):
-            stat["acc"] += int(acc)
-            stat["traj"] += 1
-
-        eng.run_chain(gen, dt, on_result)
-        return stat["acc"], stat["traj"]
-
+    CPG = args.chains_per_gpu
     barrier = ranks.barrier
+    if CPG > 1:
+        # ---- several chains per GPU: one RandomState per chain (seed 100 + global chain index,
+        # the stream np.random.seed gives the reference's rank), lock-step rounds of L steps
+        from concurrent.futures import ThreadPoolExecutor
+        rs = [np.random.RandomState(100 + rank * CPG + k) for k in range(CPG)]
+        pool = ThreadPoolExecutor(max_workers=CPG)
+        x0s = np.stack([0.001 * wm for _ in range(CPG)])
+        eng.batch_init(x0s, low, high)
 
-    if args.warmup > 0:
-        run(prepare(args.warmup))
-    prepared = prepare(args.steps)
-    eng.synchronize()
-    barrier()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    naccept, ntraj = run(prepared)
-    eng.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+        def draw_round(n):
+            def one(r):
+                return r.randn(M) * Sigma, r.rand()
+            res = list(pool.map(one, rs))
+            return np.stack([p for p, _ in res]), np.array([u for _, u in res]), n
+
+        def run_rounds(total_steps, first):
+            plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
+            nacc, nxt = 0, first
+            for i, n in enumerate(plan):
+                p0s, us, _ = nxt
+                fut = pool.submit(eng.batch_trajectory, p0s, dt, [n] * CPG, us)
+                nxt = draw_round(plan[i + 1]) if i + 1 < len(plan) else None
+                acc, _ = fut.result()
+                nacc += sum(acc)
+            return nacc, len(plan)
+
+        if args.warmup > 0:
+            run_rounds(args.warmup, draw_round(L))
+        first = draw_round(L)
+        eng.synchronize()
+        barrier()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        naccept, ntraj = run_rounds(args.steps, first)
+        eng.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+    else:
+        # the reference's RNG stream (legacy global generator), one chain per rank
+        np.random.seed(100 if args.shard else 100 + rank)   # a sharded chain shares one stream
+
+        def prepare(total_steps):
+            """Trajectories of L steps until total_steps leapfrog steps are done, pipelined as the
+            sampler does it (Engine.run_chain): momenta are drawn in the reference's RNG order one
+            trajectory ahead, so the host draw overlaps the GPU and an accepted proposal's last
+            sweep already takes the next trajectory's first step."""
+            plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
+
+            def draws():
+                for n in plan:
+                    yield n, np.random.randn(M) * Sigma, np.random.rand()
+
+            # a sampler in steady state has its next batch drawn while the GPU was busy: draw the
+            # first batch (+ its lookahead) before the clock starts, the rest overlaps as usual
+            import itertools
+            gen = draws()
+            head = list(itertools.islice(gen, eng.default_batch() + 1))
+            return plan, itertools.chain(head, gen)
+
+        def run(prepared):
+            plan, gen = prepared
+            stat = {"acc": 0, "traj": 0}
+
+            def on_result(n, acc, out5, x):
+                stat["acc"] += int(acc)
+                stat["traj"] += 1
+
+            eng.run_chain(gen, dt, on_result)
+            return stat["acc"], stat["traj"]
+
+        if args.warmup > 0:
+            run(prepare(args.warmup))
+        prepared = prepare(args.steps)
+        eng.synchronize()
+        barrier()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        naccept, ntraj = run(prepared)
+        eng.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
     prof = eng.profile_read()
     eng.profile_enable(False)
     elapsed = ranks.max(elapsed)
@@ -262,7 +302,7 @@ def main():
         achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
         line = {
             "metric": "HMC leapfrog steps/sec + G*rho achieved HBM GB/s",
-            "value": args.steps * (1 if args.shard else world) / elapsed,
+            "value": args.steps * CPG * (1 if args.shard else world) / elapsed,
             "unit": "leapfrog steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -272,8 +312,8 @@ def main():
             "config": {"workload": args.workload, "N_obs": int(N), "M_cells": int(M),
                        "G_bytes": int(N) * int(M) * 8, "regulariser": extra["reg"],
                        "matrix_free": bool(args.matrix_free), "wavelet_nnz": nnz,
-                       "chains_per_gpu": 1, "dt": dt, "traj_len": L, "trajectories": ntraj,
-                       "accepted": naccept, "speculative_first_steps": eng.chain_stats(), "parallelism": ("1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step"
+                       "chains_per_gpu": CPG, "dt": dt, "traj_len": L, "trajectories": ntraj,
+                       "accepted": naccept, "speculative_first_steps": eng.chain_stats() if CPG == 1 else None, "parallelism": ("1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step"
                                        % (world, args.shard_backend)) if args.shard
                        else "chain-parallel x%d (no collective)" % world,
                        "device": info["name"], "cus": info["cus"],
@@ -286,6 +326,12 @@ def main():
                          "reference_formulation_equiv_GBps":
                              2 * bytes_sweep * args.steps / elapsed / 1e9},
         }
+        if CPG > 1:
+            line["roofline"].update({
+                "kernel": "batch_adjoint_kernel + batch_forward_kernel (v_mfma_f64_16x16x4, %d chains "
+                          "share each read of G; two sweeps per leapfrog step of the batch)" % CPG,
+                "fp64_matrix_TFLOPs": 4.0 * N * M * 16 * prof["sweeps"] / 2 / (prof["sweep_ms"] * 1e-3) / 1e12,
+                "reference_formulation_equiv_GBps": 2 * bytes_sweep * CPG * args.steps / elapsed / 1e9})
         if args.matrix_free:
             line["roofline"].update({"bound": "fp64 transcendental throughput (no stored G)",
                                      "achieved": None, "frac": None, "traffic": None,

@@ -54,6 +54,10 @@ PROTOTYPES = {
                                C.POINTER(C.c_int), _dp, _dp, C.POINTER(C.c_int)]),
     "gh_chain_get_x": (C.c_int, [_ctx, _dp]),
     "gh_chain_get_dsyn": (C.c_int, [_ctx, _dp]),
+    "gh_batch_init": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
+    "gh_batch_trajectory": (C.c_int, [_ctx, _dp, C.c_double, C.POINTER(C.c_int), _dp,
+                                      C.POINTER(C.c_int), _dp]),
+    "gh_batch_get_x": (C.c_int, [_ctx, C.c_int, _dp]),
     "gh_posterior_window": (C.c_int, [_ctx, C.c_int]),
     "gh_posterior_add": (C.c_int, [_ctx]),
     "gh_posterior_read": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), _dp, _dp]),

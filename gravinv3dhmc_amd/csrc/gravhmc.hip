@@ -2,6 +2,7 @@
 // One context = one GPU + one stream + one inversion problem resident in HBM.
 #include "../../include/gravhmc.h"
 #include "kernels.hip.h"
+#include "batch.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -116,6 +117,23 @@ struct gh_ctx {
         double *data = nullptr;
         double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
     } wv;
+
+    // several chains sharing every sweep of G (fp64 MFMA path, batch.hip.h)
+    struct Batch {
+        int C = 0;
+        double *Xc = nullptr, *Rtc = nullptr, *GREGc = nullptr, *Dc = nullptr;   // current states
+        double *Xw[2] = {nullptr, nullptr}, *Pw[2] = {nullptr, nullptr};
+        double *Rtw = nullptr, *GREGw = nullptr, *Dw = nullptr, *scal = nullptr;
+        double *slab = nullptr, *regpart = nullptr, *pp_part = nullptr, *pp0_part = nullptr;
+        double *stage = nullptr;  // C x M rows as the host passes them
+        double *Gb = nullptr;     // second copy of G in MFMA operand order (adjoint), if HBM allows
+        double *h = nullptr;      // pinned
+        int n_colblocks = 0, n_regblocks = 0, n_waves = 0, n_pp0 = 0;
+        int64_t cols_per_block = 0;
+        double U[CB][3];
+        bool ready = false;
+        int64_t sweeps = 0;
+    } bt;
 
     // ring of the last K accepted samples (posterior statistics without text I/O)
     double *ring = nullptr, *ring_mean = nullptr, *ring_sd = nullptr;
@@ -780,6 +798,7 @@ void gh_destroy(gh_ctx *c)
         if (api && api->CommDestroy) api->CommDestroy(c->sh.comm);
     }
     if (c->sh.hbuf) hipHostFree(c->sh.hbuf);
+    if (c->bt.h) hipHostFree(c->bt.h);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_scal) hipHostFree(c->h_scal);
     for (hipEvent_t ev : c->ev) hipEventDestroy(ev);
@@ -1558,6 +1577,290 @@ int gh_posterior_read(gh_ctx *c, int64_t *n_in_window, int64_t *n_total, double 
     if (mean) TRY(d2h(c, mean, c->ring_mean, (size_t)c->M));
     if (sd) TRY(d2h(c, sd, c->ring_sd, (size_t)c->M));
     return GH_OK;
+}
+
+// --------------------------------------------------------------- batched chains (MFMA)
+
+static int batch_alloc(gh_ctx *c)
+{
+    gh_ctx::Batch &b = c->bt;
+    const size_t M16 = (size_t)c->M * CB, L16 = (size_t)c->ld * CB;
+    if (b.Xc) return GH_OK;
+    TRY(dalloc(c, &b.Xc, M16));
+    TRY(dalloc(c, &b.Rtc, L16));
+    TRY(dalloc(c, &b.GREGc, M16));
+    TRY(dalloc(c, &b.Dc, L16));
+    for (int i = 0; i < 2; ++i) {
+        TRY(dalloc(c, &b.Xw[i], M16));
+        TRY(dalloc(c, &b.Pw[i], M16));
+    }
+    TRY(dalloc(c, &b.Rtw, L16));
+    TRY(dalloc(c, &b.GREGw, M16));
+    TRY(dalloc(c, &b.Dw, L16));
+    TRY(dalloc(c, &b.scal, CB * 4));
+    TRY(dalloc(c, &b.stage, M16));
+    // forward: 512-row blocks x column blocks, about 4 workgroups per CU in total
+    const int rowblocks = (int)((c->ld + 511) / 512);
+    int colblocks = std::max(1, (c->cus * 4 + rowblocks - 1) / rowblocks);
+    int64_t cpb = (c->M + colblocks - 1) / colblocks;
+    cpb = (cpb + 15) / 16 * 16;
+    b.cols_per_block = cpb;
+    b.n_colblocks = (int)((c->M + cpb - 1) / cpb);
+    TRY(dalloc(c, &b.slab, (size_t)b.n_colblocks * L16));
+    b.n_regblocks = (int)((c->M + 15) / 16);
+    TRY(dalloc(c, &b.regpart, (size_t)b.n_regblocks * CB));
+    const int64_t ntiles = (c->M + 15) / 16;
+    const int wgs = (int)std::min<int64_t>((ntiles + 3) / 4, (int64_t)c->cus * 4);
+    b.n_waves = wgs * 4;
+    TRY(dalloc(c, &b.pp_part, (size_t)b.n_waves * CB));
+    b.n_pp0 = (int)std::min<int64_t>(512, (c->M + 15) / 16);
+    TRY(dalloc(c, &b.pp0_part, (size_t)b.n_pp0 * CB));
+    HIPCHK(c, hipHostMalloc((void **)&b.h, sizeof(double) * (size_t)(CB * 4 + (b.n_waves + b.n_pp0) * CB)));
+    // the adjoint GEMM wants G in MFMA operand order; 288 GB of HBM usually has room for the
+    // second copy (C2: 40 GB + 40 GB).  Without it the kernel reads the column-major matrix.
+    if (env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)2 << 30)) {
+            void *ptr = nullptr;
+            if (hipMalloc(&ptr, need_b) == hipSuccess) {
+                c->allocs.push_back(ptr);
+                b.Gb = static_cast<double *>(ptr);
+                batch_relayout_kernel<<<dim3(1 << 16), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, (int)(c->ld / 16),
+                                                                                  ntiles, b.Gb);
+                HIPCHK(c, hipGetLastError());
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    TRY(dalloc(c, &c->tmpM, (size_t)c->M));
+    TRY(dalloc(c, &c->low, (size_t)c->M));
+    TRY(dalloc(c, &c->high, (size_t)c->M));
+    if (!c->mwapr) TRY(dalloc(c, &c->mwapr, (size_t)c->M));
+    if (!c->wm2) TRY(dalloc(c, &c->wm2, (size_t)c->M));
+    return GH_OK;
+}
+
+static int batch_time_begin(gh_ctx *c, bool &timed)
+{
+    timed = c->prof && c->ev_used + 2 <= c->ev.size();
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    return GH_OK;
+}
+
+static int batch_time_end(gh_ctx *c, bool timed)
+{
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
+    c->bt.sweeps += 1;
+    return GH_OK;
+}
+
+// forward of all chains at X, then regulariser and residuals into (D, GREG, Rt, scal)
+static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, double *Rt)
+{
+    gh_ctx::Batch &b = c->bt;
+    BatchFwdArgs f;
+    f.G = c->G;
+    f.ld = c->ld;
+    f.M = c->M;
+    f.N = c->N;
+    f.X = X;
+    f.cols_per_block = b.cols_per_block;
+    f.slab = b.slab;
+    bool timed;
+    TRY(batch_time_begin(c, timed));
+    batch_forward_kernel<<<dim3((unsigned)((c->ld + 511) / 512), (unsigned)b.n_colblocks), dim3(256), 0,
+                           c->stream>>>(f);
+    TRY(batch_time_end(c, timed));
+    const int64_t n16 = c->ld * CB;
+    batch_reduce_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.slab, b.n_colblocks,
+                                                                                        n16, D);
+    BatchRegArgs ra;
+    ra.kind = c->reg_kind;
+    ra.M = c->M;
+    ra.nz = c->shape[0];
+    ra.ny = c->shape[1];
+    ra.nx = c->shape[2];
+    ra.alpha = c->alpha;
+    ra.beta = c->beta;
+    ra.X = X;
+    ra.mwapr = c->mwapr;
+    ra.wm2 = c->wm2;
+    ra.GREG = GREG;
+    ra.regpart = b.regpart;
+    batch_reg_kernel<<<dim3((unsigned)b.n_regblocks), dim3(256), 0, c->stream>>>(ra);
+    BatchFinishArgs fa;
+    fa.N = c->N;
+    fa.ld = c->ld;
+    fa.n_regpart = b.n_regblocks;
+    fa.D = D;
+    fa.gfix = c->have_fix ? c->gfix : nullptr;
+    fa.dobs_c = c->dobs_c;
+    fa.regpart = b.regpart;
+    fa.alpha = c->alpha;
+    fa.Rt = Rt;
+    fa.scal = b.scal;
+    batch_finish_kernel<<<dim3(CB), dim3(1024), 0, c->stream>>>(fa);
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+static int batch_upload_rows(gh_ctx *c, const double *rows, int C, double *dst)
+{
+    gh_ctx::Batch &b = c->bt;
+    HIPCHK(c, hipMemcpyAsync(b.stage, rows, sizeof(double) * (size_t)C * (size_t)c->M, hipMemcpyHostToDevice,
+                             c->stream));
+    const int64_t n16 = c->M * CB;
+    batch_interleave_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.stage, C, c->M, dst);
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const double *high)
+{
+    if (!c || !x0s || !low || !high) return fail(c, GH_ERR_ARG, "gh_batch_init: null pointer");
+    if (C < 1 || C > CB) return fail(c, GH_ERR_ARG, "gh_batch_init: 1..16 chains per batch");
+    TRY(need(c, c->have_G && c->have_data && c->have_reg && !c->mf,
+             "gh_batch_init: needs the stored (dense) kernel matrix, gh_set_data and gh_set_reg"));
+    if (c->wv.on || c->sh.kind != 0)
+        return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the dense, unsharded kernel only");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(batch_alloc(c));
+    gh_ctx::Batch &b = c->bt;
+    b.C = C;
+    TRY(h2d(c, c->low, low, (size_t)c->M));
+    TRY(h2d(c, c->high, high, (size_t)c->M));
+    TRY(batch_upload_rows(c, x0s, C, b.Xc));
+    TRY(batch_evaluate(c, b.Xc, b.Dc, b.GREGc, b.Rtc));
+    TRY(d2h(c, b.h, b.scal, CB * 4));
+    for (int k = 0; k < CB; ++k) {
+        b.U[k][0] = b.h[4 * k + 2];
+        b.U[k][1] = b.h[4 * k + 0];
+        b.U[k][2] = b.h[4 * k + 1];
+    }
+    b.ready = true;
+    return GH_OK;
+}
+
+int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, const double *us, int *accepted,
+                        double *out5s)
+{
+    if (!c || !p0s || !L || !us || !accepted || !out5s) return fail(c, GH_ERR_ARG, "gh_batch_trajectory: null pointer");
+    gh_ctx::Batch &b = c->bt;
+    TRY(need(c, b.ready, "gh_batch_trajectory: call gh_batch_init first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    const int C = b.C;
+    int Lmax = 0;
+    for (int k = 0; k < C; ++k) {
+        if (L[k] < 1) return fail(c, GH_ERR_ARG, "gh_batch_trajectory: L must be >= 1");
+        Lmax = std::max(Lmax, L[k]);
+    }
+    const int64_t n16 = c->M * CB;
+    TRY(batch_upload_rows(c, p0s, C, b.Pw[0]));
+    batch_sumsq_kernel<<<dim3((unsigned)b.n_pp0), dim3(256), 0, c->stream>>>(b.Pw[0], c->M, b.pp0_part);
+    const double *X_in = b.Xc, *Rt_in = b.Rtc, *GREG_in = b.GREGc;
+    int pin = 0, xo = 0;
+    for (int s = 0; s <= Lmax; ++s) {
+        BatchAdjArgs a{};
+        a.Gb = b.Gb;
+        a.G = c->G;
+        a.ld = c->ld;
+        a.M = c->M;
+        a.np = (int)(c->ld / 16);
+        a.Rt = Rt_in;
+        a.GREG = GREG_in;
+        a.X_in = X_in;
+        a.P_in = b.Pw[pin];
+        a.X_out = b.Xw[xo];
+        a.P_out = b.Pw[pin ^ 1];
+        a.low = c->low;
+        a.high = c->high;
+        a.G_out = nullptr;
+        a.pp_part = b.pp_part;
+        a.dt = dt;
+        a.n_waves = b.n_waves;
+        bool any_upd = false;
+        for (int k = 0; k < CB; ++k) {
+            a.phase[k] = PH_IDLE;
+            a.cu[k] = (s == 0) ? dt * 0.5 : dt;
+            a.cp[k] = dt * 0.5;
+            if (k < C) {
+                if (s < L[k]) {
+                    a.phase[k] = PH_UPD;
+                    any_upd = true;
+                } else if (s == L[k]) {
+                    a.phase[k] = PH_PFIN;
+                }
+            }
+        }
+        bool timed;
+        TRY(batch_time_begin(c, timed));
+        batch_adjoint_kernel<<<dim3((unsigned)(b.n_waves / 4)), dim3(256), 0, c->stream>>>(a);
+        TRY(batch_time_end(c, timed));
+        HIPCHK(c, hipGetLastError());
+        if (any_upd) TRY(batch_evaluate(c, b.Xw[xo], b.Dw, b.GREGw, b.Rtw));
+        X_in = b.Xw[xo];
+        Rt_in = b.Rtw;
+        GREG_in = b.GREGw;
+        pin ^= 1;
+        xo ^= 1;
+    }
+    double *h = b.h;
+    HIPCHK(c, hipMemcpyAsync(h, b.scal, sizeof(double) * CB * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + CB * 4, b.pp_part, sizeof(double) * (size_t)b.n_waves * CB, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipMemcpyAsync(h + CB * 4 + (size_t)b.n_waves * CB, b.pp0_part, sizeof(double) * (size_t)b.n_pp0 * CB,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned mask = 0;
+    for (int k = 0; k < C; ++k) {
+        double pp1 = 0.0, pp0 = 0.0;
+        for (int w = 0; w < b.n_waves; ++w) pp1 += h[CB * 4 + (size_t)w * CB + k];
+        for (int w = 0; w < b.n_pp0; ++w) pp0 += h[CB * 4 + (size_t)(b.n_waves + w) * CB + k];
+        const double Unew[3] = {h[4 * k + 2], h[4 * k + 0], h[4 * k + 1]};
+        const double Hcur = 0.5 * pp0 + b.U[k][0];
+        const double Hnew = 0.5 * pp1 + Unew[0];
+        const bool acc = (Hnew < Hcur) || (us[k] < std::exp(-(Hnew - Hcur)));
+        if (acc) {
+            mask |= 1u << k;
+            b.U[k][0] = Unew[0];
+            b.U[k][1] = Unew[1];
+            b.U[k][2] = Unew[2];
+        }
+        accepted[k] = acc ? 1 : 0;
+        out5s[5 * k + 0] = b.U[k][0];
+        out5s[5 * k + 1] = b.U[k][1];
+        out5s[5 * k + 2] = b.U[k][2];
+        out5s[5 * k + 3] = Hcur;
+        out5s[5 * k + 4] = Hnew;
+    }
+    if (mask) {
+        const int64_t l16 = c->ld * CB;
+        batch_commit_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(X_in, b.Xc, n16, mask);
+        batch_commit_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.GREGw, b.GREGc, n16,
+                                                                                            mask);
+        batch_commit_kernel<<<dim3((unsigned)((l16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.Dw, b.Dc, l16, mask);
+        batch_commit_rt_kernel<<<dim3((unsigned)((l16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.Rtw, b.Rtc, l16,
+                                                                                               mask);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return GH_OK;
+}
+
+int gh_batch_get_x(gh_ctx *c, int chain, double *x)
+{
+    if (!c || !x) return fail(c, GH_ERR_ARG, "gh_batch_get_x: null pointer");
+    TRY(need(c, c->bt.ready && chain >= 0 && chain < c->bt.C, "gh_batch_get_x: no such chain"));
+    HIPCHK(c, hipSetDevice(c->device));
+    batch_extract_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(c->bt.Xc, chain, c->M,
+                                                                                           c->tmpM);
+    HIPCHK(c, hipGetLastError());
+    return d2h(c, x, c->tmpM, (size_t)c->M);
 }
 
 int gh_leapfrog(gh_ctx *c, double *x_inout, const double *p0, double dt, int L, const double *low,

@@ -294,6 +294,31 @@ class Engine(object):
         self._chk(self._lib.gh_chain_get_dsyn(self._h, ptr(d)))
         return d
 
+    # -- several chains per GPU (MFMA) ----------------------------------------------
+    def batch_init(self, x0s, low, high):
+        x0s = np.ascontiguousarray(np.atleast_2d(x0s), dtype=np.float64)
+        self._batch_C = x0s.shape[0]
+        low, high = f64(low), f64(high)
+        self._chk(self._lib.gh_batch_init(self._h, self._batch_C, ptr(x0s), ptr(low), ptr(high)))
+
+    def batch_trajectory(self, p0s, dt, Ls, us):
+        Cn = self._batch_C
+        p0s = np.ascontiguousarray(np.atleast_2d(p0s), dtype=np.float64)
+        if p0s.shape != (Cn, self.M):
+            raise ValueError("p0s must be (C, M)")
+        Ls_ = (C.c_int * Cn)(*[int(v) for v in Ls])
+        us_ = np.ascontiguousarray(us, dtype=np.float64)
+        acc = (C.c_int * Cn)()
+        out5 = np.empty((Cn, 5))
+        self._chk(self._lib.gh_batch_trajectory(self._h, ptr(p0s), float(dt), Ls_, ptr(us_), acc,
+                                                ptr(out5)))
+        return [bool(a) for a in acc], out5
+
+    def batch_get_x(self, chain):
+        x = np.empty(self.M)
+        self._chk(self._lib.gh_batch_get_x(self._h, int(chain), ptr(x)))
+        return x
+
     # -- posterior window ---------------------------------------------------------
     def posterior_window(self, K=100):
         self._chk(self._lib.gh_posterior_window(self._h, int(K)))

@@ -167,6 +167,20 @@ int gh_chain_run(gh_ctx *ctx, int K, const int *L, const double *p0s, const doub
 int gh_chain_stats(gh_ctx *ctx, int64_t *spec_hits, int64_t *spec_misses);
 int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
 int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state */);
+/* ---- several chains sharing every sweep of G (fp64 MFMA) ---------------------------------- */
+
+/* Up to 16 independent chains (the reference runs them as separate MPI ranks, hmc.py:367-369) on
+ * ONE GPU against ONE copy of G: per leapfrog step the adjoint and the forward products of all
+ * chains are two skinny GEMMs on v_mfma_f64_16x16x4 (32 flop per byte of G instead of 0.5), so 16
+ * chains cost two sweeps of G per step instead of 16.  Each chain keeps its own trajectory
+ * length L[c] (chains that finish early idle until the longest is done) and its own Metropolis
+ * variate; every chain reproduces what a single-chain context computes from the same inputs.
+ * Host arrays are chain-major: x0s, p0s = C rows of M doubles.  Dense, unsharded kernel only. */
+int gh_batch_init(gh_ctx *ctx, int C, const double *x0s, const double *low, const double *high);
+int gh_batch_trajectory(gh_ctx *ctx, const double *p0s, double dt, const int *L, const double *us,
+                        int *accepted /* C */, double *out5s /* C x 5, as gh_chain_trajectory */);
+int gh_batch_get_x(gh_ctx *ctx, int chain, double *x /* M */);
+
 /* Posterior statistics without text I/O.  The reference appends every accepted
  * model as a '%.8f' text row to model.dat (hmc.py:328-332) and its plot scripts take np.mean /
  * np.std over the last 100 rows (plot_uniform.py:44-55,103-104).  gh_posterior_window reserves a

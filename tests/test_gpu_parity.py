@@ -785,3 +785,64 @@ def test_posterior_window_and_sample_sinks(G, orc, tmp_path, capsys):
     d_mean = Aw @ (gm.Wm.diagonal() * st["mean"])
     assert abs(sm["RMSD"] - np.sqrt(np.linalg.norm(p["dobs"] - d_mean) ** 2 / 42)) < 1e-12
     assert abs(sm["RMSM"] - np.sqrt(np.linalg.norm(rho_true - st["mean"]) ** 2 / M)) < 1e-15
+
+
+# --------------------------------------------------------- several chains per GPU (fp64 MFMA)
+
+@pytest.mark.parametrize("case", ["small_tv", "random_ms", "random_damping_big"])
+def test_batched_chains_match_single_chain_engines(G, case):
+    """gh_batch_*: up to 16 chains share every sweep of G through v_mfma_f64_16x16x4; every chain
+    must reproduce a single-chain context fed the same momenta / lengths / variates
+    (<= 1e-10: the MFMA contracts rows in another order than the wave reduction)."""
+    rng = np.random.default_rng(11)
+    if case == "small_tv":
+        p = gold("potential_small.npz")
+        A, dobs, shape, reg, beta = np.asarray(p["Aw"]) * p["wm"][None, :], p["dobs"], p["shape"], "TV", 0.001
+        C, dt, sig, hi, ntraj = 5, 0.02, 0.3, 0.02, 6
+    elif case == "random_ms":
+        N, M = 1000, 700
+        A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.1, 3, size=M))
+        dobs, shape, reg, beta = rng.normal(size=N) * 5, (7, 10, 10), "MS", 0.01
+        C, dt, sig, hi, ntraj = 16, 0.01, 0.05, 0.3, 3
+    else:
+        N, M = 5003, 1234
+        A = np.asfortranarray(rng.normal(size=(N, M)))
+        dobs, shape, reg, beta = rng.normal(size=N) * 20, (1, 1, M), "Damping", 0.01
+        C, dt, sig, hi, ntraj = 3, 0.004, 0.02, 0.5, 2
+    N, M = A.shape
+
+    def make():
+        e = G.Engine(N, M)
+        e.upload_G(A)
+        w = e.weight(0.5)
+        e.set_data(dobs)
+        e.set_reg(reg, 1.0, beta, shape, 0.001 * w)
+        return e, w
+
+    eb, wm = make()
+    low, high = 0.0 * wm, hi * wm
+    x0s = np.stack([(0.001 + 0.002 * c) * wm for c in range(C)])
+    eb.batch_init(x0s, low, high)
+    singles = []
+    for c in range(C):
+        e, _ = make()
+        e.chain_init(x0s[c], low, high)
+        singles.append(e)
+    n_acc = n_rej = 0
+    for it in range(ntraj):
+        Ls = rng.integers(1, 9, size=C)
+        p0s = rng.normal(size=(C, M)) * sig
+        us = rng.uniform(size=C)
+        acc, out5 = eb.batch_trajectory(p0s, dt, Ls, us)
+        for c in range(C):
+            a1, o1 = singles[c].chain_trajectory(p0s[c], dt, int(Ls[c]), float(us[c]))
+            assert a1 == acc[c], (case, it, c, o1, out5[c])
+            assert relmax(out5[c], o1) < 1e-10, (case, it, c, out5[c], o1)
+            assert relmax(eb.batch_get_x(c), singles[c].chain_get_x()) < 1e-10
+            n_acc += a1
+            n_rej += not a1
+    assert n_acc > 0
+    if case == "small_tv":
+        assert n_rej > 0
+    for e in singles + [eb]:
+        e.close()
