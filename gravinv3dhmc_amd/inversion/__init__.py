@@ -1,3 +1,3 @@
 """Potential (GravMagModule) and sampler (HamitonianMC, HMCSample)."""
-from .hmc import HamitonianMC, HMCSample  # noqa: F401
+from .hmc import HamitonianMC, HMCSample, HMCSampleBatch  # noqa: F401
 from .potential import GravMagModule  # noqa: F401

@@ -271,3 +271,75 @@ def HMCSample(model, nsamples, ndraws, delta, Lrange,
     chain.posterior_last = posterior_last
     chain.sample(nsamples, ndraws)
     return chain
+
+
+def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
+                   initial_model, aprior_model, boundaries, constraint, log_factor, dobs,
+                   adaptiveRegul, RegulRate, RegulFactor, regularization, beta,
+                   seed, Sigma, nbest=100, first_rank=0, save_folder="mychain", sample_sink="text"):
+    """`n_chains` (<= 16) independent chains on ONE GPU against ONE copy of the kernel matrix.
+
+    The reference runs K chains as K MPI ranks, each rebuilding its own G (run_main.sh:17,
+    hmc.py:367-369).  Here chain c is the chain the reference's rank first_rank + c would run --
+    its own legacy RandomState(seed + rank) drawn in the reference's order (L, momentum,
+    Metropolis variate), its own folder save_folder + str(rank), the same console lines -- but
+    every leapfrog step of all chains shares two sweeps of G on the fp64 MFMA path
+    (gh_batch_trajectory).  Chains that reach ndraws + nsamples accepted samples keep running
+    (unrecorded) until the slowest one is done.  'mandatory' constraint only."""
+    if constraint != 'mandatory':
+        raise ValueError("HMCSampleBatch supports the 'mandatory' boundary constraint only")
+    eng = model._engine
+    _, WmInv, Wm = model.kernelw()
+    low, high = Wm @ boundaries[:, 0], Wm @ boundaries[:, 1]
+    mw0, mwapr = Wm @ initial_model, Wm @ aprior_model
+    model._use_reg(regularization, RegulFactor, beta, mwapr)
+    M, N = mw0.shape[0], np.asarray(dobs).shape[0]
+    ranks = [first_rank + c for c in range(n_chains)]
+    rs = [np.random.RandomState(seed + r) for r in ranks]
+    folders = [save_folder + str(r) for r in ranks]
+    for f in folders:
+        os.makedirs(f, exist_ok=True)
+        for name in ("model.dat", "model.bin"):
+            if os.path.exists(f + "/" + name):
+                os.remove(f + "/" + name)
+    print("initial mw:", mw0)
+    print("mw boundaryies:", high, low)
+    print("Using mandatory boundary constraint.")
+    eng.batch_init(np.stack([mw0] * n_chains), low, high)
+    alpha = RegulFactor
+    acc_n = [0] * n_chains
+    tot_n = [0] * n_chains
+    target = ndraws + nsamples
+    while min(acc_n) < target:
+        Ls, p0s, us = [], [], []
+        for r in rs:
+            Ls.append(r.randint(Lrange[0], Lrange[1] + 1))
+            p0s.append(r.randn(M) * Sigma)
+            us.append(r.rand())
+        accepted, out5 = eng.batch_trajectory(np.stack(p0s), delta, Ls, us)
+        for c in range(n_chains):
+            if acc_n[c] >= target:
+                continue
+            U, U_data, U_model = out5[c][0], out5[c][1], out5[c][2]
+            Udn, Umn = U_data / N, U_model / M
+            Un = Udn + alpha * Umn
+            if accepted[c]:
+                if acc_n[c] >= ndraws:
+                    with open(folders[c] + "/misfit.dat", "a") as f:
+                        np.savetxt(f, np.array([[U, U_data, U_model, Un, Udn, Umn, alpha]]), fmt='%.8f',
+                                   delimiter=' ')
+                    if sample_sink != "none":
+                        m = WmInv @ eng.batch_get_x(c)
+                        if sample_sink == "text":
+                            with open(folders[c] + "/model.dat", "a") as f:
+                                np.savetxt(f, m[None, :], fmt='%.8f', delimiter=' ')
+                        else:
+                            with open(folders[c] + "/model.bin", "ab") as f:
+                                np.ascontiguousarray(m).tofile(f)
+                acc_n[c] += 1
+            tot_n[c] += 1
+            print("chain {}: {:.2%}, misfit(total, data, alpha, model)=({:.7f},{:.7f},{:.2f},{:.7f}) "
+                  "-- accept ratio {:.2%}\n".format(ranks[c], acc_n[c] / target, Un, Udn, alpha, Umn,
+                                                    acc_n[c] / tot_n[c]))
+        sys.stdout.flush()
+    return acc_n, tot_n

@@ -846,3 +846,36 @@ def test_batched_chains_match_single_chain_engines(G, case):
         assert n_rej > 0
     for e in singles + [eb]:
         e.close()
+
+
+def test_hmcsample_batch_reproduces_reference_chains(G, tmp_path, capsys):
+    """HMCSampleBatch: chains 0..2 of one MFMA batch; chain 0 must print the reference's own
+    chain-0 lines (chain_small fixtures), every chain must equal a separate HMCSample(myrank=r)."""
+    c = gold("chain_small.npz")
+    p = gold("potential_small.npz")
+    M = p["wm"].size
+    for tag in ("a", "b"):
+        dt, Sigma, lo, hi, n = c[tag + "_cfg"]
+        reg = str(c[tag + "_reg"])
+        args = (np.full(M, 0.001 + lo), np.full(M, 0.001), np.c_[np.full(M, lo), np.full(M, hi)],
+                "mandatory", 1000, p["dobs"], "Fixed", 0.8, 1.0, reg, 0.001, 100, float(Sigma))
+        gm = _module_small(G, p)
+        capsys.readouterr()
+        G.HMCSampleBatch(gm, 3, int(n), 0, float(dt), [5, 20], *args,
+                         save_folder=str(tmp_path / ("batch_%s_chain" % tag)))
+        out = capsys.readouterr().out.splitlines()
+        ref0 = [str(s) for s in c[tag + "_lines"]]
+        got0 = [l for l in out if l.startswith("chain 0:")]
+        assert got0 == ref0
+        for r in (1, 2):
+            gs = _module_small(G, p)
+            capsys.readouterr()
+            G.HMCSample(gs, int(n), 0, float(dt), [5, 20], *args, myrank=r,
+                        save_folder=str(tmp_path / ("single_%s_chain" % tag)))
+            single = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain %d:" % r)]
+            assert [l for l in out if l.startswith("chain %d:" % r)] == single
+            a = np.loadtxt(str(tmp_path / ("batch_%s_chain%d" % (tag, r))) + "/model.dat")
+            b = np.loadtxt(str(tmp_path / ("single_%s_chain%d" % (tag, r))) + "/model.dat")
+            np.testing.assert_allclose(a, b, atol=2e-8)
+        np.testing.assert_allclose(np.loadtxt(str(tmp_path / ("batch_%s_chain0" % tag)) + "/model.dat"),
+                                   c[tag + "_model"], atol=2e-8)
