@@ -48,8 +48,12 @@ struct gh_ctx {
 
     // sweep configuration
     int TW = 0, EPT2 = 0, PF = 1;
+    int n_panels = 1;        // row panels of the dense sweep (N > 16384 rows: > 1, two reads of G per step)
+    int64_t panel_rows = 0;
+    double *gbuf = nullptr;   // gradient accumulated over the panels
     bool NT = false;
     int n_teams = 0, grid = 0;
+    int n_teams_sweep = 0;   // teams of the sweep launch (n_teams may be larger: size of the pp partials)
     int64_t cols_per_team = 0;
     size_t lds_bytes = 0;
 
@@ -270,21 +274,21 @@ static int configure_sweep(gh_ctx *c)
 {
     const int64_t ld = c->ld;
     int tw, per;  // rows one unit of EPT2 covers = tw*64*2
+    c->n_panels = 1;
+    c->panel_rows = ld;
     if (ld <= 1024) tw = 1;
     else if (ld <= 4096) tw = 4;
     else if (ld <= 16384) tw = 16;
     else {
-        // too many rows for the register-resident dense sweep: only the matrix-free path works
-        c->dense_ok = false;
-        c->TW = 16;
-        c->EPT2 = 8;
-        c->n_teams = 1;
-        c->grid = 1;
-        c->cols_per_team = c->M;
-        return GH_OK;
+        // more rows than a team can hold in registers: row panels of <= 16384 rows.  The dot
+        // product of a column then spans several launches, so the adjoint and the forward can no
+        // longer share one read of G (two reads per step, like the reference's formulation).
+        tw = 16;
+        c->n_panels = (int)((ld + 16383) / 16384);
+        c->panel_rows = ((ld + c->n_panels - 1) / c->n_panels + 15) / 16 * 16;
     }
     per = tw * 128;
-    int e = (int)((ld + per - 1) / per);
+    int e = (int)((c->panel_rows + per - 1) / per);
     if (e == 7) e = 8;
     c->TW = tw;
     c->EPT2 = e;
@@ -302,8 +306,10 @@ static int configure_sweep(gh_ctx *c)
     if (cpt < min_cols) cpt = min_cols;
     c->cols_per_team = cpt;
     c->n_teams = (int)((c->M + cpt - 1) / cpt);
+    c->n_teams_sweep = c->n_teams;
     c->grid = (c->n_teams + wg_teams - 1) / wg_teams;
-    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : ld + 2 * (tw + 8)) * sizeof(double);
+    if (c->n_panels > 1) c->n_teams = std::max(c->n_teams, (int)((c->M + 255) / 256));  // vec_update partials
+    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : c->panel_rows + 2 * (tw + 8)) * sizeof(double);
     if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
     sweep_fn f = sweep_for(c);
     if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
@@ -358,14 +364,13 @@ static int launch_mf(gh_ctx *c, SweepArgs &a)
     return GH_OK;
 }
 
-static int launch_sweep(gh_ctx *c, SweepArgs &a)
+static int launch_sweep_one(gh_ctx *c, SweepArgs &a)
 {
-    if (c->mf) return launch_mf(c, a);
     a.G = c->G;
     a.ld = c->ld;
     a.M = c->M;
     a.cols_per_team = c->cols_per_team;
-    a.n_teams = c->n_teams;
+    a.n_teams = c->n_teams_sweep;
     const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
     sweep_fn f = sweep_for(c);
     // short sweeps: an event pair costs about as much as the kernel, time every 16th launch only
@@ -381,7 +386,45 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
     return GH_OK;
 }
 
-
+static int launch_sweep(gh_ctx *c, SweepArgs &a)
+{
+    if (c->mf) return launch_mf(c, a);
+    if (c->n_panels == 1) {
+        a.row0 = 0;
+        a.rows = c->ld;
+        return launch_sweep_one(c, a);
+    }
+    // row panels: adjoint of every panel into gbuf, elementwise update, forward of every panel
+    const SweepArgs full = a;
+    if (full.mode & SW_ADJ) {
+        double *gdst = (full.mode & SW_GOUT) ? full.g_out : c->gbuf;
+        for (int p = 0; p < c->n_panels; ++p) {
+            SweepArgs s = full;
+            s.mode = SW_ADJ | SW_GOUT | (p ? SW_GACC : 0);
+            s.greg = p ? nullptr : full.greg;
+            s.g_out = gdst;
+            s.row0 = (int64_t)p * c->panel_rows;
+            s.rows = std::min<int64_t>(c->panel_rows, c->ld - s.row0);
+            TRY(launch_sweep_one(c, s));
+        }
+        if (full.mode & (SW_UPD | SW_PFIN)) {
+            SweepArgs u = full;
+            vec_update_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(u, gdst, c->M);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    if (full.mode & SW_FWD) {
+        for (int p = 0; p < c->n_panels; ++p) {
+            SweepArgs s = full;
+            s.mode = SW_FWD;
+            s.x_in = (full.mode & SW_UPD) ? full.x_out : full.x_in;
+            s.row0 = (int64_t)p * c->panel_rows;
+            s.rows = std::min<int64_t>(c->panel_rows, c->ld - s.row0);
+            TRY(launch_sweep_one(c, s));
+        }
+    }
+    return GH_OK;
+}
 
 // ------------------------------------------------------------------ collective layer
 
@@ -710,6 +753,7 @@ static int ensure_work(gh_ctx *c)
     TRY(dalloc(c, &c->pb[0], M));
     TRY(dalloc(c, &c->pb[1], M));
     TRY(dalloc(c, &c->pn, M));
+    if (c->n_panels > 1) TRY(dalloc(c, &c->gbuf, M));
     TRY(dalloc(c, &c->slab, (size_t)c->grid * ld));
     if (c->grid > 64) {
         c->slab2_rows = 16;
@@ -1009,11 +1053,15 @@ int gh_weight(gh_ctx *c, double weightfactor, double *wm_out)
     if (c->mf) {
         mf_colnorm_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(mf_geom(c), weightfactor,
                                                                                         c->wm);
+    } else if (c->n_panels > 1) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(c->M, (int64_t)c->cus * 16);
+        colnorm_kernel<<<dim3(blocks), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, weightfactor, c->wm);
+        colscale_kernel<<<dim3(blocks), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, c->wm);
     } else {
         weight_fn f = weight_for(c);
         const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
         hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), 0, c->stream, c->G, c->ld, c->M,
-                           c->cols_per_team, c->n_teams, weightfactor, c->wm);
+                           c->cols_per_team, c->n_teams_sweep, weightfactor, c->wm);
     }
     HIPCHK(c, hipGetLastError());
     std::vector<double> w((size_t)c->M);

@@ -52,13 +52,15 @@ enum : int {
     SW_FWD = 4,   // accumulate G_j * x_j into the team's forward partial
     SW_PFIN = 8,  // final half-step momentum update + sum of p^2 (needs SW_ADJ)
     SW_GOUT = 16, // write the gradient 2*dot + greg to g_out (needs SW_ADJ)
+    SW_GACC = 64, // with SW_GOUT: add 2*dot to g_out instead of overwriting it (row panels)
     SW_SPEC = 32  // with SW_PFIN|SW_UPD|SW_FWD: the update part is the FIRST step of the next
                   // trajectory, taken speculatively from its freshly drawn momentum pn_in
 };
 
 struct SweepArgs {
     const double *G;
-    int64_t ld;
+    int64_t ld;           // leading dimension of G and row stride of the slab
+    int64_t row0, rows;   // row panel handled by this launch (rows: multiple of 16, <= capacity)
     int64_t M;
     int64_t cols_per_team;
     int n_teams;
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     // LDS: [0, ld) r ; then TW==1: 4 x ld scratch for the cross-wave forward reduce,
     //      TW>1: 2 x (TW + 8) doubles: ping-pong slots of the dot reduction + column scalars.
     double *r_s = smem;
-    double *scratch = smem + a.ld;
+    double *scratch = smem + a.rows;
     constexpr int SLOT = TW + 8;
 
     const int tid = threadIdx.x;
@@ -110,11 +112,11 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     const int ttid = (TW == 1) ? lane : tid;  // thread index inside the team
     const int team = blockIdx.x * WG_TEAMS + ((TW == 1) ? wave : 0);
     const int64_t ld = a.ld;
-    const int ld2 = (int)(ld >> 1);  // in double2 units
+    const int ld2 = (int)(a.rows >> 1);  // rows of this panel in double2 units
     const int mode = a.mode;
 
     if (mode & SW_ADJ) {
-        const d2 *r2 = reinterpret_cast<const d2 *>(a.r);
+        const d2 *r2 = reinterpret_cast<const d2 *>(a.r + a.row0);
         d2 *rs2 = reinterpret_cast<d2 *>(r_s);
         for (int e = tid; e < ld2; e += blockDim.x) rs2[e] = r2[e];
     }
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     double pp = 0.0;
 
     auto load_col = [&](ColRegs<EPT2> &c, int64_t j) {
-        const d2 *col = reinterpret_cast<const d2 *>(a.G + j * ld);
+        const d2 *col = reinterpret_cast<const d2 *>(a.G + j * ld + a.row0);
 #pragma unroll
         for (int k = 0; k < EPT2; ++k) {
             const int e = k * TEAM_THREADS + ttid;
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
             }
             xj = cx;
             const double g = 2.0 * s + cgr;
-            if ((mode & SW_GOUT) && ttid == 0) a.g_out[j] = g;
+            if ((mode & SW_GOUT) && ttid == 0) a.g_out[j] = (mode & SW_GACC) ? a.g_out[j] + g : g;
             if (mode & SW_PFIN) {
                 const double pf = cp - a.c_p * g;
                 pp += pf * pf;
@@ -270,13 +272,13 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
                 if (e < ld2) sc2[wave * ld2 + e] = dacc[k];
             }
             __syncthreads();
-            d2 *out = reinterpret_cast<d2 *>(a.slab + (int64_t)blockIdx.x * ld);
+            d2 *out = reinterpret_cast<d2 *>(a.slab + (int64_t)blockIdx.x * ld + a.row0);
             for (int e = tid; e < ld2; e += blockDim.x) {
                 const d2 s0 = sc2[e], s1 = sc2[ld2 + e], s2 = sc2[2 * ld2 + e], s3 = sc2[3 * ld2 + e];
                 out[e] = ((s0 + s1) + s2) + s3;
             }
         } else {
-            d2 *out = reinterpret_cast<d2 *>(a.slab + (int64_t)blockIdx.x * ld);
+            d2 *out = reinterpret_cast<d2 *>(a.slab + (int64_t)blockIdx.x * ld + a.row0);
 #pragma unroll
             for (int k = 0; k < EPT2; ++k) {
                 const int e = k * TEAM_THREADS + ttid;
@@ -452,6 +454,78 @@ __global__ void __launch_bounds__(1024) sum_kernel(const double *part, int n, do
     if (threadIdx.x == 0) {
         out[0] = tot;
         out[1] = 0.0;
+    }
+}
+
+// Leapfrog update from a ready gradient g (row-panel path for N > 16384: the adjoint of all
+// panels is accumulated first, then this elementwise pass does what sweep_kernel does per column).
+__global__ void __launch_bounds__(256) vec_update_kernel(SweepArgs a, const double *g, int64_t M)
+{
+    __shared__ double red[4];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int mode = a.mode;
+    double pp = 0.0;
+    if (j < M) {
+        const double grad = g[j];
+        if (mode & SW_PFIN) {
+            const double pf = a.p_in[j] - a.c_p * grad;
+            pp = pf * pf;
+            if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+        }
+        if (mode & SW_UPD) {
+            const double psrc = (mode & SW_SPEC) ? a.pn_in[j] : a.p_in[j];
+            double pj = psrc - a.c_u * grad;
+            double xj = a.x_in[j] + a.dt * pj;
+            const double hi = a.high[j], lo = a.low[j];
+            if (xj > hi) {
+                xj = hi;
+                pj = -pj;
+            } else if (xj < lo) {
+                xj = lo;
+                pj = -pj;
+            }
+            a.p_out[j] = pj;
+            a.x_out[j] = xj;
+        }
+    }
+    if (mode & SW_PFIN) {
+        const double t = block_allreduce_sum(pp, red, 4);
+        if (threadIdx.x == 0) a.pp_part[blockIdx.x] = t;
+    }
+}
+
+// column norms / scaling without keeping a column in registers (any N): one workgroup per column
+__global__ void __launch_bounds__(256)
+colnorm_kernel(const double *G, int64_t ld, int64_t M, double wf, double *wm)
+{
+    __shared__ double red[4];
+    for (int64_t j = blockIdx.x; j < M; j += gridDim.x) {
+        const d2 *col = reinterpret_cast<const d2 *>(G + j * ld);
+        double s = 0.0;
+        for (int64_t e = threadIdx.x; e < (ld >> 1); e += 256) {
+            const d2 v = col[e];
+            s += v.x * v.x;
+            s += v.y * v.y;
+        }
+        const double t = block_allreduce_sum(s, red, 4);
+        if (threadIdx.x == 0) wm[j] = (wf == 0.5) ? sqrt(t) : pow(t, wf);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+colscale_kernel(double *G, int64_t ld, int64_t M, const double *wm)
+{
+    for (int64_t j = blockIdx.x; j < M; j += gridDim.x) {
+        const double w = wm[j];
+        if (w == 0.0) continue;
+        const double inv = 1.0 / w;
+        d2 *col = reinterpret_cast<d2 *>(G + j * ld);
+        for (int64_t e = threadIdx.x; e < (ld >> 1); e += 256) {
+            d2 v = col[e];
+            v.x *= inv;
+            v.y *= inv;
+            col[e] = v;
+        }
     }
 }
 

@@ -105,7 +105,7 @@ def test_tesseroid_frontend_warns_and_matches(G):
 
 @pytest.mark.parametrize("N,M", [(1, 1), (17, 5), (42, 120), (600, 257), (625, 1000), (1024, 64),
                                  (1025, 300), (2500, 123), (4097, 77), (7381, 300), (10000, 513),
-                                 (16384, 40)])
+                                 (16384, 40), (16385, 21), (20000, 77), (40000, 33)])
 def test_forward_adjoint_vs_numpy(G, N, M):
     rng = np.random.default_rng(N * 1000 + M)
     A = np.asfortranarray(rng.normal(size=(N, M)))
@@ -196,10 +196,8 @@ def test_error_behaviour(G):
     with pytest.raises(ValueError):
         eng.chain_trajectory(np.zeros(eng.M), 0.01, 5, 0.5)   # chain before chain_init
     eng.close()
-    big = G.Engine(20000, 10)                            # > 16384 rows: matrix-free only
-    with pytest.raises(NotImplementedError):
-        big.upload_G(np.zeros((20000, 10)))
-    big.close()
+    with pytest.raises(ValueError):
+        G.Engine(10, 10).upload_G(np.zeros((9, 10)))     # wrong shape
     with pytest.raises(ValueError):
         G.Engine(0, 10)
 
@@ -879,3 +877,36 @@ def test_hmcsample_batch_reproduces_reference_chains(G, tmp_path, capsys):
             np.testing.assert_allclose(a, b, atol=2e-8)
         np.testing.assert_allclose(np.loadtxt(str(tmp_path / ("batch_%s_chain0" % tag)) + "/model.dat"),
                                    c[tag + "_model"], atol=2e-8)
+
+
+def test_row_panels_chain_matches_oracle(G, orc):
+    """N > 16384 observations: the dense sweep runs in row panels (adjoint of all panels, update,
+    forward of all panels); potential, gradient and trajectories against the CPU oracle."""
+    rng = np.random.default_rng(8)
+    N, M = 17011, 150
+    A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.2, 2, size=M))
+    dobs = rng.normal(size=N) * 3
+    eng = G.Engine(N, M)
+    eng.upload_G(A)
+    wm = eng.weight(0.5)
+    Aw, wmo = orc.col_weight(A)
+    assert relmax(wm, wmo) < 1e-13 and relmax(eng.download_G(), Aw) < 1e-13
+    eng.set_data(dobs)
+    for reg, shape in (("MS", (1, 1, M)), ("TV", (5, 5, 6))):
+        eng.set_reg(reg, 0.7, 0.01, shape, 0.001 * wm)
+        P = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.7, 0.01, wm=wm, shape=shape)
+        x = rng.uniform(0, 1, M) * wm
+        a, b = eng.misfit_and_grad(x), P.misfit_and_grad(x)
+        assert abs(a[0] - b[0]) < 1e-11 * abs(b[0]) and relmax(a[1], b[1]) < 1e-11 and relmax(a[2], b[2]) < 1e-11
+        low, high = 0.0 * wm, 0.3 * wm
+        xg = xo = 0.001 * wm
+        eng.chain_init(xg, low, high)
+        trajs = [(int(rng.integers(1, 7)), rng.normal(size=M) * 0.02, float(rng.uniform())) for _ in range(5)]
+        res = []
+        eng.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res.append((acc, o.copy(), xs)), want_x=True)
+        for (L, p0, u), (acc, o, xs) in zip(trajs, res):
+            xo, acco, oo, _ = P.leapfrog(xo, p0, 0.002, L, low, high, u)
+            assert acc == acco and relmax(o, oo) < 1e-9
+            if acc:
+                assert relmax(xs, xo) < 1e-9
+    eng.close()
