@@ -72,6 +72,9 @@ EXTRA = {
     # C4: global 3 deg tesseroid mesh, 121 x 61 obs at 5000 m, Damping 0.05, bounds [0, 0.8]
     "c4_global_tesseroid": dict(kind=1, reg="Damping", alpha=0.05, beta=0.01, dt=0.005, hi=0.8,
                                 wavelet=0),
+    # C5: 200 x 200 x 60 prisms (M = 2.4e6), 200 x 200 obs (N = 4e4): G = 768 GB, one chain sharded
+    # over 8 GPUs (--shard).  On one GPU use --cells-fraction 8: the 96 GB share one rank holds.
+    "c5_uniform_200x200x60": dict(kind=0, reg="MS", alpha=1.0, beta=0.001, dt=0.001, hi=1.0, wavelet=0),
 }
 
 
@@ -84,6 +87,12 @@ def make_extra(name):
         obs = (xp, yp, np.zeros_like(xp))
         rho = np.zeros(mesh.shape)
         rho[2:5, 10:18, 7:11] = 1.0
+    elif name == "c5_uniform_200x200x60":
+        mesh = mesher.PrismMesh((0, 20000, 0, 20000, 0, 6000), (100, 100, 100))
+        yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 20000, 200), np.linspace(0, 20000, 200))]
+        obs = (xp, yp, np.zeros_like(xp))
+        rho = np.zeros(mesh.shape)
+        rho[10:30, 80:120, 80:120] = 1.0
     else:
         mesh = mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))
         lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 3.0), np.arange(-90, 91, 3.0),
@@ -148,6 +157,9 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="independent chains batched on each GPU against ONE copy of G through the "
                          "fp64 MFMA path (1..16); value then counts the steps of all chains")
+    ap.add_argument("--cells-fraction", type=int, default=1,
+                    help="keep only the first 1/F of the cells: the share one of F GPUs holds when "
+                         "the chain is sharded (single-GPU rehearsal of a model that exceeds one HBM)")
     ap.add_argument("--matrix-free", action="store_true",
                     help="never store G: re-evaluate the kernel entries in every pass")
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
@@ -179,7 +191,11 @@ def main():
         mesh, xp, yp, zp, rho = make_problem(args.workload)
         extra = dict(kind=0, reg="Damping", alpha=1.0, beta=0.01, dt=WORKLOADS[args.workload][4],
                      hi=1.0, wavelet=0)
-    N, M = xp.size, mesh.size
+    bounds = mesh.cell_bounds()
+    if args.cells_fraction > 1:
+        keep = mesh.size // args.cells_fraction
+        bounds, rho = bounds[:keep], rho[:keep]
+    N, M = xp.size, bounds.shape[0]
     dev = 0 if args.rehearse_on_one_gpu else local_rank
     if args.shard:
         from gravinv3dhmc_amd.dist import make_sharded_engine
@@ -191,7 +207,7 @@ def main():
         eng.set_matrix_free(True)
     t0 = time.time()
     eng.set_obs(xp, yp, zp)
-    eng.set_cells(mesh.cell_bounds(), extra["kind"], 1.6)
+    eng.set_cells(bounds, extra["kind"], 1.6)
     eng.build_G()
     eng.synchronize()
     t_build = time.time() - t0

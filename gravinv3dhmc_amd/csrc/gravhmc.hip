@@ -284,7 +284,7 @@ static int configure_sweep(gh_ctx *c)
         // product of a column then spans several launches, so the adjoint and the forward can no
         // longer share one read of G (two reads per step, like the reference's formulation).
         tw = 16;
-        c->n_panels = (int)((ld + 16383) / 16384);
+        c->n_panels = (int)((ld + 10239) / 10240);  // <= 10240 rows: 5 double2 per thread, no spills
         c->panel_rows = ((ld + c->n_panels - 1) / c->n_panels + 15) / 16 * 16;
     }
     per = tw * 128;
@@ -2034,7 +2034,9 @@ int gh_profile_read(gh_ctx *c, double *sweep_ms, int64_t *sweep_launches, int64_
     const int64_t timed = (int64_t)(c->ev_used / 2);
     if (sweep_ms) *sweep_ms = ms;
     if (sweep_launches) *sweep_launches = timed;
-    if (bytes_per_sweep) *bytes_per_sweep = c->N * c->M * (int64_t)sizeof(double);
+    // one launch reads one row panel of G (the whole matrix when N <= 16384)
+    if (bytes_per_sweep)
+        *bytes_per_sweep = (c->n_panels > 1 ? c->panel_rows : c->N) * c->M * (int64_t)sizeof(double);
     return GH_OK;
 }
 
