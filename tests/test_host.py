@@ -125,3 +125,17 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|liborc|gravhmc_oracle", txt, re.M), \
                     (dirpath, f)
+
+
+def test_utils_carve_roundtrip_and_regular():
+    from gravinv3dhmc_amd import utils
+    rho = np.arange(10.0)
+    mask = [2, 5, 9]
+    c = utils.rho2carve(rho, mask)
+    assert list(c) == [0, 1, 3, 4, 6, 7, 8]
+    back = utils.carve2rho(c, mask, 10, fill=-1.0)
+    assert list(back) == [0, 1, -1, 3, 4, -1, 6, 7, 8, -1]
+    assert np.array_equal(utils.rho2carve(rho, []), rho)
+    x, y, z = utils.regular((0, 2000, 0, 3000), (20, 30), z=0.0)
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 3000, 30), np.linspace(0, 2000, 20))]
+    assert np.array_equal(x, xp) and np.array_equal(y, yp) and z.shape == (600,) and not z.any()
