@@ -40,6 +40,8 @@ PROTOTYPES = {
     "gh_forward": (C.c_int, [_ctx, _dp, _dp]),
     "gh_adjoint": (C.c_int, [_ctx, _dp, _dp]),
     "gh_misfit_and_grad": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
+    "gh_reg_eval": (C.c_int, [_ctx, C.c_int, C.c_double, C.POINTER(C.c_int), C.c_int, _dp, _dp,
+                              C.POINTER(C.c_double), _dp]),
     "gh_compress_wavelet": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_int,
                                       C.POINTER(_i64), C.POINTER(_i64)]),
     "gh_download_csr": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(C.c_int32), _dp]),

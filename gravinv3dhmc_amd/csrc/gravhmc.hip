@@ -671,6 +671,7 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
 {
     double *d_out = o.d, *r_out = o.r, *greg_out = o.greg, *scal_out = o.scal;
     RegArgs ra;
+    ra.ms_grad_den_mw = 0;
     ra.kind = c->reg_kind;
     ra.M = c->M;
     ra.nz = c->shape[0];
@@ -1204,6 +1205,44 @@ int gh_misfit_and_grad(gh_ctx *c, const double *x, double out3[3], double *grad,
     out3[0] = c->h_scal[2];
     out3[1] = c->h_scal[0];
     out3[2] = c->h_scal[1];
+    return GH_OK;
+}
+
+int gh_reg_eval(gh_ctx *c, int kind, double beta, const int shape3[3], int ms_grad_den_mw, const double *mw,
+                const double *mwapr, double *value, double *grad)
+{
+    if (!c || !mw || !mwapr || !value) return fail(c, GH_ERR_ARG, "gh_reg_eval: null pointer");
+    if (kind < 0 || kind > 3)
+        return fail(c, GH_ERR_ARG, "Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.");
+    if (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV)
+        if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
+            return fail(c, GH_ERR_ARG, "gh_reg_eval: Smoothness/TV need shape nz*ny*nx == M");
+    if (kind == GH_REG_MS) TRY(need(c, c->weighted, "gh_reg_eval: MS needs gh_weight first (uses Wm^2)"));
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    double *dx = c->xb[3], *dapr = c->st[3].greg, *dg = c->tmpM;
+    TRY(h2d(c, dx, mw, (size_t)c->M));
+    TRY(h2d(c, dapr, mwapr, (size_t)c->M));
+    RegArgs ra;
+    ra.ms_grad_den_mw = ms_grad_den_mw;
+    ra.kind = kind;
+    ra.M = c->M;
+    ra.nz = shape3 ? shape3[0] : 1;
+    ra.ny = shape3 ? shape3[1] : 1;
+    ra.nx = shape3 ? shape3[2] : (int)c->M;
+    ra.alpha = 1.0;
+    ra.beta = beta;
+    ra.x = dx;
+    ra.mwapr = dapr;
+    ra.wm2 = c->wm2;
+    ra.greg = dg;
+    ra.regpart = c->regpart;
+    reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+    sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, c->st[3].scal);
+    HIPCHK(c, hipGetLastError());
+    TRY(d2h(c, c->h_scal, c->st[3].scal, 2));
+    *value = c->h_scal[0];
+    if (grad) TRY(d2h(c, grad, dg, (size_t)c->M));
     return GH_OK;
 }
 

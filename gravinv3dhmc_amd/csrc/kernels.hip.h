@@ -344,6 +344,7 @@ __global__ void __launch_bounds__(256) reduce_slab_kernel(const double *slab, in
 }
 
 struct RegArgs {
+    int ms_grad_den_mw;  // 1: MS gradient denominator uses mw^2 (reginv.py:288-292) instead of (mw-mwapr)^2
     int kind;
     int64_t M;
     int nz, ny, nx;
@@ -369,7 +370,8 @@ __global__ void __launch_bounds__(256) reg_kernel(RegArgs a)
         } else if (a.kind == 2) {  // MS
             const double v2 = v * v, den = v2 + a.beta, w2 = a.wm2[j];
             val = (w2 * v2) / den;
-            g = (2.0 * a.beta * w2 * v) / (den * den);
+            const double deng = a.ms_grad_den_mw ? a.x[j] * a.x[j] + a.beta : den;
+            g = (2.0 * a.beta * w2 * v) / (deng * deng);
         } else {  // Smoothness (1) / TV (3)
             const int64_t nx = a.nx, ny = a.ny, nz = a.nz;
             const int64_t i = j % nx, jj = (j / nx) % ny, k = j / (nx * ny);

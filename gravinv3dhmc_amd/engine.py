@@ -151,6 +151,20 @@ class Engine(object):
         self._chk(self._lib.gh_misfit_and_grad(self._h, ptr(x), ptr(out3), ptr(grad), ptr(dpre)))
         return out3[0], grad, dpre, out3[1], out3[2]
 
+    def reg_eval(self, regularization, mw, mwapr, beta=0.01, shape=None, ms_grad_den_mw=False,
+                 want_grad=True):
+        """(value, grad) of one regulariser alone (alpha = 1)."""
+        if regularization not in _lib.REG_KINDS:
+            raise ValueError("Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.")
+        mw, mwapr = f64(mw), f64(mwapr)
+        shp = (C.c_int * 3)(*[int(s) for s in shape]) if shape is not None else None
+        val = C.c_double(0)
+        grad = np.empty(self.M) if want_grad else None
+        self._chk(self._lib.gh_reg_eval(self._h, _lib.REG_KINDS[regularization], float(beta), shp,
+                                        1 if ms_grad_den_mw else 0, ptr(mw), ptr(mwapr),
+                                        C.byref(val), ptr(grad)))
+        return val.value, grad
+
     # -- wavelet-compressed forward -----------------------------------------------
     def compress_wavelet(self, dims, shape=None, thr=1e-3, levels=2):
         shp = (C.c_int * 3)(*[int(v) for v in shape]) if shape is not None else None

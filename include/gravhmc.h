@@ -111,6 +111,13 @@ int gh_adjoint(gh_ctx *ctx, const double *r, double *g);
 int gh_misfit_and_grad(gh_ctx *ctx, const double *x, double out3[3], double *grad,
                        double *dpre);
 
+/* Regulariser value and gradient alone (alpha = 1), for optimisers that combine the terms
+ * themselves: ConjugateGradient of inversion/reginv.py:271-355.  ms_grad_den_mw = 1 reproduces
+ * that file's MS gradient, whose denominator is (mw^2 + beta)^2 (reginv.py:288-292) instead of
+ * ((mw - mwapr)^2 + beta)^2 (potential.py:732-735). */
+int gh_reg_eval(gh_ctx *ctx, int kind, double beta, const int shape3[3], int ms_grad_den_mw,
+                const double *mw, const double *mwapr, double *value, double *grad /* M or NULL */);
+
 /* ---- wavelet-compressed forward operator (gravmag/compressor1D.py, compressor3D.py) ------ */
 
 /* Build the compressed kernel on the device: row-wise db4 / 'periodization' DWT of the weighted

@@ -1,0 +1,78 @@
+"""NumPy restatement of the reference's conjugate-gradient optimiser (test infrastructure only).
+
+inversion/reginv.py:120-149 (newkernel), :248-355 (data / model terms), :357-492 (CG), with the
+reference's quirks: no mean removal in the data term, MS gradient denominator (mw^2 + beta)^2,
+clamp of the unweighted model after every update.  Pinned by tests/golden/cg_small.npz, generated
+from the reference class itself (oracle/make_golden.py::cg_small).
+"""
+import numpy as np
+
+from oracle import oracle
+
+
+def cg(K, dobs, shape, initialModel, apriorModel, boundary, regularization="MS", beta=0.01, q=0.9,
+       maxk=100):
+    Aw, wm = oracle.col_weight(K)
+    N, M = Aw.shape
+    wm2 = wm * wm
+    R = oracle.fd3d_dense(shape) if regularization in ("Smoothness", "TV") else None
+
+    def data(mw):
+        return np.linalg.norm(Aw @ mw - dobs) ** 2
+
+    def data_g(mw):
+        return 2 * Aw.T @ (Aw @ mw - dobs)
+
+    def model(mw):
+        v = mw - mwapr
+        if regularization == "MS":
+            return np.sum(wm2 * v ** 2 / (v ** 2 + beta))
+        if regularization == "Damping":
+            return v @ v
+        t = R @ v
+        return t @ t if regularization == "Smoothness" else np.sum(np.sqrt(t ** 2 + beta))
+
+    def model_g(mw):
+        v = mw - mwapr
+        if regularization == "MS":
+            return 2 * beta * wm2 * v / (mw * mw + beta) ** 2
+        if regularization == "Damping":
+            return 2 * v
+        t = R @ v
+        return 2 * R.T @ t if regularization == "Smoothness" else R.T @ (t / np.sqrt(t ** 2 + beta))
+
+    def step(mw, I, Iw, alpha):
+        kstep = (Iw @ I) / (np.linalg.norm(Aw @ Iw) ** 2 + alpha * np.linalg.norm(Iw) ** 2)
+        m = (mw - kstep * Iw) / wm
+        m[m < boundary[0]] = boundary[0]
+        m[m > boundary[1]] = boundary[1]
+        return wm * m
+
+    mw, mwapr = wm * initialModel, wm * apriorModel
+    dm, mm, rf = [], [], []
+    mw_new = mw
+    for k in range(maxk):
+        if k == 0:
+            alpha = 0
+        elif k == 1:
+            alpha = data(mw_new) / model(mw_new)
+        elif data(mw) - data(mw_new) < 0.01 * data(mw):
+            alpha = q * alpha
+        rf.append(alpha)
+        if k == 0:
+            dm.append(data(mw) / N)
+            I = data_g(mw) + alpha * model_g(mw)
+            mm.append(model(mw) / M)
+            Iw = I
+            mw_new = step(mw, I, Iw, alpha)
+        else:
+            I_old, Iw_old = I, Iw
+            mw = mw_new
+            I = data_g(mw) + alpha * model_g(mw)
+            Iw = I + (np.linalg.norm(I) ** 2 / np.linalg.norm(I_old) ** 2) * Iw_old
+            mw_new = step(mw, I, Iw, alpha)
+            dm.append(data(mw_new) / N)
+            mm.append(model(mw_new) / M)
+            if dm[-1] < 0.001:
+                break
+    return mw_new / wm, Aw @ mw_new, np.array(dm), np.array(mm), np.array(rf, dtype=float)

@@ -383,6 +383,35 @@ def mesher_cases(R):
     print("mesher_cases", {k: out[k + "_bounds"].shape for k in cases})
 
 
+def cg_small(R):
+    """The reference's ConjugateGradient.CG (inversion/reginv.py:357-492) on a small prism problem."""
+    from inversion import reginv
+    from oracle import cg_port
+    mrange, mspacing = (0, 2000, 0, 3000, 0, 1000), (250, 500, 400)
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 3000, 7), np.linspace(0, 2000, 6))]
+    zp = np.zeros_like(xp)
+    pm = _quiet(R.mesher.PrismMesh, mrange, mspacing)
+    b = np.array([c.get_bounds() for c in pm])
+    K = oracle.prism_gz_kernel(xp, yp, zp, b)
+    rho = np.zeros(pm.shape)
+    rho[1:3, 2:4, 1:4] = 0.8
+    dobs = K @ rho.ravel() + np.random.default_rng(5).normal(size=xp.size) * 0.01
+    cgm = _quiet(reginv.ConjugateGradient, dobs, mrange, mspacing, (xp, yp, zp))
+    M = pm.size
+    out = dict(xp=xp, yp=yp, zp=zp, dobs=dobs, mrange=np.array(mrange, float), mspacing=np.array(mspacing, float),
+               shape=np.array(pm.shape), K=K)
+    for reg in ("MS", "Damping", "Smoothness", "TV"):
+        res = _quiet(cgm.CG, np.full(M, 0.001), np.full(M, 0.001), (0.0, 1.0), regularization=reg,
+                     beta=0.01, q=0.9, maxk=8)
+        po = cg_port.cg(K, dobs, pm.shape, np.full(M, 0.001), np.full(M, 0.001), (0.0, 1.0), reg, 0.01, 0.9, 8)
+        for a_, b_ in zip(res, po):
+            assert _relmax(np.asarray(b_, float), np.asarray(a_, float)) < 1e-9, (reg, _relmax(np.asarray(b_, float), np.asarray(a_, float)))
+        for name, v in zip(("model", "data", "dmis", "mmis", "alpha"), res):
+            out[reg + "_" + name] = np.asarray(v, dtype=float)
+        print("cg_small", reg, "iterations", len(res[2]), "final data misfit", res[2][-1])
+    np.savez_compressed(os.path.join(GOLD, "cg_small.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     R = ref_harness.load()
@@ -400,6 +429,7 @@ def main():
     chain_small(R)
     example_inputs(R)
     c1_leapfrog_rows(R, xp, yp, zp)
+    cg_small(R)
     print("golden fixtures written to", GOLD)
 
 

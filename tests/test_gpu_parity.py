@@ -910,3 +910,32 @@ def test_row_panels_chain_matches_oracle(G, orc):
             if acc:
                 assert relmax(xs, xo) < 1e-9
     eng.close()
+
+
+# ------------------------------------------------------------- conjugate gradient (reginv)
+
+def test_conjugate_gradient_matches_reference(G, capsys):
+    """ConjugateGradient.CG on the device primitives against the reference's own run
+    (tests/golden/cg_small.npz, inversion/reginv.py:357-492), all four regularisers."""
+    g = gold("cg_small.npz")
+    cg = G.ConjugateGradient(g["dobs"], tuple(g["mrange"]), tuple(g["mspacing"]),
+                             (g["xp"], g["yp"], g["zp"]), verbose=False)
+    M = cg.msize
+    assert (cg.dsize, M, cg.mshape) == (42, 120, tuple(g["shape"]))
+    for reg in ("MS", "Damping", "Smoothness", "TV"):
+        res = cg.CG(np.full(M, 0.001), np.full(M, 0.001), (0.0, 1.0), regularization=reg, beta=0.01,
+                    q=0.9, maxk=8)
+        capsys.readouterr()
+        errs = {name: relmax(np.asarray(v, float), g[reg + "_" + name])
+                for name, v in zip(("model", "data", "dmis", "mmis", "alpha"), res)}
+        assert max(errs.values()) < 1e-7, (reg, errs)
+    with pytest.raises(ValueError):
+        cg.CG(np.full(M, 0.001), np.full(M, 0.001), (0.0, 1.0), regularization="L1")
+    # the MS gradient quirk of reginv.py:288-292 is what gh_reg_eval(ms_grad_den_mw=1) computes
+    rng = np.random.default_rng(0)
+    wm = cg.Wm.diagonal()
+    mw, apr = rng.uniform(0, 1, M) * wm, 0.3 * wm
+    v, gq = cg._engine.reg_eval("MS", mw, apr, 0.01, cg.mshape, ms_grad_den_mw=True)
+    assert relmax(gq, 2 * 0.01 * wm ** 2 * (mw - apr) / (mw * mw + 0.01) ** 2) < 1e-14
+    v2, gp = cg._engine.reg_eval("MS", mw, apr, 0.01, cg.mshape, ms_grad_den_mw=False)
+    assert v == v2 and relmax(gp, 2 * 0.01 * wm ** 2 * (mw - apr) / ((mw - apr) ** 2 + 0.01) ** 2) < 1e-14

@@ -229,3 +229,15 @@ def test_wavelet_orthonormal_on_even_lengths():
     c1 = w.wavedec1_packed(x)
     np.testing.assert_allclose((c1 ** 2).sum(1), (x ** 2).sum(1), rtol=1e-13)
     assert w.wavedec3_packed(np.zeros(6000), (10, 30, 20))[1] == (11, 31, 20)
+
+
+def test_cg_port_matches_reference_golden():
+    """oracle/cg_port.py against the reference's ConjugateGradient.CG outputs (cg_small.npz)."""
+    from oracle import cg_port
+    g = gold("cg_small.npz")
+    M = int(np.prod(g["shape"]))
+    for reg in ("MS", "Damping", "Smoothness", "TV"):
+        res = cg_port.cg(g["K"], g["dobs"], tuple(g["shape"]), np.full(M, 0.001), np.full(M, 0.001),
+                         (0.0, 1.0), reg, 0.01, 0.9, 8)
+        for name, v in zip(("model", "data", "dmis", "mmis", "alpha"), res):
+            assert relmax(v, g[reg + "_" + name]) < 1e-9, (reg, name)
