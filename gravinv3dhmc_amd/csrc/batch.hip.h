@@ -50,7 +50,8 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// Adjoint of all chains + leapfrog update (hmc.py:114-152) for one 16-column tile per wave.
+// Adjoint of all chains + leapfrog update (hmc.py:114-152): every wave owns TWO adjacent
+// 16-column tiles, so each fragment of the residuals read from L2 feeds two MFMAs.
 // Rows 16 p + 2 k + {0,1} and 16 p + 8 + 2 k + {0,1} of patch p are contracted by the four MFMAs
 // of lane group k = lane >> 4.
 __global__ void __launch_bounds__(256) batch_adjoint_kernel(BatchAdjArgs a)
@@ -59,80 +60,95 @@ __global__ void __launch_bounds__(256) batch_adjoint_kernel(BatchAdjArgs a)
     const int lo = lane & 15, k = lane >> 4;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t ntiles = (a.M + 15) / 16;
+    const int64_t npairs = (ntiles + 1) / 2;
+    const bool tiled = a.Gb != nullptr;
     double pp = 0.0;
-    for (int64_t tile = wave; tile < ntiles; tile += a.n_waves) {
-        const int64_t j0 = tile * 16;
-        const int64_t ja = j0 + lo;  // the column this lane feeds as A operand
-        const bool col_ok = ja < a.M;
+    for (int64_t pair = wave; pair < npairs; pair += a.n_waves) {
         // column-major G: 16 columns x 64 B per load.  Gb: the tile's operands are one contiguous
         // stream (1 KiB per load), which is what keeps HBM pages open.
-        const bool tiled = a.Gb != nullptr;
-        const d2 *gcol = tiled ? reinterpret_cast<const d2 *>(a.Gb) + tile * a.np * 128 + lane
-                               : reinterpret_cast<const d2 *>(a.G + (col_ok ? ja : 0) * a.ld) + k;
+        const d2 *gcol[2];
+        bool tile_ok[2], col_ok[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t tile = 2 * pair + h;
+            const int64_t ja = tile * 16 + lo;  // the column this lane feeds as A operand
+            tile_ok[h] = tile < ntiles;
+            col_ok[h] = tile_ok[h] && (tiled || ja < a.M);
+            gcol[h] = tiled ? reinterpret_cast<const d2 *>(a.Gb) + (tile_ok[h] ? tile : 0) * a.np * 128 + lane
+                            : reinterpret_cast<const d2 *>(a.G + (col_ok[h] ? ja : 0) * a.ld) + k;
+        }
         const int gstep = tiled ? 128 : 8, ghalf = tiled ? 64 : 4;
         const d2 *rt = reinterpret_cast<const d2 *>(a.Rt) + (k * 16 + lo);
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        // software pipeline: three patches are in flight while one is multiplied (ring of four)
-        d2 g0[4], g1[4], r0[4], r1[4];
+        d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+        // software pipeline: two patches are in flight while one is multiplied (ring of three)
+        d2 g0[3][2], g1[3][2], r0[3], r1[3];
         auto fetch = [&](int slot, int p) {
             const bool ok = p < a.np;
-            const bool gok = ok && (col_ok || tiled);
-            g0[slot] = gok ? __builtin_nontemporal_load(gcol + (int64_t)gstep * p) : d2{0.0, 0.0};
-            g1[slot] = gok ? __builtin_nontemporal_load(gcol + (int64_t)gstep * p + ghalf) : d2{0.0, 0.0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool gok = ok && col_ok[h];
+                g0[slot][h] = gok ? __builtin_nontemporal_load(gcol[h] + (int64_t)gstep * p) : d2{0.0, 0.0};
+                g1[slot][h] = gok ? __builtin_nontemporal_load(gcol[h] + (int64_t)gstep * p + ghalf) : d2{0.0, 0.0};
+            }
             r0[slot] = ok ? rt[128 * p] : d2{0.0, 0.0};
             r1[slot] = ok ? rt[128 * p + 64] : d2{0.0, 0.0};
         };
         auto mult = [&](int slot) {
-            acc = mfma_f64(g0[slot].x, r0[slot].x, acc);
-            acc = mfma_f64(g0[slot].y, r0[slot].y, acc);
-            acc = mfma_f64(g1[slot].x, r1[slot].x, acc);
-            acc = mfma_f64(g1[slot].y, r1[slot].y, acc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                acc[h] = mfma_f64(g0[slot][h].x, r0[slot].x, acc[h]);
+                acc[h] = mfma_f64(g0[slot][h].y, r0[slot].y, acc[h]);
+                acc[h] = mfma_f64(g1[slot][h].x, r1[slot].x, acc[h]);
+                acc[h] = mfma_f64(g1[slot][h].y, r1[slot].y, acc[h]);
+            }
         };
         fetch(0, 0);
         fetch(1, 1);
-        fetch(2, 2);
-        for (int p = 0; p < a.np; p += 4) {  // zero patches beyond np add nothing
-            fetch(3, p + 3);
+        for (int p = 0; p < a.np; p += 3) {  // zero patches beyond np add nothing
+            fetch(2, p + 2);
             mult(0);
-            fetch(0, p + 4);
+            fetch(0, p + 3);
             mult(1);
-            fetch(1, p + 5);
+            fetch(1, p + 4);
             mult(2);
-            fetch(2, p + 6);
-            mult(3);
         }
-        // acc[q] = <G_j, r_c> for column j = j0 + k + 4 q and chain c = lo
+        // acc[h][q] = <G_j, r_c> for column j = 16 (2 pair + h) + k + 4 q and chain c = lo
         const int c = lo;
         const int ph = a.phase[c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t j = j0 + k + 4 * q;
-            if (j >= a.M) continue;
-            const int64_t idx = j * CB + c;
-            const double g = 2.0 * acc[q] + (a.GREG ? a.GREG[idx] : 0.0);
-            if (ph == PH_GOUT) {
-                a.G_out[idx] = g;
-            } else if (ph == PH_UPD) {
-                double pj = a.P_in[idx] - a.cu[c] * g;
-                double xj = a.X_in[idx] + a.dt * pj;
-                const double hi = a.high[j], lw = a.low[j];
-                if (xj > hi) {
-                    xj = hi;
-                    pj = -pj;
-                } else if (xj < lw) {
-                    xj = lw;
-                    pj = -pj;
+        for (int h = 0; h < 2; ++h) {
+            if (!tile_ok[h]) continue;
+            const int64_t j0 = (2 * pair + h) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t j = j0 + k + 4 * q;
+                if (j >= a.M) continue;
+                const int64_t idx = j * CB + c;
+                const double g = 2.0 * acc[h][q] + (a.GREG ? a.GREG[idx] : 0.0);
+                if (ph == PH_GOUT) {
+                    a.G_out[idx] = g;
+                } else if (ph == PH_UPD) {
+                    double pj = a.P_in[idx] - a.cu[c] * g;
+                    double xj = a.X_in[idx] + a.dt * pj;
+                    const double hi = a.high[j], lw = a.low[j];
+                    if (xj > hi) {
+                        xj = hi;
+                        pj = -pj;
+                    } else if (xj < lw) {
+                        xj = lw;
+                        pj = -pj;
+                    }
+                    a.P_out[idx] = pj;
+                    a.X_out[idx] = xj;
+                } else if (ph == PH_PFIN) {
+                    const double pf = a.P_in[idx] - a.cp[c] * g;
+                    pp += pf * pf;
+                    a.P_out[idx] = pf;
+                    a.X_out[idx] = a.X_in[idx];
+                } else {
+                    a.P_out[idx] = a.P_in[idx];
+                    a.X_out[idx] = a.X_in[idx];
                 }
-                a.P_out[idx] = pj;
-                a.X_out[idx] = xj;
-            } else if (ph == PH_PFIN) {
-                const double pf = a.P_in[idx] - a.cp[c] * g;
-                pp += pf * pf;
-                a.P_out[idx] = pf;
-                a.X_out[idx] = a.X_in[idx];
-            } else {
-                a.P_out[idx] = a.P_in[idx];
-                a.X_out[idx] = a.X_in[idx];
             }
         }
     }

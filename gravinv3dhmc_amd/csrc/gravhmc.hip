@@ -1697,7 +1697,8 @@ static int batch_alloc(gh_ctx *c)
     b.n_regblocks = (int)((c->M + 15) / 16);
     TRY(dalloc(c, &b.regpart, (size_t)b.n_regblocks * CB));
     const int64_t ntiles = (c->M + 15) / 16;
-    const int wgs = (int)std::min<int64_t>((ntiles + 3) / 4, (int64_t)c->cus * 4);
+    const int64_t npairs = (ntiles + 1) / 2;  // a wave owns two adjacent column tiles
+    const int wgs = (int)std::min<int64_t>((npairs + 3) / 4, (int64_t)c->cus * 4);
     b.n_waves = wgs * 4;
     TRY(dalloc(c, &b.pp_part, (size_t)b.n_waves * CB));
     b.n_pp0 = (int)std::min<int64_t>(512, (c->M + 15) / 16);
