@@ -317,7 +317,7 @@ def main():
         bytes_sweep = prof["bytes_per_sweep"]          # N*M_local*8: one read of this rank's G
         achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
         line = {
-            "metric": "HMC leapfrog steps/sec + G*rho achieved HBM GB/s",
+            "metric": "HMC leapfrog steps/sec + G\u00b7\u03c1 achieved HBM GB/s at 1/2/4/8 GPUs",
             "value": args.steps * CPG * (1 if args.shard else world) / elapsed,
             "unit": "leapfrog steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
