@@ -318,7 +318,14 @@ def example_inputs(R):
     log = os.path.join(ex, "segmentgrid", "logout_T0.txt")
     out["seg_T0_chain0"] = _chain_lines(log, 0, 40)
     out["seg_T0_chain1"] = _chain_lines(log, 1, 40)
-    for k in ("real_T0_chain0", "uni_T1_chain0", "seg_T0_chain0"):
+    # ratiogrid: geometric dz (ratio 1.05), shape (19, 30, 30): ODD lengths on every wavelet level
+    out["ratio_obs"] = np.loadtxt(os.path.join(ex, "ratiogrid", "modeldata", "model_ratio_gz_noise.txt"))
+    log = os.path.join(ex, "ratiogrid", "logout_T1.txt")
+    out["ratio_T1_chain0"] = _chain_lines(log, 0, 40)
+    out["ratio_T1_chain1"] = _chain_lines(log, 1, 40)
+    out["ratio_initial_mw_head"] = np.array([2.28807790e-03, 2.36481323e-03, 2.42123838e-03])
+    out["ratio_initial_mw_tail"] = np.array([5.19145835e-05, 5.08185019e-05, 4.96606275e-05])
+    for k in ("real_T0_chain0", "uni_T1_chain0", "seg_T0_chain0", "ratio_T1_chain0"):
         print(k, out[k].shape, out[k][0])
     np.savez_compressed(os.path.join(GOLD, "example_inputs.npz"), **out)
 

@@ -939,3 +939,31 @@ def test_conjugate_gradient_matches_reference(G, capsys):
     assert relmax(gq, 2 * 0.01 * wm ** 2 * (mw - apr) / (mw * mw + 0.01) ** 2) < 1e-14
     v2, gp = cg._engine.reg_eval("MS", mw, apr, 0.01, cg.mshape, ms_grad_den_mw=False)
     assert v == v2 and relmax(gp, 2 * 0.01 * wm ** 2 * (mw - apr) / ((mw - apr) ** 2 + 0.01) ** 2) < 1e-14
+
+
+def test_ratiogrid_wavelet_log_lines_on_gpu(G, tmp_path, capsys):
+    """example/ratiogrid/logout_T1.txt chains 0 and 1 on the device: ratio mesh (19, 30, 30), odd
+    wavelet lengths, MS, a rejected proposal on line 3 of chain 0."""
+    e = gold("example_inputs.npz")
+    obs = e["ratio_obs"]
+    M = 17100
+    import re
+    pat = re.compile(r"=\(([-\d.]+),([-\d.]+),([-\d.]+),([-\d.]+)\) -- accept ratio ([\d.]+)%")
+    for rank, key in ((0, "ratio_T1_chain0"), (1, "ratio_T1_chain1")):
+        gm = G.GravMagModule(obs[:, 3], (0, 6000, 0, 6000, 0, 6000), (200, 200, 200),
+                             (obs[:, 0], obs[:, 1], obs[:, 2]), mratio=1.05, wavelet='3D', verbose=False)
+        assert gm.mshape == (19, 30, 30)
+        capsys.readouterr()
+        G.HMCSample(gm, 6, 0, 0.01, [5, 20], np.full(M, 0.001), np.full(M, 0.001),
+                    np.c_[np.zeros(M), np.full(M, 0.4)], "mandatory", 1000, obs[:, 3], "Fixed", 0.8, 1,
+                    "MS", 0.001, 100, 0.001, myrank=rank, save_folder=str(tmp_path / "ratio_chain"),
+                    sample_sink="none")
+        lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain %d" % rank)]
+        got = np.array([[float(v) for v in pat.search(l).groups()] for l in lines])
+        n = min(len(got), len(e[key]))          # the fixture keeps the first 40 lines of the log
+        assert n >= 6
+        got, ref = got[:n], e[key][:n]
+        np.testing.assert_allclose(got[:, [0, 1, 3]], ref[:, [0, 1, 3]], rtol=0, atol=1.01e-7)
+        np.testing.assert_allclose(got[:, 4], ref[:, 4], atol=0.006)
+        assert (np.diff(got[:, 4]) < 0).any()  # rejected proposals occur, as in the reference's log
+        gm._engine.close()

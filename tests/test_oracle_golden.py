@@ -241,3 +241,30 @@ def test_cg_port_matches_reference_golden():
                          (0.0, 1.0), reg, 0.01, 0.9, 8)
         for name, v in zip(("model", "data", "dmis", "mmis", "alpha"), res):
             assert relmax(v, g[reg + "_" + name]) < 1e-9, (reg, name)
+
+
+def test_wavelet_odd_lengths_pinned_by_ratiogrid_log():
+    """example/ratiogrid/logout_T1.txt: geometric-dz mesh of shape (19, 30, 30) -- odd lengths on
+    both wavelet levels (19 -> 10 -> 5, 15 -> 8) -- wavelet 3D + MS, including a REJECTED proposal
+    (accept ratio 66.67 % on line 3).  Pins the odd-length periodization of oracle/wavelet.py."""
+    from gravinv3dhmc_amd import mesher
+    from oracle import wavelet as w
+    e = gold("example_inputs.npz")
+    obs = e["ratio_obs"]
+    mesh = mesher.PrismMesh((0, 6000, 0, 6000, 0, 6000), (200, 200, 200), 1.05)
+    assert mesh.shape == (19, 30, 30)
+    Aw, wm = oracle.col_weight(oracle.prism_gz_kernel(obs[:, 0], obs[:, 1], obs[:, 2], mesh.cell_bounds()))
+    np.testing.assert_allclose((0.001 * wm)[:3], e["ratio_initial_mw_head"], rtol=5e-9)
+    np.testing.assert_allclose((0.001 * wm)[-3:], e["ratio_initial_mw_tail"], rtol=5e-9)
+    N, M = Aw.shape
+    shape = mesh.shape
+    csr = w.compress_kernel(Aw, 3, shape)
+    assert csr.shape == (N, 21 * 31 * 31 - 0) or csr.shape[1] == w.model_coeffs(np.zeros(M), 3, shape).size
+    P = oracle.Problem(Aw, obs[:, 3], 0.001 * wm, "MS", 1.0, 0.001, wm=wm, shape=shape, csr=csr,
+                       dwt=lambda x: w.model_coeffs(x, 3, shape))
+    rows, _ = _run_chain(P, wm, 0.001 * wm, 0 * wm, 0.4 * wm, 0.01, [5, 20], 0.001, 100, 3, N, M)
+    ref = e["ratio_T1_chain0"][:len(rows)]
+    np.testing.assert_allclose(rows[:, :3], ref[:, [0, 1, 3]], rtol=0, atol=1.01e-7)
+    ratio = 100.0 * np.cumsum(rows[:, 3]) / np.arange(1, len(rows) + 1)
+    np.testing.assert_allclose(ratio, ref[:, 4], atol=0.006)
+    assert (rows[:, 3] == 0).any()          # the rejected proposal of the log is reproduced
