@@ -967,3 +967,30 @@ def test_ratiogrid_wavelet_log_lines_on_gpu(G, tmp_path, capsys):
         np.testing.assert_allclose(got[:, 4], ref[:, 4], atol=0.006)
         assert (np.diff(got[:, 4]) < 0).any()  # rejected proposals occur, as in the reference's log
         gm._engine.close()
+
+
+def test_global_c4_full_kernel_against_reference_log(G, orc):
+    """Config C4 at full size (7381 x 72000 tesseroids, 5.3e8 adaptive-GLQ pairs, assembled on the
+    device in ~0.1 s; the reference's log reports 246 s + 228 s of weighting): `initial mw` of
+    example/global/logout_T1.txt to its 9 printed digits, and sampled columns against the oracle."""
+    from test_oracle_golden import GLOBAL_MW_HEAD, GLOBAL_MW_TAIL, global_inputs
+    mesh, lon, lat, h = global_inputs()
+    gm = G.GravMagModule(np.zeros(lon.size), (-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3),
+                         (lon, lat, h), coordinate="spherical", verbose=False)
+    assert gm.mshape == (10, 60, 120) and gm._engine.M == 72000
+    wm = gm.Wm.diagonal()
+    np.testing.assert_allclose(0.01 * wm[:3], GLOBAL_MW_HEAD, rtol=5e-9)
+    np.testing.assert_allclose(0.01 * wm[-3:], GLOBAL_MW_TAIL, rtol=0, atol=5.1e-9)
+    st = gm._engine.kernel_stats()
+    assert st["warn_cells"] == 0 and st["leaves"] >= 7381 * 72000
+    cols = np.r_[0, 1, 2, 35999, 36000, 71997, 71998, 71999]
+    Ko = orc.tess_gz_kernel(lon, lat, h, mesh.cell_bounds()[cols])
+    assert relmax(wm[cols], np.sqrt((Ko ** 2).sum(0))) < 1e-11
+    # unit-norm columns: ||Aw e_j|| = 1
+    for j in (0, 36000, 71999):
+        e = np.zeros(72000)
+        e[j] = 1.0
+        d = gm._engine.forward(e)
+        assert abs(np.linalg.norm(d) - 1.0) < 1e-12
+        assert relmax(d, Ko[:, list(cols).index(j)] / wm[j]) < 1e-10
+    gm._engine.close()

@@ -268,3 +268,29 @@ def test_wavelet_odd_lengths_pinned_by_ratiogrid_log():
     ratio = 100.0 * np.cumsum(rows[:, 3]) / np.arange(1, len(rows) + 1)
     np.testing.assert_allclose(ratio, ref[:, 4], atol=0.006)
     assert (rows[:, 3] == 0).any()          # the rejected proposal of the log is reproduced
+
+
+GLOBAL_MW_HEAD = np.array([10.29561741, 10.015107, 9.91994061])     # example/global/logout_T1.txt:42-43
+GLOBAL_MW_TAIL = np.array([0.07159403, 0.07159418, 0.07159425])
+
+
+def global_inputs():
+    """Config C4 geometry (example/global/main_global.py:25-28, model_global.py:159-162)."""
+    from gravinv3dhmc_amd import mesher
+    mesh = mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))
+    lon, lat = [a.ravel() for a in np.meshgrid(np.linspace(-180, 180, 121), np.linspace(-90, 90, 61),
+                                               indexing="ij")]
+    return mesh, lon, lat, np.full_like(lon, 5000.0)
+
+
+def test_global_log_initial_mw_columns():
+    """`initial mw` of example/global/logout_T1.txt (0.01 x column norms of the 7381 x 72000
+    tesseroid kernel): the six printed cells need only six columns of the kernel."""
+    mesh, lon, lat, h = global_inputs()
+    b = mesh.cell_bounds()
+    assert b.shape == (72000, 6) and lon.size == 7381
+    cols = np.r_[0, 1, 2, 71997, 71998, 71999]
+    K = oracle.tess_gz_kernel(lon, lat, h, b[cols])
+    mw = 0.01 * np.sqrt((K ** 2).sum(0))
+    np.testing.assert_allclose(mw[:3], GLOBAL_MW_HEAD, rtol=5e-9)
+    np.testing.assert_allclose(mw[3:], GLOBAL_MW_TAIL, rtol=0, atol=5.1e-9)   # 8 decimals printed
