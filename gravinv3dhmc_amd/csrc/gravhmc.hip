@@ -687,6 +687,8 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
     const double *gfix = c->have_fix ? c->gfix : nullptr;
     const double *regpart = c->regpart;
     int n_regpart = c->n_regpart;
+    const double *src;
+    int nseg;
     if (c->sh.kind != 0) {
         // sharded cells: local forward partial and local regulariser sum travel in ONE
         // all-reduce, then every rank finishes the (replicated) data part identically
@@ -695,31 +697,39 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
         sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, buf + c->ld);
         TRY(comm_allreduce(c, buf, c->ld + 2));
-        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(buf, 1, c->ld, c->N, gfix, d_out,
-                                                                            c->dpart);
+        src = buf;
+        nseg = 1;
         regpart = buf + c->ld;
         n_regpart = 1;
     } else if (c->wv.on) {
-        // forward through the compressed operator; d_out then acts as a one-row slab
+        // forward through the compressed operator: d_out is already complete
         TRY(wavelet_forward(c, x, d_out));
-        reduce_slab_kernel<<<dim3(c->n_dpart), dim3(32, 8), 0, c->stream>>>(d_out, 1, c->ld, c->N, gfix, d_out,
-                                                                            c->dpart);
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+        src = d_out;
+        nseg = 1;
+    } else if (c->grid > 64 && c->slab2) {
+        // many slab rows: first stage of the reduction and the regulariser share one launch,
+        // finish_kernel sums the 16 segments
+        nseg = c->slab2_rows;
+        reduce_reg_kernel<<<dim3((unsigned)(c->n_dpart * nseg + c->n_regpart)), dim3(256), 0, c->stream>>>(
+            c->slab, c->grid, c->ld, nseg, c->n_dpart, c->slab2, ra);
+        src = c->slab2;
     } else {
-        reduce_slab(c, gfix, d_out);
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+        src = c->slab;
+        nseg = c->grid;
     }
     FinishArgs fa;
     fa.N = c->N;
     fa.ld = c->ld;
-    fa.n_dpart = c->n_dpart;
+    fa.nseg = nseg;
     fa.n_regpart = n_regpart;
-    fa.d = d_out;
+    fa.src = src;
     fa.gfix = gfix;
     fa.dobs_c = c->dobs_c;
-    fa.dpart = c->dpart;
     fa.regpart = regpart;
     fa.alpha = c->alpha;
+    fa.d = d_out;
     fa.r = r_out;
     fa.scal = scal_out;
     finish_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(fa);

@@ -355,11 +355,11 @@ struct RegArgs {
 };
 
 // Regulariser value + gradient at x (potential.py:719-736, 775-810) as a stencil; the
-// finite-difference operator of potential.py:266-361 is never materialised.
-__global__ void __launch_bounds__(256) reg_kernel(RegArgs a)
+// finite-difference operator of potential.py:266-361 is never materialised.  `blk`: index of the
+// 256-cell block, `red`: 4 doubles of LDS.
+__device__ __forceinline__ void reg_block(const RegArgs &a, int blk, double *red)
 {
-    __shared__ double red[4];
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = (int64_t)blk * 256 + threadIdx.x;
     double val = 0.0;
     if (j < a.M) {
         const double v = a.x[j] - a.mwapr[j];
@@ -405,24 +405,80 @@ __global__ void __launch_bounds__(256) reg_kernel(RegArgs a)
         a.greg[j] = a.alpha * g;
     }
     const double tot = block_allreduce_sum(val, red, 4);
-    if (threadIdx.x == 0) a.regpart[blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.regpart[blk] = tot;
+}
+
+__global__ void __launch_bounds__(256) reg_kernel(RegArgs a)
+{
+    __shared__ double red[4];
+    reg_block(a, blockIdx.x, red);
+}
+
+// One launch for the two independent halves of the per-step epilogue: blocks [0, n_red) sum the
+// slab rows of one segment for 32 observations each (first stage of the slab reduction, same
+// arithmetic as reduce_slab_kernel with nseg > 1), the remaining blocks evaluate the regulariser.
+__global__ void __launch_bounds__(256)
+reduce_reg_kernel(const double *slab, int n_rows_slab, int64_t ld, int nseg, int n_dpart, double *slab2,
+                  RegArgs ra)
+{
+    __shared__ double red8[8][33];
+    __shared__ double red[4];
+    const int n_red = n_dpart * nseg;
+    if ((int)blockIdx.x >= n_red) {
+        reg_block(ra, blockIdx.x - n_red, red);
+        return;
+    }
+    const int rx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int bx = blockIdx.x % n_dpart, seg = blockIdx.x / n_dpart;
+    const int64_t i = (int64_t)bx * 32 + rx;
+    const int per = (n_rows_slab + nseg - 1) / nseg;
+    const int t0 = seg * per;
+    const int t1 = (t0 + per < n_rows_slab) ? t0 + per : n_rows_slab;
+    double acc = 0.0;
+    if (i < ld)
+        for (int t = t0 + ty; t < t1; t += 8) acc += slab[(int64_t)t * ld + i];
+    red8[ty][rx] = acc;
+    __syncthreads();
+    if (ty == 0 && i < ld) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red8[q][rx];
+        slab2[(int64_t)seg * ld + i] = s;
+    }
 }
 
 struct FinishArgs {
     int64_t N, ld;
-    int n_dpart, n_regpart;
-    const double *d, *gfix, *dobs_c, *dpart, *regpart;
+    int nseg, n_regpart;
+    const double *src;  // nseg x ld partial forward products (nseg = 1: the finished d)
+    const double *gfix, *dobs_c, *regpart;
     double alpha;
+    double *d;     // ld: forward product d = sum of the segments
     double *r;     // ld (zero padded)
     double *scal;  // [0]=U_data [1]=R [2]=U [3]=mean(dinv)
 };
 
-// Single block: mean removal, residual, data misfit (potential.py:700-706) and U = U_d + alpha R.
+// Single block: last stage of the slab reduction, mean removal, residual, data misfit
+// (potential.py:700-706) and U = U_d + alpha R.  The segment sum uses the association order of
+// reduce_slab_kernel (eight strided partial sums, then their sum), so a d that went through that
+// kernel first (sharded / wavelet paths, nseg = 1) and a d summed here have the same bits.
 __global__ void __launch_bounds__(1024) finish_kernel(FinishArgs a)
 {
     __shared__ double red[16];
     double s = 0.0;
-    for (int t = threadIdx.x; t < a.n_dpart; t += 1024) s += a.dpart[t];
+    for (int64_t i = threadIdx.x; i < a.ld; i += 1024) {
+        double q8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < a.nseg; t += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (t + q < a.nseg) q8[q] += a.src[(int64_t)(t + q) * a.ld + i];
+        }
+        double di = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) di += q8[q];
+        a.d[i] = di;
+        if (i < a.N) s += di + (a.gfix ? a.gfix[i] : 0.0);
+    }
     const double mean = block_allreduce_sum(s, red, 16) / (double)a.N;
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < a.ld; i += 1024) {

@@ -310,13 +310,25 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     acc_n = [0] * n_chains
     tot_n = [0] * n_chains
     target = ndraws + nsamples
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=n_chains + 1)
+
+    def draw_round():
+        """(L, momentum, Metropolis variate) of every chain, each from its own stream in the
+        reference's order; the streams are independent, so they are drawn concurrently."""
+        def one(r):
+            L = r.randint(Lrange[0], Lrange[1] + 1)
+            return L, r.randn(M) * Sigma, r.rand()
+        res = list(pool.map(one, rs))
+        return [a for a, _, _ in res], [b for _, b, _ in res], [c for _, _, c in res]
+
+    nxt = draw_round()
     while min(acc_n) < target:
-        Ls, p0s, us = [], [], []
-        for r in rs:
-            Ls.append(r.randint(Lrange[0], Lrange[1] + 1))
-            p0s.append(r.randn(M) * Sigma)
-            us.append(r.rand())
-        accepted, out5 = eng.batch_trajectory(np.stack(p0s), delta, Ls, us)
+        Ls, p0s, us = nxt
+        # the next round is drawn on the host while the GPU runs this one
+        fut = pool.submit(eng.batch_trajectory, np.stack(p0s), delta, Ls, us)
+        nxt = draw_round()
+        accepted, out5 = fut.result()
         for c in range(n_chains):
             if acc_n[c] >= target:
                 continue
@@ -342,4 +354,5 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
                   "-- accept ratio {:.2%}\n".format(ranks[c], acc_n[c] / target, Un, Udn, alpha, Umn,
                                                     acc_n[c] / tot_n[c]))
         sys.stdout.flush()
+    pool.shutdown(wait=False)
     return acc_n, tot_n
