@@ -8,8 +8,8 @@ trajectories) runs in hand-written HIP kernels behind the C-ABI of include/gravh
 from . import constants, mesher  # noqa: F401
 from .engine import DeviceMatrix, Engine  # noqa: F401
 from .gravmag import prism, tesseroid  # noqa: F401
-from .inversion import (ConjugateGradient, GravMagModule, HamitonianMC, HMCSample,  # noqa: F401
+from .inversion import (BootStrap, ConjugateGradient, GravMagModule, HamitonianMC, HMCSample,  # noqa: F401
                         HMCSampleBatch)
 
 __all__ = ["constants", "mesher", "prism", "tesseroid", "Engine", "DeviceMatrix",
-           "GravMagModule", "HamitonianMC", "HMCSample", "HMCSampleBatch", "ConjugateGradient"]
+           "GravMagModule", "HamitonianMC", "HMCSample", "HMCSampleBatch", "ConjugateGradient", "BootStrap"]

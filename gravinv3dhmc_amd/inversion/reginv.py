@@ -184,3 +184,131 @@ class ConjugateGradient(object):
         model_inv = self.WmInv @ mw_new
         data_inv = self._engine.forward(mw_new)   # = A @ model_inv (reginv.py:490)
         return model_inv, data_inv, data_misfit, model_misfit, regul_factor
+
+
+class BootStrap(object):
+    """Bootstrap of the observations around the CG inversion (mirror of reginv.py:494-755).
+
+    The reference builds, for every replicate, a row-resampled copy of the weighted kernel
+    (`AwSample[i, :] = Aw[indexSample[i], :]`, reginv.py:736-741).  Sampling rows with
+    replacement is the same as weighting row r by the number of times it was drawn:
+        |Aw_s v - d_s|^2 = sum_r c_r (Aw[r].v - d[r])^2,   Aw_s^T (Aw_s v - d_s) = Aw^T (c * (Aw v - d))
+    so the resident kernel is used as it is (no second matrix, no gather), with the count vector
+    c applied to the N-vector between the forward and the adjoint sweep.  MS stabiliser of that
+    class: no prior, beta squared (reginv.py:599-629)."""
+
+    def __init__(self, mrange, mspacing, obsurface, dobs, boundary, samples=100, beta=0.01, maxk=100,
+                 mratio=1, njobs=1, wavelet=False, device=0, verbose=True, **kwargs):
+        if wavelet:
+            raise NotImplementedError("BootStrap with a wavelet-compressed forward is not built")
+        self.mrange, self.mspacing, self.mratio = mrange, mspacing, mratio
+        self.lonobs, self.latobs, self.heightobs = obsurface[0], obsurface[1], obsurface[2]
+        self.boundary, self.samples, self.njobs = boundary, samples, njobs
+        self.dobs = np.asarray(dobs, dtype=np.float64)
+        self.maxk, self.beta, self.wavelet = maxk, beta, wavelet
+        say = print if verbose else (lambda *a, **k: None)
+        say("Calculating gravity field using prism.")
+        mesh = mesher.PrismMesh(mrange, mspacing, mratio)
+        for _key, value in kwargs.items():
+            self.mask = mesh.carvetopo(value[0], value[1], value[2])
+        mesh.addprop('density', np.zeros(mesh.size))
+        self.mesh = mesh
+        bounds = mesh.cell_bounds(active_only=True)
+        start = time.time()
+        eng = Engine(int(np.asarray(self.lonobs).size), bounds.shape[0], device=device)
+        eng.set_obs(self.lonobs, self.latobs, self.heightobs)
+        eng.set_cells(bounds, _lib.CELL_PRISM)
+        eng.build_G()
+        say("End of calculate kernel:", time.time() - start)
+        self._engine = eng
+        self.mshape = mesh.shape
+        self.dsize, self.msize = eng.N, eng.M
+        self.mxs, self.mys, self.mzs = mesh.get_xs(), mesh.get_ys(), mesh.get_zs()
+        wm = eng.weight(0.5)
+        with np.errstate(divide='ignore'):
+            inv = 1.0 / wm
+        self.Wm, self.WmInv, self.WmSquare = _diag(wm), _diag(inv), _diag(wm * wm)
+        self.Aw = DeviceMatrix(eng)
+        self._zero = np.zeros(eng.M)
+
+    # terms of one replicate: `counts[r]` = how often observation r was drawn
+    def data(self, mw, counts, dobs):
+        res = self._engine.forward(mw) - dobs
+        return float(np.sum(counts * res * res))
+
+    def data_gfun(self, mw, counts, dobs):
+        return 2 * self._engine.adjoint(counts * (self._engine.forward(mw) - dobs))
+
+    def model_MS(self, mw):
+        return self._engine.reg_eval("MS", mw, self._zero, self.beta ** 2, self.mshape, want_grad=False)[0]
+
+    def model_gfun_MS(self, mw):
+        return self._engine.reg_eval("MS", mw, self._zero, self.beta ** 2, self.mshape)[1]
+
+    def CG(self, counts, dobs, initialModel):
+        """One replicate (reginv.py:631-713); `counts` replaces the resampled kernel."""
+        mw = self.Wm @ initialModel
+        rhomin, rhomax = self.boundary[0], self.boundary[1]
+        q = 0.9
+        data_misfit, model_misfit, regul_factor = [], [], []
+
+        def step(mw_, I_, Iw_, alpha_):
+            fw = self._engine.forward(Iw_)
+            kstep = np.dot(Iw_.T, I_) / (np.sum(counts * fw * fw) + alpha_ * np.linalg.norm(Iw_) ** 2)
+            mtemp = self.WmInv @ (mw_ - kstep * Iw_)
+            mtemp[mtemp < rhomin] = rhomin
+            mtemp[mtemp > rhomax] = rhomax
+            return self.Wm @ mtemp
+
+        mw_new = mw
+        for k in range(0, self.maxk):
+            if k == 0:
+                alpha = 0
+            elif k == 1:
+                alpha = self.data(mw_new, counts, dobs) / self.model_MS(mw_new)
+            else:
+                d_old = self.data(mw, counts, dobs)
+                if d_old - self.data(mw_new, counts, dobs) < 0.01 * d_old:
+                    alpha = q * alpha
+            regul_factor.append(alpha)
+            if k == 0:
+                I = self.data_gfun(mw, counts, dobs) + alpha * self.model_gfun_MS(mw)
+                Iw = I
+                mw_new = step(mw, I, Iw, alpha)
+            if k > 0:
+                I_old, Iw_old = I, Iw
+                mw = mw_new
+                I = self.data_gfun(mw, counts, dobs) + alpha * self.model_gfun_MS(mw)
+                mu = np.linalg.norm(I) ** 2 / np.linalg.norm(I_old) ** 2
+                Iw = I + mu * Iw_old
+                mw_new = step(mw, I, Iw, alpha)
+                d_new = self.data(mw_new, counts, dobs)
+                if d_new < 0.1:
+                    print("Data error is {} < 0.1, stop iteration!".format(d_new))
+                    break
+                data_misfit.append(d_new / self.dsize)
+                m_new = self.model_MS(mw_new) / self.msize
+                model_misfit.append(m_new)
+                print(d_new / self.dsize)
+                print(m_new)
+            print("CG iteration: ", k)
+        return self.WmInv @ mw_new, data_misfit, model_misfit, regul_factor
+
+    def BSCG(self, initialModel):
+        """`samples` replicates, replicate s drawn with np.random.seed(s) (reginv.py:715-755)."""
+        model_inv_all = np.zeros((self.samples, self.msize))
+        data_misfit_all = np.zeros((self.samples, self.maxk - 1))
+        model_misfit_all = np.zeros((self.samples, self.maxk - 1))
+        regul_factor_all = np.zeros((self.samples, self.maxk))
+        for sample in range(self.samples):
+            print("*********Sample {}*********".format(sample + 1))
+            np.random.seed(sample)
+            index = np.arange(0, self.dsize)
+            indexSample = np.random.choice(index, size=self.dsize, replace=True, p=None)
+            counts = np.bincount(indexSample, minlength=self.dsize).astype(np.float64)
+            model_inv, data_misfit, model_misfit, regul_factor = self.CG(counts, self.dobs, initialModel)
+            model_inv_all[sample, :] = model_inv
+            data_misfit_all[sample, :] = data_misfit
+            model_misfit_all[sample, :] = model_misfit
+            regul_factor_all[sample, :] = regul_factor
+        return model_inv_all, data_misfit_all, model_misfit_all, regul_factor_all

@@ -76,3 +76,59 @@ def cg(K, dobs, shape, initialModel, apriorModel, boundary, regularization="MS",
             if dm[-1] < 0.001:
                 break
     return mw_new / wm, Aw @ mw_new, np.array(dm), np.array(mm), np.array(rf, dtype=float)
+
+
+def bootstrap(K, dobs, boundary, initialModel, samples=3, beta=0.01, maxk=5):
+    """inversion/reginv.py:494-755 (BootStrap.BSCG / .CG): CG with the MS variant of that class
+    (no prior, beta squared: :599-629) on row-resampled data, seed = sample index."""
+    Aw, wm = oracle.col_weight(K)
+    N, M = Aw.shape
+    wm2 = wm * wm
+    b2 = beta ** 2
+
+    def run(A, d):
+        data = lambda mw: np.linalg.norm(A @ mw - d) ** 2
+        data_g = lambda mw: 2 * A.T @ (A @ mw - d)
+        model = lambda mw: np.sum(wm2 * mw * mw / (mw * mw + b2))
+        model_g = lambda mw: 2 * wm2 * (mw * b2) / (mw * mw + b2) ** 2
+
+        def step(mw, I, Iw, alpha):
+            kstep = (Iw @ I) / (np.linalg.norm(A @ Iw) ** 2 + alpha * np.linalg.norm(Iw) ** 2)
+            m = (mw - kstep * Iw) / wm
+            m[m < boundary[0]] = boundary[0]
+            m[m > boundary[1]] = boundary[1]
+            return wm * m
+
+        mw = wm * initialModel
+        dm, mm, rf = [], [], []
+        for k in range(maxk):
+            if k == 0:
+                alpha = 0
+            elif k == 1:
+                alpha = data(mw_new) / model(mw_new)
+            elif data(mw) - data(mw_new) < 0.01 * data(mw):
+                alpha = 0.9 * alpha
+            rf.append(alpha)
+            if k == 0:
+                I = data_g(mw) + alpha * model_g(mw)
+                Iw = I
+                mw_new = step(mw, I, Iw, alpha)
+            else:
+                I_old, Iw_old = I, Iw
+                mw = mw_new
+                I = data_g(mw) + alpha * model_g(mw)
+                Iw = I + (np.linalg.norm(I) ** 2 / np.linalg.norm(I_old) ** 2) * Iw_old
+                mw_new = step(mw, I, Iw, alpha)
+                if data(mw_new) < 0.1:
+                    break
+                dm.append(data(mw_new) / N)
+                mm.append(model(mw_new) / M)
+        return mw_new / wm, dm, mm, rf
+
+    models = np.zeros((samples, M))
+    dms, mms, rfs = np.zeros((samples, maxk - 1)), np.zeros((samples, maxk - 1)), np.zeros((samples, maxk))
+    for s in range(samples):
+        np.random.seed(s)
+        idx = np.random.choice(np.arange(N), size=N, replace=True, p=None)
+        models[s], dms[s], mms[s], rfs[s] = run(Aw[idx, :], dobs[idx])
+    return models, dms, mms, rfs

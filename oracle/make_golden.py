@@ -419,6 +419,23 @@ def cg_small(R):
     np.savez_compressed(os.path.join(GOLD, "cg_small.npz"), **out)
 
 
+def bs_small(R):
+    """The reference's BootStrap.BSCG (inversion/reginv.py:494-755) on the small prism problem."""
+    from inversion import reginv
+    from oracle import cg_port
+    g = np.load(os.path.join(GOLD, "cg_small.npz"))
+    mrange, mspacing = tuple(g["mrange"]), tuple(g["mspacing"])
+    bs = _quiet(reginv.BootStrap, mrange, mspacing, (g["xp"], g["yp"], g["zp"]), g["dobs"], (0.0, 1.0),
+                samples=3, beta=0.1, maxk=5)
+    M = bs.msize
+    res = _quiet(bs.BSCG, np.full(M, 0.001))
+    po = cg_port.bootstrap(g["K"], g["dobs"], (0.0, 1.0), np.full(M, 0.001), samples=3, beta=0.1, maxk=5)
+    for a_, b_ in zip(res, po):
+        assert _relmax(b_, a_) < 1e-9, _relmax(b_, a_)
+    np.savez_compressed(os.path.join(GOLD, "bs_small.npz"), models=res[0], dmis=res[1], mmis=res[2], alpha=res[3])
+    print("bs_small", res[0].shape, res[1][:, -1])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     R = ref_harness.load()
@@ -437,6 +454,7 @@ def main():
     example_inputs(R)
     c1_leapfrog_rows(R, xp, yp, zp)
     cg_small(R)
+    bs_small(R)
     print("golden fixtures written to", GOLD)
 
 

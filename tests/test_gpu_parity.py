@@ -994,3 +994,15 @@ def test_global_c4_full_kernel_against_reference_log(G, orc):
         assert abs(np.linalg.norm(d) - 1.0) < 1e-12
         assert relmax(d, Ko[:, list(cols).index(j)] / wm[j]) < 1e-10
     gm._engine.close()
+
+
+def test_bootstrap_matches_reference(G, capsys):
+    """BootStrap.BSCG (row counts on the resident kernel instead of a resampled copy) against the
+    reference's own run (tests/golden/bs_small.npz, inversion/reginv.py:715-755)."""
+    g, b = gold("cg_small.npz"), gold("bs_small.npz")
+    bs = G.BootStrap(tuple(g["mrange"]), tuple(g["mspacing"]), (g["xp"], g["yp"], g["zp"]), g["dobs"],
+                     (0.0, 1.0), samples=3, beta=0.1, maxk=5, verbose=False)
+    res = bs.BSCG(np.full(bs.msize, 0.001))
+    capsys.readouterr()
+    for name, v in zip(("models", "dmis", "mmis", "alpha"), res):
+        assert relmax(v, b[name]) < 1e-7, name

@@ -294,3 +294,12 @@ def test_global_log_initial_mw_columns():
     mw = 0.01 * np.sqrt((K ** 2).sum(0))
     np.testing.assert_allclose(mw[:3], GLOBAL_MW_HEAD, rtol=5e-9)
     np.testing.assert_allclose(mw[3:], GLOBAL_MW_TAIL, rtol=0, atol=5.1e-9)   # 8 decimals printed
+
+
+def test_bootstrap_port_matches_reference_golden():
+    from oracle import cg_port
+    g, b = gold("cg_small.npz"), gold("bs_small.npz")
+    M = int(np.prod(g["shape"]))
+    res = cg_port.bootstrap(g["K"], g["dobs"], (0.0, 1.0), np.full(M, 0.001), samples=3, beta=0.1, maxk=5)
+    for name, v in zip(("models", "dmis", "mmis", "alpha"), res):
+        assert relmax(v, b[name]) < 1e-9, name
