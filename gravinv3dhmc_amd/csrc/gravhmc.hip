@@ -292,8 +292,10 @@ static int configure_sweep(gh_ctx *c)
     if (e == 7) e = 8;
     c->TW = tw;
     c->EPT2 = e;
-    // two columns in flight per team where the registers allow it (16-wave teams: 122 VGPRs)
-    c->PF = env_int("GRAVHMC_PF", tw == 16 ? 2 : 1) == 2 ? 2 : 1;
+    // two columns in flight per team where the registers allow it (16-wave teams with <= 5 double2
+    // per thread: 122 VGPRs, no spills; measured at 6 and 8 double2: 5.4 / 3.1 TB/s against 6.5 / 6.1
+    // with one column in flight)
+    c->PF = env_int("GRAVHMC_PF", (tw == 16 && e <= 5) ? 2 : 1) == 2 ? 2 : 1;
     // G larger than the Infinity Cache is streamed once per sweep: bypass-friendly loads
     c->NT = env_int("GRAVHMC_NT", c->ld * c->M * 8 > (int64_t)(512 << 20) ? 1 : 0) != 0;
     const int wg_teams = (tw == 1) ? 4 : 1;
