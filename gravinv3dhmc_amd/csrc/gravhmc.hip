@@ -3,6 +3,7 @@
 #include "../../include/gravhmc.h"
 #include "kernels.hip.h"
 #include "batch.hip.h"
+#include "resident.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -138,6 +139,24 @@ struct gh_ctx {
         bool ready = false;
         int64_t sweeps = 0;
     } bt;
+
+    // resident chain kernel (resident.hip.h): G held in LDS across a whole batch of trajectories
+    struct Resident {
+        int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
+        int cpw = 0, nwg = 0, nred = 0, rc = 0;
+        size_t lds = 0;
+        ghk::u64 *slabg = nullptr, *dsumg = nullptr, *scalg = nullptr, *doneg = nullptr;
+        double *xpub = nullptr;
+        unsigned *abort_w = nullptr;
+        unsigned tag = 0, tagE = 0;  // granule tags used so far (the buffers keep them across launches)
+        int Kcap = 0;
+        int *L = nullptr, *accepted = nullptr, *n_run = nullptr;
+        double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
+        int64_t launches = 0, evals = 0;
+        long long *dbg = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    } rs;
+    int64_t prof_res_evals = 0;
 
     // ring of the last K accepted samples (posterior statistics without text I/O)
     double *ring = nullptr, *ring_mean = nullptr, *ring_sd = nullptr;
@@ -859,6 +878,8 @@ void gh_destroy(gh_ctx *c)
     for (void *p : c->allocs) hipFree(p);
     if (c->h_scal) hipHostFree(c->h_scal);
     for (hipEvent_t ev : c->ev) hipEventDestroy(ev);
+    if (c->rs.ev0) hipEventDestroy(c->rs.ev0);
+    if (c->rs.ev1) hipEventDestroy(c->rs.ev1);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1583,6 +1604,208 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     return GH_OK;
 }
 
+typedef void (*resident_fn)(ResArgs);
+
+static resident_fn resident_for(int rc)
+{
+    switch (rc) {
+    case 1: return resident_chain_kernel<1>;
+    case 2: return resident_chain_kernel<2>;
+    case 3: return resident_chain_kernel<3>;
+    case 4: return resident_chain_kernel<4>;
+    case 5: return resident_chain_kernel<5>;
+    case 6: return resident_chain_kernel<6>;
+    case 7: return resident_chain_kernel<7>;
+    case 8: return resident_chain_kernel<8>;
+    }
+    return nullptr;
+}
+
+// Can this problem run on the resident chain kernel?  Dense stored G on one device, N <= 1024,
+// and one column block per CU that fits the CU's LDS next to the kernel's scratch.
+static bool resident_plan(gh_ctx *c)
+{
+    gh_ctx::Resident &r = c->rs;
+    if (r.state != 0) return r.state > 0;
+    r.state = -1;
+    if (env_int("GRAVHMC_RESIDENT", 1) == 0) return false;
+    if (c->mf || c->wv.on || c->sh.kind != 0 || c->n_panels != 1 || c->ld > 1024 || !c->G) return false;
+    int coop = 0, lds_max = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) != hipSuccess || !coop)
+        return false;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess)
+        return false;
+    const int cpw = (int)((c->M + c->cus - 1) / c->cus);
+    const size_t lds = resident_lds_doubles(c->ld, cpw) * sizeof(double);
+    if (lds > (size_t)lds_max || cpw > RES_THREADS) return false;
+    r.cpw = cpw;
+    r.nwg = (int)((c->M + cpw - 1) / cpw);
+    r.nred = (int)((c->ld + RES_RED_ROWS - 1) / RES_RED_ROWS);
+    if (r.nred > r.nwg || r.nwg > RES_MAX_WG) return false;  // every reducer is a workgroup of the grid
+    r.rc = (int)((c->ld / 2 + 63) / 64);
+    r.lds = lds;
+    resident_fn f = resident_for(r.rc);
+    if (!f) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), RES_THREADS,
+                                                     lds) != hipSuccess || per_cu < 1 ||
+        (int64_t)per_cu * c->cus < r.nwg) {
+        (void)hipGetLastError();
+        return false;
+    }
+    r.state = 1;
+    return true;
+}
+
+// K trajectories in one cooperative launch (same contract as gh_chain_run)
+static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
+                              int64_t stop_at_accepts, int64_t record_from, int *accepted, double *out5s,
+                              double *x_out, int *n_run)
+{
+    gh_ctx::Resident &r = c->rs;
+    const size_t M = (size_t)c->M;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!r.slabg) {
+        TRY(dalloc(c, &r.slabg, (size_t)r.nwg * (size_t)c->ld * 2));
+        TRY(dalloc(c, &r.dsumg, (size_t)c->ld * 2));
+        TRY(dalloc(c, &r.scalg, (size_t)r.nwg * 8));
+        TRY(dalloc(c, &r.doneg, (size_t)r.nred));
+        TRY(dalloc(c, &r.xpub, 2 * M));
+        TRY(dalloc(c, &r.abort_w, 4));
+        TRY(dalloc(c, &r.n_run, 4));
+        if (env_int("GRAVHMC_RESIDENT_TIMING", 0)) TRY(dalloc(c, &r.dbg, 32));
+        HIPCHK(c, hipEventCreate(&r.ev0));
+        HIPCHK(c, hipEventCreate(&r.ev1));
+    }
+    if (K > r.Kcap) {
+        // grown rarely (the host batches a fixed number of trajectories per call); the old blocks
+        // stay in the context's allocation list until gh_destroy
+        const int cap = std::max(K, 32);
+        r.L = nullptr;
+        r.accepted = nullptr;
+        r.p0s = r.us = r.out5s = r.xacc = nullptr;
+        TRY(dalloc(c, &r.L, (size_t)cap));
+        TRY(dalloc(c, &r.accepted, (size_t)cap));
+        TRY(dalloc(c, &r.p0s, (size_t)cap * M, false));
+        TRY(dalloc(c, &r.us, (size_t)cap));
+        TRY(dalloc(c, &r.out5s, (size_t)cap * 5));
+        TRY(dalloc(c, &r.xacc, (size_t)cap * M, false));
+        r.Kcap = cap;
+    }
+    const bool want_x = x_out != nullptr || c->ring != nullptr;
+    int64_t steps = 0;
+    for (int k = 0; k < K; ++k) steps += L[k];
+    if ((uint64_t)r.tag + (uint64_t)steps + 2 > 0xf0000000ull || (uint64_t)r.tagE + (uint64_t)K + 2 > 0xf0000000ull) {
+        // 32-bit tags about to wrap: start the count again on zeroed granules
+        HIPCHK(c, hipMemsetAsync(r.slabg, 0, (size_t)r.nwg * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.dsumg, 0, (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.scalg, 0, (size_t)r.nwg * 8 * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.doneg, 0, (size_t)r.nred * sizeof(ghk::u64), c->stream));
+        r.tag = r.tagE = 0;
+    }
+    HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemcpyAsync(r.p0s, p0s, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(r.us, us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(r.L, L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    ResArgs a{};
+    a.G = c->G;
+    a.ld = c->ld;
+    a.N = c->N;
+    a.M = c->M;
+    a.cols_per_wg = r.cpw;
+    a.nwg = r.nwg;
+    a.nred = r.nred;
+    a.gfix = c->have_fix ? c->gfix : nullptr;
+    a.dobs_c = c->dobs_c;
+    a.low = c->low;
+    a.high = c->high;
+    a.kind = c->reg_kind;
+    a.nz = c->shape[0];
+    a.ny = c->shape[1];
+    a.nx = c->shape[2];
+    a.alpha = c->alpha;
+    a.beta = c->beta;
+    a.mwapr = c->mwapr;
+    a.wm2 = c->wm2;
+    a.x_cur = c->xb[c->xcur];
+    a.K = K;
+    a.L = r.L;
+    a.p0s = r.p0s;
+    a.us = r.us;
+    a.dt = dt;
+    a.stop_at_accepts = stop_at_accepts;
+    a.accept_count0 = c->accept_count;
+    a.accepted = r.accepted;
+    a.out5s = r.out5s;
+    a.xacc = want_x ? r.xacc : nullptr;
+    a.n_run = r.n_run;
+    a.slabg = r.slabg;
+    a.dsumg = r.dsumg;
+    a.scalg = r.scalg;
+    a.doneg = r.doneg;
+    a.xpub = r.xpub;
+    a.tag0 = r.tag;
+    a.tagE0 = r.tagE;
+    a.abort_w = r.abort_w;
+    a.dbg = r.dbg;
+    void *params[] = {&a};
+    if (c->prof) HIPCHK(c, hipEventRecord(r.ev0, c->stream));
+    HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void *>(resident_for(r.rc)), dim3(r.nwg),
+                                         dim3(RES_THREADS), params, (unsigned)r.lds, c->stream));
+    if (c->prof) HIPCHK(c, hipEventRecord(r.ev1, c->stream));
+    unsigned h_sync[4] = {0, 0, 0, 0};
+    int h_run[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(h_sync, r.abort_w, sizeof h_sync, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_run, r.n_run, sizeof h_run, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(accepted, r.accepted, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out5s, r.out5s, (size_t)K * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_sync[0] != 0u) {
+        // tags of an aborted launch are in an unknown state: start again on zeroed granules
+        r.tag = r.tagE = 0xf0000000u;
+        return fail(c, GH_ERR_HIP, "resident chain kernel: a workgroup timed out waiting for the others "
+                                   "(is another process holding compute units of this device?)");
+    }
+    r.tag += (unsigned)h_run[1];
+    r.tagE += (unsigned)h_run[2];
+    r.launches += 1;
+    r.evals += h_run[1];
+    if (c->prof) {
+        float t = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&t, r.ev0, r.ev1));
+        c->prof_ms_acc += t;
+        c->prof_res_evals += h_run[1];
+    }
+    *n_run = h_run[0];
+    for (int k = 0; k < h_run[0]; ++k) {
+        if (!accepted[k]) continue;
+        c->accept_count += 1;
+        if (c->ring && c->accept_count > record_from) {
+            ring_store_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
+                r.xacc + (size_t)k * M, c->weighted ? c->wm : nullptr, c->M,
+                c->ring + (size_t)c->ring_next * M);
+            c->ring_next = (c->ring_next + 1) % c->ring_K;
+            c->ring_count += 1;
+        }
+        if (x_out)
+            HIPCHK(c, hipMemcpyAsync(x_out + (size_t)k * M, r.xacc + (size_t)k * M, M * sizeof(double),
+                                     hipMemcpyDeviceToHost, c->stream));
+    }
+    // bring the per-launch state (d, r, scalars of the current sample) back in step with x
+    c->spec_valid = c->pn_valid = false;
+    TRY(eval_forward(c, c->xb[c->xcur], c->st[c->cur]));
+    TRY(d2h(c, c->h_scal, c->st[c->cur].scal, 4));
+    c->U_cur[0] = c->h_scal[2];
+    c->U_cur[1] = c->h_scal[0];
+    c->U_cur[2] = c->h_scal[1];
+    return GH_OK;
+}
+
 int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
                  const double *p0_lookahead, int64_t stop_at_accepts, int64_t record_from, int *accepted,
                  double *out5s, double *x_out, int *n_run)
@@ -1592,6 +1815,18 @@ int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double
     TRY(need(c, c->chain_ready, "gh_chain_run: call gh_chain_init first"));
     const size_t M = (size_t)c->M;
     *n_run = 0;
+    if (resident_plan(c)) {
+        int64_t steps = 0;
+        bool ok = true;
+        for (int k = 0; k < K; ++k) {
+            if (L[k] < 1) return fail(c, GH_ERR_ARG, "gh_chain_run: L must be >= 1");
+            steps += L[k];
+        }
+        ok = steps < ((int64_t)1 << 28);  // granule tags are 32-bit
+        if (ok)
+            return chain_run_resident(c, K, L, p0s, us, dt, stop_at_accepts, record_from, accepted, out5s,
+                                      x_out, n_run);
+    }
     for (int k = 0; k < K; ++k) {
         const double *nxt = (k + 1 < K) ? p0s + (size_t)(k + 1) * M : p0_lookahead;
         if (nxt) TRY(gh_chain_prefetch_momentum(c, nxt));
@@ -1974,6 +2209,18 @@ int gh_leapfrog(gh_ctx *c, double *x_inout, const double *p0, double dt, int L, 
 }
 
 // Diagnostic (not in the public header): time a pure streaming read of the resident G.
+int gh_debug_resident_timing(gh_ctx *c, long long out32[32], int64_t *launches, int64_t *evals)
+{
+    if (!c || !out32) return GH_ERR_ARG;
+    if (launches) *launches = c->rs.launches;
+    if (evals) *evals = c->rs.evals;
+    for (int i = 0; i < 32; ++i) out32[i] = 0;
+    if (!c->rs.dbg) return GH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out32, c->rs.dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+
 int gh_debug_stream_read(gh_ctx *c, int blocks, int threads, int nt, int reps, double *ms_out)
 {
     if (!c || !c->have_G) return GH_ERR_ARG;
@@ -2068,6 +2315,7 @@ int gh_profile_enable(gh_ctx *c, int enable)
     c->ev_used = 0;
     c->prof_ms_acc = 0.0;
     c->prof_launches = 0;
+    c->prof_res_evals = 0;
     return GH_OK;
 }
 
@@ -2083,7 +2331,8 @@ int gh_profile_read(gh_ctx *c, double *sweep_ms, int64_t *sweep_launches, int64_
         ms += t;
     }
     // launches beyond the event pool are counted but not timed: scale to the timed share
-    const int64_t timed = (int64_t)(c->ev_used / 2);
+    // (an evaluation inside the resident chain kernel counts as one sweep)
+    const int64_t timed = (int64_t)(c->ev_used / 2) + c->prof_res_evals;
     if (sweep_ms) *sweep_ms = ms;
     if (sweep_launches) *sweep_launches = timed;
     // one launch reads one row panel of G (the whole matrix when N <= 16384)

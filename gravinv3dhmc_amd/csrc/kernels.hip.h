@@ -354,56 +354,62 @@ struct RegArgs {
     double *regpart;  // per-block partial of R
 };
 
-// Regulariser value + gradient at x (potential.py:719-736, 775-810) as a stencil; the
-// finite-difference operator of potential.py:266-361 is never materialised.  `blk`: index of the
-// 256-cell block, `red`: 4 doubles of LDS.
+// Regulariser term of cell j at the model a.x (own value xj = a.x[j] passed in; neighbours of the
+// stencil kinds are read from a.x): returns dR/dx_j, adds the cell's share of R to `val`
+// (potential.py:719-736, 775-810).  The finite-difference operator of potential.py:266-361 is never
+// materialised.
+__device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double xj, double &val)
+{
+    const double v = xj - a.mwapr[j];
+    double g = 0.0;
+    if (a.kind == 0) {  // Damping
+        val = v * v;
+        g = 2.0 * v;
+    } else if (a.kind == 2) {  // MS
+        const double v2 = v * v, den = v2 + a.beta, w2 = a.wm2[j];
+        val = (w2 * v2) / den;
+        const double deng = a.ms_grad_den_mw ? xj * xj + a.beta : den;
+        g = (2.0 * a.beta * w2 * v) / (deng * deng);
+    } else {  // Smoothness (1) / TV (3)
+        const int64_t nx = a.nx, ny = a.ny, nz = a.nz;
+        const int64_t i = j % nx, jj = (j / nx) % ny, k = j / (nx * ny);
+        const int64_t stride[3] = {1, nx, nx * ny};
+        const bool fwd[3] = {i < nx - 1, jj < ny - 1, k < nz - 1};
+        const bool bwd[3] = {i > 0, jj > 0, k > 0};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            if (fwd[ax]) {
+                const int64_t q = j + stride[ax];
+                const double t = v - (a.x[q] - a.mwapr[q]);
+                if (a.kind == 1) {
+                    val += t * t;
+                    g += 2.0 * t;
+                } else {
+                    const double s = sqrt(t * t + a.beta);
+                    val += s;
+                    g += t / s;
+                }
+            }
+            if (bwd[ax]) {
+                const int64_t q = j - stride[ax];
+                const double t = (a.x[q] - a.mwapr[q]) - v;
+                if (a.kind == 1)
+                    g -= 2.0 * t;
+                else
+                    g -= t / sqrt(t * t + a.beta);
+            }
+        }
+    }
+    return g;
+}
+
+// Regulariser value + gradient of one 256-cell block.  `blk`: index of the block, `red`: 4
+// doubles of LDS.
 __device__ __forceinline__ void reg_block(const RegArgs &a, int blk, double *red)
 {
     const int64_t j = (int64_t)blk * 256 + threadIdx.x;
     double val = 0.0;
-    if (j < a.M) {
-        const double v = a.x[j] - a.mwapr[j];
-        double g = 0.0;
-        if (a.kind == 0) {  // Damping
-            val = v * v;
-            g = 2.0 * v;
-        } else if (a.kind == 2) {  // MS
-            const double v2 = v * v, den = v2 + a.beta, w2 = a.wm2[j];
-            val = (w2 * v2) / den;
-            const double deng = a.ms_grad_den_mw ? a.x[j] * a.x[j] + a.beta : den;
-            g = (2.0 * a.beta * w2 * v) / (deng * deng);
-        } else {  // Smoothness (1) / TV (3)
-            const int64_t nx = a.nx, ny = a.ny, nz = a.nz;
-            const int64_t i = j % nx, jj = (j / nx) % ny, k = j / (nx * ny);
-            const int64_t stride[3] = {1, nx, nx * ny};
-            const bool fwd[3] = {i < nx - 1, jj < ny - 1, k < nz - 1};
-            const bool bwd[3] = {i > 0, jj > 0, k > 0};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                if (fwd[ax]) {
-                    const int64_t q = j + stride[ax];
-                    const double t = v - (a.x[q] - a.mwapr[q]);
-                    if (a.kind == 1) {
-                        val += t * t;
-                        g += 2.0 * t;
-                    } else {
-                        const double s = sqrt(t * t + a.beta);
-                        val += s;
-                        g += t / s;
-                    }
-                }
-                if (bwd[ax]) {
-                    const int64_t q = j - stride[ax];
-                    const double t = (a.x[q] - a.mwapr[q]) - v;
-                    if (a.kind == 1)
-                        g -= 2.0 * t;
-                    else
-                        g -= t / sqrt(t * t + a.beta);
-                }
-            }
-        }
-        a.greg[j] = a.alpha * g;
-    }
+    if (j < a.M) a.greg[j] = a.alpha * reg_cell(a, j, a.x[j], val);
     const double tot = block_allreduce_sum(val, red, 4);
     if (threadIdx.x == 0) a.regpart[blk] = tot;
 }

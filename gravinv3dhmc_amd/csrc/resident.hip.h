@@ -1,0 +1,593 @@
+// Resident chain kernel (gfx950): a whole batch of HMC trajectories in ONE launch for sensitivity
+// matrices small enough to live in the chip's LDS (256 CUs x 160 KB: N*M*8 <= ~36 MB, N <= 1024 --
+// the reference's uniformgrid example and BASELINE configs[0], 600 x 6000).
+//
+// At that size the sweep-per-launch path is bound by launches and by re-reading G from L2/MALL
+// (3 launches, ~30 us per leapfrog step at C1), not by HBM.  Here every workgroup owns a fixed
+// block of columns (cells), loads them into LDS once per launch and keeps them there; per
+// leapfrog step only N-vectors cross the chip:
+//
+//   local              wave-per-column dots <G_j, r> -> gradient -> momentum/position update with
+//                      clamp-and-reflect (hmc.py:114-152); thread-per-row forward partial
+//                      sum_j G_ij x_j over the workgroup's columns
+//   hop A              the partials are published as tagged granules; `nred` reducer workgroups
+//                      sum 8 rows each over all workgroups in a fixed order -> d, published likewise
+//   hop B              every workgroup reads d, removes the mean and forms r redundantly
+//                      (potential.py:700-706: identical bits everywhere), evaluates the regulariser
+//                      gradient of its own cells
+//   trajectory end     last half momentum step, one all-gather of three scalars per workgroup
+//                      (R, p'p before/after), Metropolis test (hmc.py:158-177) decided identically
+//                      by every workgroup; the gradient at the proposal is kept for the next
+//                      trajectory, so a trajectory of L steps costs exactly L evaluations
+//
+// Inter-workgroup hand-offs: the data is the flag.  A double travels as two naturally aligned
+// 8-byte granules {tag = evaluation number, 32 bits of the value}, each written by ONE
+// write-through (sc1) store and read by sc1 loads that bypass the reader's L1; a reader re-reads
+// its granules until every tag is the evaluation it waits for.  No counters, no fences, no
+// barrier on the hot path; a buffer is only overwritten after every reader has published
+// something that depends on having read it.  (First version: arrival counters + agent acquire,
+// 2 x ~5 us per evaluation; this form: see DESIGN.md.)  Every spin is bounded: on a time-out the
+// abort word is raised, every workgroup leaves and the host reports the failure.  The launch is
+// cooperative (all workgroups resident: one per CU by the LDS request).
+#pragma once
+#include "kernels.hip.h"
+
+namespace ghk {
+
+constexpr int RES_THREADS = 512;
+constexpr int RES_WAVES = 8;
+constexpr int RES_RED_ROWS = 8;                       // rows of d one reducer workgroup sums
+constexpr int RES_MAX_WG = 256;                       // four partials per reducer thread
+constexpr long long RES_TIMEOUT_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock, per wait
+
+using u64 = unsigned long long;
+
+struct ResArgs {
+    const double *G;
+    int64_t ld, N, M;
+    int cols_per_wg, nwg, nred;
+    const double *gfix, *dobs_c, *low, *high;
+    // regulariser (x is set per evaluation inside the kernel)
+    int kind, nz, ny, nx;
+    double alpha, beta;
+    const double *mwapr, *wm2;
+    // chain
+    double *x_cur;  // M: in = current model, out = model after the last trajectory run
+    int K;
+    const int *L;
+    const double *p0s;  // K x M momenta, drawn by the host in the reference's order
+    const double *us;   // K uniforms of the Metropolis test
+    double dt;
+    long long stop_at_accepts, accept_count0;
+    // outputs
+    int *accepted;   // K
+    double *out5s;   // K x {U, U_data, R, H_current, H_proposal}
+    double *xacc;    // K x M accepted models (nullptr: not wanted)
+    int *n_run;      // [0] trajectories run, [1] evaluations, [2] scalar gathers
+    // workspace (granule buffers keep their tags across launches: tag0 / tagE0 continue the count)
+    u64 *slabg;      // nwg x ld x 2 forward partials
+    u64 *dsumg;      // ld x 2
+    u64 *doneg;      // nred: {tag, 1} once a reducer's rows of dsumg are out
+    u64 *scalg;      // nwg x 8 trajectory-end scalars
+    double *xpub;    // 2 x M models as the stencil regularisers see them (Smoothness / TV)
+    unsigned tag0, tagE0;
+    unsigned *abort_w;
+    long long *dbg;  // optional: 2 x 16 accumulated phase times (100 MHz ticks) of the first / last workgroup
+};
+
+static inline size_t resident_lds_doubles(int64_t ld, int cols_per_wg)
+{
+    return (size_t)cols_per_wg * (size_t)ld + (size_t)ld + 64 * RES_RED_ROWS + 16 + 8 * (size_t)cols_per_wg + 8;
+}
+
+// 8-byte write-through store (global_store_dwordx2 sc1)
+__device__ __forceinline__ void st_wt(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<u64 *>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one double as two tagged granules at g[0], g[1]
+__device__ __forceinline__ void st_gran(u64 *g, unsigned tag, double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    __hip_atomic_store(g, ((u64)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, ((u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool ld_gran(u64 *g, unsigned tag, double &v)
+{
+    const u64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+    return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+}
+
+// Every lane of the wave re-reads its granules (try_load: true when all of them carry the tag)
+// until the whole wave has them.  false: timed out or another workgroup raised the abort word.
+template <typename F>
+__device__ __forceinline__ bool res_poll(unsigned *abort_w, F &&try_load)
+{
+    unsigned spins = 0;
+    long long t0 = 0;
+    for (;;) {
+        const bool ok = try_load();
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                now - t0 > RES_TIMEOUT_TICKS) {
+                __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+// v + (v of the lane the DPP control selects; 0 where that lane does not exist or the row is masked)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+// Sum over the 64 lanes on the VALU (row_shr 1/2/4/8 scan inside the rows of 16, row_bcast 15/31
+// across them, total read from lane 63): fixed order, result uniform.  The LDS-crossbar butterfly
+// (ds_bpermute) of wave_allreduce_sum costs ~10x as much when 8 waves reduce several values each.
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+// Workgroup-wide sum (RES_WAVES waves), fixed order, result valid in every thread
+__device__ __forceinline__ double res_block_sum(double v, double *red)
+{
+    v = wave_sum_dpp(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < RES_WAVES; ++q) t += red[q];
+    return t;
+}
+
+// RC = double2 chunks a lane holds of one column / of r: 64*RC*2 >= ld
+template <int RC>
+__global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x;
+    const int ld = (int)a.ld, ld2 = ld >> 1;
+    const int cpw = a.cols_per_wg;
+    const int64_t M = a.M;
+    const int64_t j0 = (int64_t)w * cpw;
+    const int nc = (int)((M - j0 < cpw) ? (M - j0) : cpw);
+    const int nwg = a.nwg, nred = a.nred;
+    const bool stencil = (a.kind == 1 || a.kind == 3);
+
+    double *Gs = smem;                         // cpw x ld
+    double *r_s = Gs + (size_t)cpw * ld;       // ld
+    double *redbuf = r_s + ld;                 // 64 x 8
+    double *red = redbuf + 64 * RES_RED_ROWS;  // 16
+    double *xs = red + 16;                     // position of the running trajectory
+    double *ps = xs + cpw;                     // momentum
+    double *xc = ps + cpw;                     // current sample
+    double *gc = xc + cpw;                     // full gradient at the current sample
+    double *gs = gc + cpw;                     // full gradient at the latest evaluation
+    double *gr = gs + cpw;                     // alpha * dR/dx at the latest evaluation
+    double *lo = gr + cpw;
+    double *hi = lo + cpw;
+    int *flag_s = reinterpret_cast<int *>(hi + cpw);  // 1 while no wave of this workgroup gave up
+    const d2 *Gs2 = reinterpret_cast<const d2 *>(Gs);
+    d2 *r_s2 = reinterpret_cast<d2 *>(r_s);
+
+    int ev = 0, ng = 0;  // evaluations / scalar gathers so far in this launch
+    long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = 0;
+    const bool timing = a.dbg != nullptr && tid == 0 && (w == 0 || w == a.nwg - 1);
+    auto tick = [&](int slot) {
+        if (timing) {
+            const long long now = wall_clock64();
+            tacc[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    if (timing) tlast = wall_clock64();
+
+    // ---- load the workgroup's columns (contiguous in the column-major G) and per-cell vectors
+    {
+        const d2 *src = reinterpret_cast<const d2 *>(a.G + j0 * a.ld);
+        d2 *dst = reinterpret_cast<d2 *>(Gs);
+        const int tot = nc * ld2;
+        for (int e = tid; e < tot; e += RES_THREADS) dst[e] = __builtin_nontemporal_load(src + e);
+    }
+    if (tid < nc) {
+        const int64_t j = j0 + tid;
+        const double x0 = a.x_cur[j];
+        xs[tid] = x0;
+        xc[tid] = x0;
+        ps[tid] = 0.0;
+        lo[tid] = a.low[j];
+        hi[tid] = a.high[j];
+    }
+    if (tid == 0) *flag_s = 1;
+    // rows 2 tid, 2 tid + 1 of the constant data vectors live in registers
+    const int i0 = 2 * tid;
+    d2 gf = d2{0.0, 0.0}, dc = d2{0.0, 0.0};
+    if (tid < ld2) {
+        if (i0 < a.N) {
+            dc.x = a.dobs_c[i0];
+            if (a.gfix) gf.x = a.gfix[i0];
+        }
+        if (i0 + 1 < a.N) {
+            dc.y = a.dobs_c[i0 + 1];
+            if (a.gfix) gf.y = a.gfix[i0 + 1];
+        }
+    }
+
+    // prior model / MS weight of the own cell (thread tid < nc)
+    double apr_j = 0.0, w2_j = 1.0;
+    if (tid < nc) {
+        apr_j = a.mwapr[j0 + tid];
+        if (a.kind == 2) w2_j = a.wm2[j0 + tid];
+    }
+
+    RegArgs ra;
+    ra.ms_grad_den_mw = 0;
+    ra.kind = a.kind;
+    ra.M = M;
+    ra.nz = a.nz;
+    ra.ny = a.ny;
+    ra.nx = a.nx;
+    ra.alpha = a.alpha;
+    ra.beta = a.beta;
+    ra.mwapr = a.mwapr;
+    ra.wm2 = a.wm2;
+    ra.x = nullptr;
+    ra.greg = nullptr;
+    ra.regpart = nullptr;
+
+    // Forward product of xs through both hops: on return r_s holds the residual and gr the
+    // regulariser gradient; with `last` also ud (data misfit) and Rw (this workgroup's share of
+    // R) -- only the end of a trajectory needs the potential itself.  false: aborted.
+    double ud = 0.0, Rw = 0.0;
+    auto evaluate = [&](bool last) -> bool {
+        __syncthreads();  // xs complete
+        tick(0);
+        const unsigned tag = a.tag0 + (unsigned)ev + 1u;
+        const int par = ev & 1;
+        if (stencil) {
+            // neighbours read the model after hop B: the stores are drained before any of this
+            // workgroup's partials (which hop B transitively waits for) is published
+            if (tid < nc) st_wt(a.xpub + (int64_t)par * M + j0 + tid, xs[tid]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (tid < ld2) {
+            d2 acc = d2{0.0, 0.0};
+            for (int c = 0; c < nc; ++c) {
+                const d2 g = Gs2[c * ld2 + tid];
+                const double x = xs[c];
+                acc.x += g.x * x;
+                acc.y += g.y * x;
+            }
+            u64 *out = a.slabg + ((int64_t)w * ld + i0) * 2;
+            st_gran(out, tag, acc.x);
+            st_gran(out + 2, tag, acc.y);
+        }
+        // the cell-local regularisers (Damping, MS) do not wait for anybody
+        double val = 0.0;
+        if (!stencil && tid < nc) {
+            const double v = xs[tid] - apr_j;
+            if (a.kind == 0) {  // Damping (potential.py:719-723)
+                val = v * v;
+                gr[tid] = a.alpha * (2.0 * v);
+            } else {  // MS (potential.py:775-788)
+                const double v2 = v * v, den = v2 + a.beta;
+                val = (w2_j * v2) / den;
+                gr[tid] = a.alpha * ((2.0 * a.beta * w2_j * v) / (den * den));
+            }
+        }
+        tick(1);
+        if (w < nred) {
+            // reducer: rows [8 w, 8 w + 8) over all workgroups; thread = (group of partials, row)
+            const int row = tid & (RES_RED_ROWS - 1), grp = tid >> 3;
+            const int i = w * RES_RED_ROWS + row;
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            bool have[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) have[m] = !(i < ld && grp + 64 * m < nwg);
+            const bool got = res_poll(a.abort_w, [&]() -> bool {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)  // only what is still missing is read again
+                    if (!have[m]) have[m] = ld_gran(a.slabg + ((int64_t)(grp + 64 * m) * ld + i) * 2, tag, v[m]);
+                return have[0] && have[1] && have[2] && have[3];
+            });
+            if (!got) *flag_s = 0;
+            tick(3);
+            redbuf[grp * RES_RED_ROWS + row] = ((v[0] + v[1]) + v[2]) + v[3];
+            __syncthreads();
+            // wave `wave` sums row `wave` over the 64 groups (fixed order)
+            const double s = wave_sum_dpp(redbuf[lane * RES_RED_ROWS + wave]);
+            if (lane == 0 && w * RES_RED_ROWS + wave < ld)
+                st_gran(a.dsumg + (w * RES_RED_ROWS + wave) * 2, tag, s);
+            // one word per reducer tells the consumers when to look (they poll nred words instead of
+            // hammering the ld granule pairs of d); only a hint -- the rows carry their own tags
+            if (tid == 0)
+                __hip_atomic_store(a.doneg + w, ((u64)tag << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tick(4);
+        }
+        // every workgroup: the finished d
+        if (wave == 0) {
+            const bool got = res_poll(a.abort_w, [&]() -> bool {
+                bool ok = true;
+                for (int q = lane; q < nred; q += 64)
+                    ok &= (unsigned)(__hip_atomic_load(a.doneg + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
+                return ok;
+            });
+            if (!got) *flag_s = 0;
+        }
+        __syncthreads();
+        tick(5);
+        d2 dinv = d2{0.0, 0.0};
+        {
+            double dx = 0.0, dy = 0.0;
+            const bool got = res_poll(a.abort_w, [&]() -> bool {
+                bool ok = true;
+                if (tid < ld2) {
+                    ok = ld_gran(a.dsumg + 2 * i0, tag, dx);
+                    ok &= ld_gran(a.dsumg + 2 * i0 + 2, tag, dy);
+                }
+                return ok;
+            });
+            if (!got) *flag_s = 0;
+            dinv = d2{dx, dy};
+        }
+        tick(6);
+        // mean removal, residual, data misfit (potential.py:700-706)
+        double s = 0.0;
+        if (tid < ld2) {
+            dinv.x += gf.x;
+            dinv.y += gf.y;
+            if (i0 < a.N) s += dinv.x;
+            if (i0 + 1 < a.N) s += dinv.y;
+        }
+        const double mean = res_block_sum(s, red) / (double)a.N;
+        if (*flag_s == 0) return false;  // (behind the barriers of the reduction: uniform)
+        double acc = 0.0;
+        if (tid < ld2) {
+            d2 rv = d2{0.0, 0.0};
+            if (i0 < a.N) {
+                rv.x = (dinv.x - mean) - dc.x;
+                acc += rv.x * rv.x;
+            }
+            if (i0 + 1 < a.N) {
+                rv.y = (dinv.y - mean) - dc.y;
+                acc += rv.y * rv.y;
+            }
+            r_s2[tid] = rv;
+        }
+        if (stencil) {
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            // regulariser of the own cells at xs, neighbours from the published model
+            if (tid < nc) {
+                ra.x = a.xpub + (int64_t)par * M;
+                gr[tid] = a.alpha * reg_cell(ra, j0 + tid, xs[tid], val);
+            }
+        }
+        if (last) {
+            ud = res_block_sum(acc, red);
+            Rw = res_block_sum(val, red);
+        }
+        ++ev;
+        tick(7);
+        return true;
+    };
+
+    // Wave-per-column dots with r_s -> full gradient (four columns of a wave in flight).
+    // what = 0: store it in gs; 1: leapfrog update with momentum coefficient cu; 2: last half
+    // momentum step (returns this workgroup's sum of p^2, stores the gradient in gs).
+    auto dots = [&](int what, double cu) -> double {
+        __syncthreads();  // r_s, gr complete
+        d2 rr[RC];
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int e = lane + 64 * k;
+            rr[k] = (e < ld2) ? r_s2[e] : d2{0.0, 0.0};
+        }
+        double ppw = 0.0;
+        for (int cb = wave; cb < nc; cb += 4 * RES_WAVES) {
+            double s[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cb + q * RES_WAVES;
+                s[q] = 0.0;
+                if (c < nc) {
+#pragma unroll
+                    for (int k = 0; k < RC; ++k) {
+                        const int e = lane + 64 * k;
+                        if (e < ld2) {
+                            const d2 g = Gs2[c * ld2 + e];
+                            s[q] += g.x * rr[k].x;
+                            s[q] += g.y * rr[k].y;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = wave_sum_dpp(s[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cb + q * RES_WAVES;
+                if (c >= nc) continue;
+                const double g = 2.0 * s[q] + gr[c];
+                if (what == 1) {
+                    double pj = ps[c] - cu * g;
+                    double xj = xs[c] + a.dt * pj;
+                    const double chi = hi[c], clo = lo[c];
+                    if (xj > chi) {
+                        xj = chi;
+                        pj = -pj;
+                    } else if (xj < clo) {
+                        xj = clo;
+                        pj = -pj;
+                    }
+                    if (lane == 0) {
+                        ps[c] = pj;
+                        xs[c] = xj;
+                    }
+                } else {
+                    if (what == 2) {
+                        const double pf = ps[c] - cu * g;
+                        ppw += pf * pf;
+                    }
+                    if (lane == 0) gs[c] = g;
+                }
+            }
+        }
+        if (what != 2) return 0.0;
+        __syncthreads();
+        if (lane == 0) red[wave] = ppw;
+        __syncthreads();
+        double t = 0.0;
+        for (int v = 0; v < RES_WAVES; ++v) t += red[v];
+        __syncthreads();
+        return t;
+    };
+
+    // all-gather of {R share, p'p after, p'p before} over the workgroups, summed in a fixed order
+    double Rtot = 0.0, pp1 = 0.0, pp0 = 0.0;
+    auto gather_scalars = [&](double v_r, double v_pp1, double v_pp0) -> bool {
+        tick(8);
+        const unsigned tag = a.tagE0 + (unsigned)ng + 1u;
+        if (tid == 0) {
+            u64 *out = a.scalg + 8 * w;
+            st_gran(out, tag, v_r);
+            st_gran(out + 2, tag, v_pp1);
+            st_gran(out + 4, tag, v_pp0);
+        }
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        const bool got = res_poll(a.abort_w, [&]() -> bool {
+            bool ok = true;
+            if (tid < nwg) {
+                u64 *in = a.scalg + 8 * tid;
+                ok = ld_gran(in, tag, t0);
+                ok &= ld_gran(in + 2, tag, t1);
+                ok &= ld_gran(in + 4, tag, t2);
+            }
+            return ok;
+        });
+        if (!got) *flag_s = 0;
+        Rtot = res_block_sum(t0, red);
+        pp1 = res_block_sum(t1, red);
+        pp0 = res_block_sum(t2, red);
+        ++ng;
+        tick(9);
+        return *flag_s != 0;
+    };
+
+    auto finish = [&](int k_run) {
+        __syncthreads();
+        if (tid < nc) a.x_cur[j0 + tid] = xc[tid];
+        if (w == 0 && tid == 0) {
+            a.n_run[0] = k_run;
+            a.n_run[1] = ev;
+            a.n_run[2] = ng;
+        }
+        if (timing) {
+            tick(10);
+            for (int i = 0; i < 16; ++i) a.dbg[(w == 0 ? 0 : 16) + i] += tacc[i];
+        }
+    };
+
+    // ---- potential and gradient at the current sample
+    if (!evaluate(true)) return;
+    dots(0, 0.0);
+    __syncthreads();
+    if (tid < nc) gc[tid] = gs[tid];
+    if (!gather_scalars(Rw, 0.0, 0.0)) return;
+    double Ucur = ud + a.alpha * Rtot, Ucur_d = ud, Ucur_r = Rtot;
+
+    long long accepts = a.accept_count0;
+    int k = 0;
+    for (; k < a.K; ++k) {
+        const int Lk = a.L[k];
+        const double u = a.us[k];
+        // momentum of this trajectory, first half step from the kept gradient (hmc.py:95-113)
+        double q = 0.0;
+        __syncthreads();
+        if (tid < nc) {
+            const double p0 = a.p0s[(int64_t)k * M + j0 + tid];
+            q = p0 * p0;
+            double pj = p0 - 0.5 * a.dt * gc[tid];
+            double xj = xc[tid] + a.dt * pj;
+            if (xj > hi[tid]) {
+                xj = hi[tid];
+                pj = -pj;
+            } else if (xj < lo[tid]) {
+                xj = lo[tid];
+                pj = -pj;
+            }
+            ps[tid] = pj;
+            xs[tid] = xj;
+        }
+        const double pp0w = res_block_sum(q, red);
+        for (int s = 0; s < Lk; ++s) {
+            if (s > 0) dots(1, a.dt);
+            if (!evaluate(s == Lk - 1)) return;
+        }
+        const double pp1w = dots(2, 0.5 * a.dt);
+        if (!gather_scalars(Rw, pp1w, pp0w)) return;
+        const double Unew = ud + a.alpha * Rtot;
+        const double Hcur = 0.5 * pp0 + Ucur;
+        const double Hnew = 0.5 * pp1 + Unew;
+        const bool acc = (Hnew < Hcur) || (u < exp(-(Hnew - Hcur)));  // hmc.py:158-177
+        if (acc) {
+            Ucur = Unew;
+            Ucur_d = ud;
+            Ucur_r = Rtot;
+            accepts += 1;
+            if (tid < nc) {
+                xc[tid] = xs[tid];
+                gc[tid] = gs[tid];
+                if (a.xacc) a.xacc[(int64_t)k * M + j0 + tid] = xs[tid];
+            }
+        }
+        if (w == 0 && tid == 0) {
+            a.accepted[k] = acc ? 1 : 0;
+            double *o = a.out5s + 5 * k;
+            o[0] = Ucur;
+            o[1] = Ucur_d;
+            o[2] = Ucur_r;
+            o[3] = Hcur;
+            o[4] = Hnew;
+        }
+        if (acc && a.stop_at_accepts > 0 && accepts >= a.stop_at_accepts) {
+            ++k;
+            break;
+        }
+    }
+    finish(k);
+}
+
+}  // namespace ghk

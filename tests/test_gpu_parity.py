@@ -545,10 +545,12 @@ def test_segmentgrid_wavelet_log_lines_on_gpu(G, tmp_path, capsys):
                                rtol=0, atol=1.01e-7)
 
 
-def test_speculative_chaining_is_bit_identical(G):
+def test_speculative_chaining_is_bit_identical(G, monkeypatch):
     """gh_chain_prefetch_momentum (the next trajectory's first step rides on the last sweep)
     changes the execution order only: same bits as plain trajectories, through accepts and
-    rejects, for the dense and the wavelet forward."""
+    rejects, for the dense and the wavelet forward.  (Sweep-per-launch path: the resident chain
+    kernel, which would take this small dense problem, is switched off.)"""
+    monkeypatch.setenv("GRAVHMC_RESIDENT", "0")
     p = gold("potential_small.npz")
     for wavelet in (False, '3D'):
         gm = _module_small(G, p, wavelet=wavelet)
@@ -584,11 +586,66 @@ def test_speculative_chaining_is_bit_identical(G):
         eng.close()
 
 
+# ------------------------------------------------------------ resident chain kernel
+
+@pytest.mark.parametrize("reg", ["Damping", "MS", "Smoothness", "TV"])
+def test_resident_chain_kernel_matches_sweep_path(G, monkeypatch, reg):
+    """Small dense problems run whole batches of trajectories inside one cooperative launch with
+    G resident in LDS (csrc/resident.hip.h).  Same chain as the sweep-per-launch path through
+    accepts and rejects (decisions identical, energies/models to 1e-12: the summation order over
+    the cells differs), for every regulariser, with and without the fixed field; plus the
+    stop-at-accepts contract, the accepted-model output and the posterior ring."""
+    p = gold("potential_small.npz")
+    wm = p["wm"]
+    M = wm.size
+    rng = np.random.default_rng(5)
+    sigma = 0.02 if reg == "MS" else 0.3
+    trajs = [(int(rng.integers(1, 9)), rng.normal(size=M) * sigma, float(rng.uniform())) for _ in range(40)]
+    for fix in (False, True):
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("GRAVHMC_RESIDENT", mode)
+            gm = _module_small(G, p, fixed=True, grav_fix=p["gfix"]) if fix else _module_small(G, p)
+            eng = gm._engine
+            eng.set_reg(reg, 1.0, 0.001, p["shape"], 0.001 * wm)
+            eng.chain_init(0.001 * wm, 0.0 * wm, 0.02 * wm)
+            eng.posterior_window(8)
+            out = []
+            eng.run_chain(iter(trajs), 0.02, lambda L, acc, o, x: out.append((acc, o.copy(), x)),
+                          want_x=True, batch=7, record_from=3)
+            st = eng.chain_stats()
+            res[mode] = (out, eng.chain_get_x(), eng.chain_get_dsyn(), eng.posterior_read(), st)
+            # a second call continues the chain from the device state; stops at the accept count
+            more = []
+            n_acc = sum(a_ for a_, _, _ in out)
+            eng.run_chain(iter(trajs), 0.02, lambda L, acc, o, x: more.append(acc), batch=16,
+                          stop_at_accepts=n_acc + 3)
+            res[mode] += (more,)
+            eng.close()
+        (a, ax, ad, ap, ast, am), (b, bx, bd, bp, bst, bm) = res["0"], res["1"]
+        assert ast["spec_hits"] > 0 and bst["spec_hits"] == 0       # the two paths were really taken
+        assert len(a) == len(b) == len(trajs)
+        n_acc = sum(t[0] for t in a)
+        assert 0 < n_acc and (reg != "TV" or n_acc < len(trajs))
+        for (a1, o1, x1), (a2, o2, x2) in zip(a, b):
+            assert a1 == a2
+            assert np.abs(o1 - o2).max() <= 1e-12 * np.abs(o1).max()
+            assert (x1 is None) == (x2 is None)
+            if x1 is not None:
+                assert relmax(x2, x1) < 1e-12
+        assert relmax(bx, ax) < 1e-12 and relmax(bd, ad) < 1e-12
+        assert ap["total"] == bp["total"] == max(0, n_acc - 3)
+        if ap["total"]:
+            assert relmax(bp["mean"], ap["mean"]) < 1e-12
+        assert am == bm and (reg == "MS" or (sum(bm) == 3 and bm[-1]))
+
+
 # ------------------------------------------------------------ one chain sharded over GPUs
 
-def test_sharded_engine_rccl_world1_is_bitwise_unsharded(G):
+def test_sharded_engine_rccl_world1_is_bitwise_unsharded(G, monkeypatch):
     """RCCL plumbing (unique id, ncclCommInitRank, ncclAllReduce on the stream) with a
     one-rank communicator: the sharded code path must reproduce the unsharded bits."""
+    monkeypatch.setenv("GRAVHMC_RESIDENT", "0")   # bitwise comparison of the two sweep-per-launch paths
     from gravinv3dhmc_amd.dist import Ranks, make_sharded_engine
     p = gold("potential_small.npz")
     env = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
