@@ -143,9 +143,9 @@ struct gh_ctx {
     // resident chain kernel (resident.hip.h): G held in LDS across a whole batch of trajectories
     struct Resident {
         int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
-        int cpw = 0, nwg = 0, nred = 0, rc = 0;
+        int cpw = 0, nwg = 0, rc = 0;
         size_t lds = 0;
-        ghk::u64 *slabg = nullptr, *dsumg = nullptr, *scalg = nullptr, *doneg = nullptr;
+        ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xccg = nullptr;
         double *xpub = nullptr;
         unsigned *abort_w = nullptr;
         unsigned tag = 0, tagE = 0;  // granule tags used so far (the buffers keep them across launches)
@@ -1640,8 +1640,7 @@ static bool resident_plan(gh_ctx *c)
     if (lds > (size_t)lds_max || cpw > RES_THREADS) return false;
     r.cpw = cpw;
     r.nwg = (int)((c->M + cpw - 1) / cpw);
-    r.nred = (int)((c->ld + RES_RED_ROWS - 1) / RES_RED_ROWS);
-    if (r.nred > r.nwg || r.nwg > RES_MAX_WG) return false;  // every reducer is a workgroup of the grid
+    if (r.nwg > RES_MAX_WG) return false;
     r.rc = (int)((c->ld / 2 + 63) / 64);
     r.lds = lds;
     resident_fn f = resident_for(r.rc);
@@ -1672,9 +1671,10 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     HIPCHK(c, hipSetDevice(c->device));
     if (!r.slabg) {
         TRY(dalloc(c, &r.slabg, (size_t)r.nwg * (size_t)c->ld * 2));
-        TRY(dalloc(c, &r.dsumg, (size_t)c->ld * 2));
+        TRY(dalloc(c, &r.xslabg, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
+        TRY(dalloc(c, &r.dclg, (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
         TRY(dalloc(c, &r.scalg, (size_t)r.nwg * 8));
-        TRY(dalloc(c, &r.doneg, (size_t)r.nred));
+        TRY(dalloc(c, &r.xccg, (size_t)r.nwg));
         TRY(dalloc(c, &r.xpub, 2 * M));
         TRY(dalloc(c, &r.abort_w, 4));
         TRY(dalloc(c, &r.n_run, 4));
@@ -1703,9 +1703,10 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     if ((uint64_t)r.tag + (uint64_t)steps + 2 > 0xf0000000ull || (uint64_t)r.tagE + (uint64_t)K + 2 > 0xf0000000ull) {
         // 32-bit tags about to wrap: start the count again on zeroed granules
         HIPCHK(c, hipMemsetAsync(r.slabg, 0, (size_t)r.nwg * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.dsumg, 0, (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.xslabg, 0, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.dclg, 0, (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.scalg, 0, (size_t)r.nwg * 8 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.doneg, 0, (size_t)r.nred * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.xccg, 0, (size_t)r.nwg * sizeof(ghk::u64), c->stream));
         r.tag = r.tagE = 0;
     }
     HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
@@ -1719,7 +1720,7 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     a.M = c->M;
     a.cols_per_wg = r.cpw;
     a.nwg = r.nwg;
-    a.nred = r.nred;
+    a.try_local = env_int("GRAVHMC_RESIDENT_LOCAL", 1);
     a.gfix = c->have_fix ? c->gfix : nullptr;
     a.dobs_c = c->dobs_c;
     a.low = c->low;
@@ -1745,9 +1746,10 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     a.xacc = want_x ? r.xacc : nullptr;
     a.n_run = r.n_run;
     a.slabg = r.slabg;
-    a.dsumg = r.dsumg;
+    a.xslabg = r.xslabg;
+    a.dclg = r.dclg;
     a.scalg = r.scalg;
-    a.doneg = r.doneg;
+    a.xccg = r.xccg;
     a.xpub = r.xpub;
     a.tag0 = r.tag;
     a.tagE0 = r.tagE;

@@ -36,8 +36,10 @@ namespace ghk {
 
 constexpr int RES_THREADS = 512;
 constexpr int RES_WAVES = 8;
-constexpr int RES_RED_ROWS = 8;                       // rows of d one reducer workgroup sums
-constexpr int RES_MAX_WG = 256;                       // four partials per reducer thread
+constexpr int RES_CLUSTERS = 8;                       // logical clusters: workgroups w with equal w % 8
+constexpr int RES_CHUNKS = 32;                        // at most: row chunks of d, one per owning member of a cluster
+constexpr int RES_MAX_WG = 256;                       // <= 32 members per cluster (two per reducing thread)
+constexpr int RES_REDBUF = 16 * 33;                   // LDS transpose buffer of the cluster reduction
 constexpr long long RES_TIMEOUT_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock, per wait
 
 using u64 = unsigned long long;
@@ -45,7 +47,8 @@ using u64 = unsigned long long;
 struct ResArgs {
     const double *G;
     int64_t ld, N, M;
-    int cols_per_wg, nwg, nred;
+    int cols_per_wg, nwg;
+    int try_local;  // 1: keep intra-cluster traffic in the XCD's L2 when the placement allows it
     const double *gfix, *dobs_c, *low, *high;
     // regulariser (x is set per evaluation inside the kernel)
     int kind, nz, ny, nx;
@@ -66,8 +69,9 @@ struct ResArgs {
     int *n_run;      // [0] trajectories run, [1] evaluations, [2] scalar gathers
     // workspace (granule buffers keep their tags across launches: tag0 / tagE0 continue the count)
     u64 *slabg;      // nwg x ld x 2 forward partials
-    u64 *dsumg;      // ld x 2
-    u64 *doneg;      // nred: {tag, 1} once a reducer's rows of dsumg are out
+    u64 *xslabg;     // 2 x 8 x ld x 2 cluster sums, double-buffered by evaluation parity
+    u64 *dclg;       // 8 x ld x 2 finished d, one copy per cluster
+    u64 *xccg;       // nwg: {launch tag, XCC id} of every workgroup
     u64 *scalg;      // nwg x 8 trajectory-end scalars
     double *xpub;    // 2 x M models as the stencil regularisers see them (Smoothness / TV)
     unsigned tag0, tagE0;
@@ -77,7 +81,7 @@ struct ResArgs {
 
 static inline size_t resident_lds_doubles(int64_t ld, int cols_per_wg)
 {
-    return (size_t)cols_per_wg * (size_t)ld + (size_t)ld + 64 * RES_RED_ROWS + 16 + 8 * (size_t)cols_per_wg + 8;
+    return (size_t)cols_per_wg * (size_t)ld + (size_t)ld + RES_REDBUF + 16 + 8 * (size_t)cols_per_wg + 8;
 }
 
 // 8-byte write-through store (global_store_dwordx2 sc1)
@@ -93,6 +97,15 @@ __device__ __forceinline__ void st_gran(u64 *g, unsigned tag, double v)
     const u64 b = (u64)__double_as_longlong(v);
     __hip_atomic_store(g, ((u64)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(g + 1, ((u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the same with plain stores: the line stays in the XCD's L2, where sc1 loads of the same XCD's
+// CUs find it (NOT visible to other XCDs until it is written back)
+__device__ __forceinline__ void st_gran_l2(u64 *g, unsigned tag, double v)
+{
+    const u64 b = (u64)__double_as_longlong(v);
+    __hip_atomic_store(g, ((u64)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(g + 1, ((u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __device__ __forceinline__ bool ld_gran(u64 *g, unsigned tag, double &v)
@@ -153,6 +166,16 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
+// inclusive scan over each row of 16 lanes: lane 15 of a row holds the row's sum
+__device__ __forceinline__ double row16_sum_dpp(double v)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+
 // Workgroup-wide sum (RES_WAVES waves), fixed order, result valid in every thread
 __device__ __forceinline__ double res_block_sum(double v, double *red)
 {
@@ -178,13 +201,13 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     const int64_t M = a.M;
     const int64_t j0 = (int64_t)w * cpw;
     const int nc = (int)((M - j0 < cpw) ? (M - j0) : cpw);
-    const int nwg = a.nwg, nred = a.nred;
+    const int nwg = a.nwg;
     const bool stencil = (a.kind == 1 || a.kind == 3);
 
     double *Gs = smem;                         // cpw x ld
     double *r_s = Gs + (size_t)cpw * ld;       // ld
-    double *redbuf = r_s + ld;                 // 64 x 8
-    double *red = redbuf + 64 * RES_RED_ROWS;  // 16
+    double *redbuf = r_s + ld;                 // 16 x 33
+    double *red = redbuf + RES_REDBUF;         // 16
     double *xs = red + 16;                     // position of the running trajectory
     double *ps = xs + cpw;                     // momentum
     double *xc = ps + cpw;                     // current sample
@@ -227,6 +250,45 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         hi[tid] = a.high[j];
     }
     if (tid == 0) *flag_s = 1;
+
+    // Logical clusters: workgroups with equal w % 8 (the dispatcher deals workgroups round-robin
+    // over the 8 XCDs, so a cluster normally shares one L2).  The reduction order is defined by the
+    // logical indices only; the placement decides how cluster-internal data is published: plain
+    // stores that stay in the shared L2 when every member reports the same XCC id, write-through
+    // stores otherwise (correct under any placement).
+    const int ncl = nwg < RES_CLUSTERS ? nwg : RES_CLUSTERS;
+    const int cg = w % RES_CLUSTERS, crank = w / RES_CLUSTERS;
+    const int cn = (nwg - cg + RES_CLUSTERS - 1) / RES_CLUSTERS;  // members of this cluster
+    // d is cut in nch row chunks; member `crank` of every cluster owns chunk `crank` (nch = size of
+    // the smallest cluster, so nobody owns two: the chunks of an evaluation proceed in parallel)
+    const int nch = (nwg / RES_CLUSTERS) < 1 ? 1 : ((nwg / RES_CLUSTERS) > RES_CHUNKS ? RES_CHUNKS : nwg / RES_CLUSTERS);
+    const int ch = (ld + nch - 1) / nch;  // rows per chunk
+    bool local = false;
+    {
+        const unsigned ltag = a.tagE0 + 1u;  // unique per launch
+        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
+        if (tid == 0)
+            __hip_atomic_store(a.xccg + w, ((u64)ltag << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0) {
+            bool same = true;
+            const bool got = res_poll(a.abort_w, [&]() -> bool {
+                bool ok = true;
+                if (lane < cn) {
+                    const u64 e = __hip_atomic_load(a.xccg + cg + RES_CLUSTERS * lane, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned)(e >> 32) == ltag;
+                    same = ((unsigned)e & 0xfu) == xcc;
+                }
+                return ok;
+            });
+            if (lane == 0) red[0] = (got && __all(same) && a.try_local) ? 1.0 : 0.0;
+            if (!got) *flag_s = 0;
+        }
+        __syncthreads();
+        local = red[0] != 0.0;
+        __syncthreads();
+        if (*flag_s == 0) return;
+    }
     // rows 2 tid, 2 tid + 1 of the constant data vectors live in registers
     const int i0 = 2 * tid;
     d2 gf = d2{0.0, 0.0}, dc = d2{0.0, 0.0};
@@ -288,8 +350,13 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 acc.y += g.y * x;
             }
             u64 *out = a.slabg + ((int64_t)w * ld + i0) * 2;
-            st_gran(out, tag, acc.x);
-            st_gran(out + 2, tag, acc.y);
+            if (local) {
+                st_gran_l2(out, tag, acc.x);
+                st_gran_l2(out + 2, tag, acc.y);
+            } else {
+                st_gran(out, tag, acc.x);
+                st_gran(out + 2, tag, acc.y);
+            }
         }
         // the cell-local regularisers (Damping, MS) do not wait for anybody
         double val = 0.0;
@@ -305,56 +372,68 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             }
         }
         tick(1);
-        if (w < nred) {
-            // reducer: rows [8 w, 8 w + 8) over all workgroups; thread = (group of partials, row)
-            const int row = tid & (RES_RED_ROWS - 1), grp = tid >> 3;
-            const int i = w * RES_RED_ROWS + row;
-            double v[4] = {0.0, 0.0, 0.0, 0.0};
-            bool have[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) have[m] = !(i < ld && grp + 64 * m < nwg);
-            const bool got = res_poll(a.abort_w, [&]() -> bool {
-#pragma unroll
-                for (int m = 0; m < 4; ++m)  // only what is still missing is read again
-                    if (!have[m]) have[m] = ld_gran(a.slabg + ((int64_t)(grp + 64 * m) * ld + i) * 2, tag, v[m]);
-                return have[0] && have[1] && have[2] && have[3];
-            });
-            if (!got) *flag_s = 0;
-            tick(3);
-            redbuf[grp * RES_RED_ROWS + row] = ((v[0] + v[1]) + v[2]) + v[3];
-            __syncthreads();
-            // wave `wave` sums row `wave` over the 64 groups (fixed order)
-            const double s = wave_sum_dpp(redbuf[lane * RES_RED_ROWS + wave]);
-            if (lane == 0 && w * RES_RED_ROWS + wave < ld)
-                st_gran(a.dsumg + (w * RES_RED_ROWS + wave) * 2, tag, s);
-            // one word per reducer tells the consumers when to look (they poll nred words instead of
-            // hammering the ld granule pairs of d); only a hint -- the rows carry their own tags
-            if (tid == 0)
-                __hip_atomic_store(a.doneg + w, ((u64)tag << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tick(4);
+        // level 1 + 2: the owner of row chunk `crank` sums it over the cluster, then over the clusters
+        if (crank < nch) {
+            const int k = crank;
+            for (int rb = 0; rb < ch; rb += 32) {  // 32 rows per pass
+                {
+                    // cluster sum: thread = (member group mg, row); members mg, mg + 16
+                    const int row = rb + (tid & 31), mg = tid >> 5;
+                    const int i = k * ch + row;
+                    const bool act = row < ch && i < ld;
+                    double v0 = 0.0, v1 = 0.0;
+                    bool h0 = !(act && mg < cn), h1 = !(act && mg + 16 < cn);
+                    const bool got = res_poll(a.abort_w, [&]() -> bool {
+                        if (!h0) h0 = ld_gran(a.slabg + ((int64_t)(cg + RES_CLUSTERS * mg) * ld + i) * 2, tag, v0);
+                        if (!h1)
+                            h1 = ld_gran(a.slabg + ((int64_t)(cg + RES_CLUSTERS * (mg + 16)) * ld + i) * 2, tag, v1);
+                        return h0 && h1;
+                    });
+                    if (!got) *flag_s = 0;
+                    redbuf[mg * 33 + (tid & 31)] = v0 + v1;
+                }
+                __syncthreads();
+                tick(3);
+                // transposed: 16 lanes = the 16 member groups of one row, summed on the VALU
+                const int row = rb + (tid >> 4), sub = tid & 15;
+                const int i = k * ch + row;
+                const bool act = row < ch && i < ld;
+                const double csum = row16_sum_dpp(redbuf[sub * 33 + (tid >> 4)]);
+                // (parity buffers: a slow owner of this chunk in another cluster may still be reading
+                // the previous evaluation's sums when this cluster is already one evaluation ahead)
+                u64 *xs_e = a.xslabg + (int64_t)par * RES_CLUSTERS * ld * 2;
+                if (act && sub == 15) st_gran(xs_e + ((int64_t)cg * ld + i) * 2, tag, csum);
+                // sum over the clusters, read back from all of them (own one included): every
+                // cluster computes the same bits
+                double u = 0.0;
+                bool hu = !(act && sub < ncl);
+                const bool got = res_poll(a.abort_w, [&]() -> bool {
+                    if (!hu) hu = ld_gran(xs_e + ((int64_t)sub * ld + i) * 2, tag, u);
+                    return hu;
+                });
+                if (!got) *flag_s = 0;
+                const double dtot = row16_sum_dpp(u);
+                if (act && sub == 15) {
+                    u64 *out = a.dclg + ((int64_t)cg * ld + i) * 2;
+                    if (local)
+                        st_gran_l2(out, tag, dtot);
+                    else
+                        st_gran(out, tag, dtot);
+                }
+                __syncthreads();  // redbuf is reused by the next pass
+                tick(4);
+            }
         }
-        // every workgroup: the finished d
-        if (wave == 0) {
-            const bool got = res_poll(a.abort_w, [&]() -> bool {
-                bool ok = true;
-                for (int q = lane; q < nred; q += 64)
-                    ok &= (unsigned)(__hip_atomic_load(a.doneg + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag;
-                return ok;
-            });
-            if (!got) *flag_s = 0;
-        }
-        __syncthreads();
-        tick(5);
+        // level 3: the finished d from this cluster's copy
         d2 dinv = d2{0.0, 0.0};
         {
             double dx = 0.0, dy = 0.0;
+            bool hx = !(tid < ld2), hy = hx;
+            u64 *in = a.dclg + ((int64_t)cg * ld + i0) * 2;
             const bool got = res_poll(a.abort_w, [&]() -> bool {
-                bool ok = true;
-                if (tid < ld2) {
-                    ok = ld_gran(a.dsumg + 2 * i0, tag, dx);
-                    ok &= ld_gran(a.dsumg + 2 * i0 + 2, tag, dy);
-                }
-                return ok;
+                if (!hx) hx = ld_gran(in, tag, dx);
+                if (!hy) hy = ld_gran(in + 2, tag, dy);
+                return hx && hy;
             });
             if (!got) *flag_s = 0;
             dinv = d2{dx, dy};
