@@ -342,6 +342,18 @@ def main():
                          "reference_formulation_equiv_GBps":
                              2 * bytes_sweep * args.steps / elapsed / 1e9},
         }
+        cstat = eng.chain_stats() if CPG == 1 else {}
+        if cstat.get("resident_evaluations", 0) > 0:
+            # G never left the chip: the figure below is what the reference formulation would have
+            # had to read per second, not HBM traffic
+            line["roofline"].update({
+                "bound": "on-chip latency (G resident in LDS, N-vector exchanges between workgroups)",
+                "achieved": None, "frac": None, "traffic": None, "peak": None,
+                "kernel": "resident_chain_kernel (%d trajectories batches in %d cooperative launches)"
+                          % (ntraj, cstat["resident_launches"]),
+                "launches": cstat["resident_launches"], "avg_ms": None,
+                "evaluations": prof["sweeps"], "us_per_evaluation": sweep_ms * 1e3,
+                "lds_equiv_GBps": achieved})
         if CPG > 1:
             line["roofline"].update({
                 "kernel": "batch_adjoint_kernel + batch_forward_kernel (v_mfma_f64_16x16x4, %d chains "

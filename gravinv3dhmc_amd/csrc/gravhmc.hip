@@ -1605,6 +1605,7 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
 }
 
 typedef void (*resident_fn)(ResArgs);
+enum { GH_RESIDENT_ABORTED = 1000 };  // internal: chain_run_resident gave up, state untouched
 
 static resident_fn resident_for(int rc)
 {
@@ -1670,11 +1671,12 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     const size_t M = (size_t)c->M;
     HIPCHK(c, hipSetDevice(c->device));
     if (!r.slabg) {
-        TRY(dalloc(c, &r.slabg, (size_t)r.nwg * (size_t)c->ld * 2));
+        // (+8 rows / entries: the abort test announces one phantom workgroup per cluster)
+        TRY(dalloc(c, &r.slabg, (size_t)(r.nwg + 8) * (size_t)c->ld * 2));
         TRY(dalloc(c, &r.xslabg, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
         TRY(dalloc(c, &r.dclg, (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
         TRY(dalloc(c, &r.scalg, (size_t)r.nwg * 8));
-        TRY(dalloc(c, &r.xccg, (size_t)r.nwg));
+        TRY(dalloc(c, &r.xccg, (size_t)r.nwg + 8));
         TRY(dalloc(c, &r.xpub, 2 * M));
         TRY(dalloc(c, &r.abort_w, 4));
         TRY(dalloc(c, &r.n_run, 4));
@@ -1720,6 +1722,8 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     a.M = c->M;
     a.cols_per_wg = r.cpw;
     a.nwg = r.nwg;
+    // test hook: the workgroups wait for partners that do not exist, time out and abort
+    if (env_int("GRAVHMC_RESIDENT_TEST_ABORT", 0)) a.nwg += 8;
     a.try_local = env_int("GRAVHMC_RESIDENT_LOCAL", 1);
     a.gfix = c->have_fix ? c->gfix : nullptr;
     a.dobs_c = c->dobs_c;
@@ -1768,10 +1772,13 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     HIPCHK(c, hipMemcpyAsync(out5s, r.out5s, (size_t)K * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h_sync[0] != 0u) {
-        // tags of an aborted launch are in an unknown state: start again on zeroed granules
-        r.tag = r.tagE = 0xf0000000u;
-        return fail(c, GH_ERR_HIP, "resident chain kernel: a workgroup timed out waiting for the others "
-                                   "(is another process holding compute units of this device?)");
+        // A workgroup waited 2 s for the others: they were not all resident (another process holding
+        // compute units of this device).  Nothing of the chain state was written; this context goes
+        // back to the sweep-per-launch path for good and the caller's batch is run there.
+        r.state = -1;
+        fprintf(stderr, "libgravhmc: resident chain kernel timed out waiting for its workgroups; "
+                        "continuing on the sweep-per-launch path\n");
+        return GH_RESIDENT_ABORTED;
     }
     r.tag += (unsigned)h_run[1];
     r.tagE += (unsigned)h_run[2];
@@ -1817,6 +1824,8 @@ int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double
     TRY(need(c, c->chain_ready, "gh_chain_run: call gh_chain_init first"));
     const size_t M = (size_t)c->M;
     *n_run = 0;
+    // already there (a caller that submits batches ahead of looking at the results)
+    if (stop_at_accepts > 0 && c->accept_count >= stop_at_accepts) return GH_OK;
     if (resident_plan(c)) {
         int64_t steps = 0;
         bool ok = true;
@@ -1825,9 +1834,12 @@ int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double
             steps += L[k];
         }
         ok = steps < ((int64_t)1 << 28);  // granule tags are 32-bit
-        if (ok)
-            return chain_run_resident(c, K, L, p0s, us, dt, stop_at_accepts, record_from, accepted, out5s,
-                                      x_out, n_run);
+        if (ok) {
+            const int rc = chain_run_resident(c, K, L, p0s, us, dt, stop_at_accepts, record_from, accepted,
+                                              out5s, x_out, n_run);
+            if (rc != GH_RESIDENT_ABORTED) return rc;
+            *n_run = 0;
+        }
     }
     for (int k = 0; k < K; ++k) {
         const double *nxt = (k + 1 < K) ? p0s + (size_t)(k + 1) * M : p0_lookahead;
@@ -1868,6 +1880,14 @@ int gh_chain_stats(gh_ctx *c, int64_t *spec_hits, int64_t *spec_misses)
     if (!c) return GH_ERR_ARG;
     if (spec_hits) *spec_hits = c->spec_hits;
     if (spec_misses) *spec_misses = c->spec_misses;
+    return GH_OK;
+}
+
+int gh_chain_resident_stats(gh_ctx *c, int64_t *launches, int64_t *evaluations)
+{
+    if (!c) return GH_ERR_ARG;
+    if (launches) *launches = c->rs.launches;
+    if (evaluations) *evaluations = c->rs.evals;
     return GH_OK;
 }
 

@@ -217,7 +217,10 @@ class Engine(object):
     def chain_stats(self):
         a, b = C.c_int64(0), C.c_int64(0)
         self._chk(self._lib.gh_chain_stats(self._h, C.byref(a), C.byref(b)))
-        return {"spec_hits": a.value, "spec_misses": b.value}
+        la, ev = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_chain_resident_stats(self._h, C.byref(la), C.byref(ev)))
+        return {"spec_hits": a.value, "spec_misses": b.value,
+                "resident_launches": la.value, "resident_evaluations": ev.value}
 
     def _run_batch(self, batch, lookahead, dt, stop_at, record_from, want_x):
         """One gh_chain_run call over a list of (L, p0, u); returns per-trajectory results."""
@@ -237,9 +240,10 @@ class Engine(object):
                 for k in range(n_run.value)]
 
     def default_batch(self):
-        """Trajectories per gh_chain_run call: enough to hide the Python round trip, few enough
-        that the host draw of the next batch still overlaps the GPU (C2: 1, C1: 32)."""
-        return int(max(1, min(32, (2 << 20) // (8 * max(1, self.M)))))
+        """Trajectories per gh_chain_run call: enough to hide the per-call cost (Python round trip,
+        momentum upload, for small problems the launch of the resident chain kernel), few enough
+        that the host draw of the next batch still overlaps the GPU (C2: 1, C1: 128)."""
+        return int(max(1, min(128, (6 << 20) // (8 * max(1, self.M)))))
 
     def _loc_vec(self, v):
         return f64(v)
@@ -252,7 +256,8 @@ class Engine(object):
         """Pipelined trajectories: `draws` yields (L, p0, u) in RNG-stream order.  Batches of
         trajectories run inside one library call (gh_chain_run: momentum of trajectory k+1
         announced before trajectory k, so an accepted proposal's last sweep already takes the
-        next first step) while the next batch is drawn on the host.
+        next first step; small dense problems: one launch of the resident chain kernel per batch)
+        while the next batch is drawn on the host.
         `on_result(L, accepted, out5, x)` is called per finished trajectory (x = chain state after
         an accepted trajectory if want_x, else None) and may return False to stop."""
         import threading

@@ -172,6 +172,12 @@ int gh_chain_run(gh_ctx *ctx, int K, const int *L, const double *p0s, const doub
                  int *accepted, double *out5s, double *x_out, int *n_run);
 /* How often the speculative first step was used / discarded. */
 int gh_chain_stats(gh_ctx *ctx, int64_t *spec_hits, int64_t *spec_misses);
+/* Small dense problems (N <= 1024, one column block per CU fitting its LDS next to the kernel's
+ * scratch, one device, stored G): gh_chain_run runs its K trajectories inside ONE cooperative
+ * launch with G resident in LDS (csrc/resident.hip.h) instead of one sweep per launch.  Same
+ * contract and results to rounding (the summation order over the cells differs); environment
+ * GRAVHMC_RESIDENT=0 switches it off.  launches / evaluations: how much ran there so far. */
+int gh_chain_resident_stats(gh_ctx *ctx, int64_t *launches, int64_t *evaluations);
 int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
 int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state */);
 /* ---- several chains sharing every sweep of G (fp64 MFMA) ---------------------------------- */

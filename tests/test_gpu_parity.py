@@ -640,6 +640,35 @@ def test_resident_chain_kernel_matches_sweep_path(G, monkeypatch, reg):
         assert am == bm and (reg == "MS" or (sum(bm) == 3 and bm[-1]))
 
 
+def test_resident_chain_kernel_times_out_cleanly(G, monkeypatch, capfd):
+    """Every wait inside the resident kernel is bounded.  With the test hook the workgroups wait for
+    partners that never run: the kernel gives up after 2 s without touching the chain, the context
+    falls back to the sweep-per-launch path for good and the batch is run there (same bits)."""
+    p = gold("potential_small.npz")
+    wm = p["wm"]
+    M = wm.size
+    rng = np.random.default_rng(9)
+    trajs = [(int(rng.integers(1, 9)), rng.normal(size=M) * 0.3, float(rng.uniform())) for _ in range(12)]
+    res = {}
+    for mode in ("sweep", "aborting"):
+        monkeypatch.setenv("GRAVHMC_RESIDENT", "0" if mode == "sweep" else "1")
+        monkeypatch.setenv("GRAVHMC_RESIDENT_TEST_ABORT", "0" if mode == "sweep" else "1")
+        gm = _module_small(G, p)
+        eng = gm._engine
+        eng.set_reg("TV", 1.0, 0.001, p["shape"], 0.001 * wm)
+        eng.chain_init(0.001 * wm, 0.0 * wm, 0.02 * wm)
+        out = []
+        eng.run_chain(iter(trajs), 0.02, lambda L, acc, o, x: out.append((acc, o.copy())), batch=5)
+        res[mode] = (out, eng.chain_get_x())
+        eng.close()
+    assert "timed out" in capfd.readouterr().err
+    (a, ax), (b, bx) = res["sweep"], res["aborting"]
+    assert len(a) == len(b) == len(trajs)
+    for (a1, o1), (a2, o2) in zip(a, b):
+        assert a1 == a2 and np.array_equal(o1, o2)
+    assert np.array_equal(ax, bx)
+
+
 # ------------------------------------------------------------ one chain sharded over GPUs
 
 def test_sharded_engine_rccl_world1_is_bitwise_unsharded(G, monkeypatch):
