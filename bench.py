@@ -349,7 +349,7 @@ def main():
             line["roofline"].update({
                 "bound": "on-chip latency (G resident in LDS, N-vector exchanges between workgroups)",
                 "achieved": None, "frac": None, "traffic": None, "peak": None,
-                "kernel": "resident_chain_kernel (%d trajectories batches in %d cooperative launches)"
+                "kernel": "resident_chain_kernel (%d trajectories in %d launches)"
                           % (ntraj, cstat["resident_launches"]),
                 "launches": cstat["resident_launches"], "avg_ms": None,
                 "evaluations": prof["sweeps"], "us_per_evaluation": sweep_ms * 1e3,

@@ -1631,9 +1631,7 @@ static bool resident_plan(gh_ctx *c)
     r.state = -1;
     if (env_int("GRAVHMC_RESIDENT", 1) == 0) return false;
     if (c->mf || c->wv.on || c->sh.kind != 0 || c->n_panels != 1 || c->ld > 1024 || !c->G) return false;
-    int coop = 0, lds_max = 0;
-    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) != hipSuccess || !coop)
-        return false;
+    int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess)
         return false;
     const int cpw = (int)((c->M + c->cus - 1) / c->cus);
@@ -1662,7 +1660,7 @@ static bool resident_plan(gh_ctx *c)
     return true;
 }
 
-// K trajectories in one cooperative launch (same contract as gh_chain_run)
+// K trajectories in one launch of the resident chain kernel (same contract as gh_chain_run)
 static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
                               int64_t stop_at_accepts, int64_t record_from, int *accepted, double *out5s,
                               double *x_out, int *n_run)
@@ -1759,10 +1757,12 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     a.tagE0 = r.tagE;
     a.abort_w = r.abort_w;
     a.dbg = r.dbg;
-    void *params[] = {&a};
     if (c->prof) HIPCHK(c, hipEventRecord(r.ev0, c->stream));
-    HIPCHK(c, hipLaunchCooperativeKernel(reinterpret_cast<const void *>(resident_for(r.rc)), dim3(r.nwg),
-                                         dim3(RES_THREADS), params, (unsigned)r.lds, c->stream));
+    // A plain launch: the grid was checked against the occupancy query in resident_plan (one
+    // workgroup per CU by its LDS request), which is all hipLaunchCooperativeKernel would add;
+    // residency itself is the same for both, and every wait inside the kernel is bounded.
+    hipLaunchKernelGGL(resident_for(r.rc), dim3(r.nwg), dim3(RES_THREADS), r.lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
     if (c->prof) HIPCHK(c, hipEventRecord(r.ev1, c->stream));
     unsigned h_sync[4] = {0, 0, 0, 0};
     int h_run[4] = {0, 0, 0, 0};

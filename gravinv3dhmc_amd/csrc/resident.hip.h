@@ -27,8 +27,8 @@
 // barrier on the hot path; a buffer is only overwritten after every reader has published
 // something that depends on having read it.  (First version: arrival counters + agent acquire,
 // 2 x ~5 us per evaluation; this form: see DESIGN.md.)  Every spin is bounded: on a time-out the
-// abort word is raised, every workgroup leaves and the host reports the failure.  The launch is
-// cooperative (all workgroups resident: one per CU by the LDS request).
+// abort word is raised, every workgroup leaves and the host falls back to the sweep path.  The
+// grid (one workgroup per CU by the LDS request) is checked against the occupancy query on the host.
 #pragma once
 #include "kernels.hip.h"
 

@@ -173,7 +173,7 @@ int gh_chain_run(gh_ctx *ctx, int K, const int *L, const double *p0s, const doub
 /* How often the speculative first step was used / discarded. */
 int gh_chain_stats(gh_ctx *ctx, int64_t *spec_hits, int64_t *spec_misses);
 /* Small dense problems (N <= 1024, one column block per CU fitting its LDS next to the kernel's
- * scratch, one device, stored G): gh_chain_run runs its K trajectories inside ONE cooperative
+ * scratch, one device, stored G): gh_chain_run runs its K trajectories inside ONE
  * launch with G resident in LDS (csrc/resident.hip.h) instead of one sweep per launch.  Same
  * contract and results to rounding (the summation order over the cells differs); environment
  * GRAVHMC_RESIDENT=0 switches it off.  launches / evaluations: how much ran there so far. */
