@@ -101,8 +101,15 @@ struct gh_ctx {
         ncclComm_t comm = nullptr;
         gh_allreduce_fn cb = nullptr;
         void *user = nullptr;
-        double *buf = nullptr;    // device: [d partial (ld) | R partial | pad]
+        double *buf = nullptr;    // device: [d partial (ld) | R partial | pad | boundary planes (halo)]
         double *hbuf = nullptr;   // pinned staging for the callback path
+        size_t buf_n = 0;         // doubles in buf / hbuf
+        // Smoothness / TV on cells sharded in whole z-planes: the ranks exchange their boundary
+        // planes of the model once per evaluation (inside the forward partial's all-reduce)
+        bool halo = false;
+        int64_t P = 0;            // cells per plane (ny * nx)
+        double *alo = nullptr, *ahi = nullptr;  // prior model of the planes below / above
+        double *rb = nullptr;     // regulariser partial for its own (2-double) all-reduce
         int64_t collectives = 0;
     } sh;
 
@@ -503,6 +510,7 @@ static int comm_allreduce(gh_ctx *c, double *buf, int64_t count)
         return GH_OK;
     }
     // host-staged reducer (e.g. gloo): device -> pinned host -> callback -> device
+    if ((size_t)count > sh.buf_n) return fail(c, GH_ERR_ARG, "all-reduce larger than the staging buffer");
     HIPCHK(c, hipMemcpyAsync(sh.hbuf, buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (sh.cb(sh.user, sh.hbuf, count) != 0) return fail(c, GH_ERR_COMM, "all-reduce callback failed");
@@ -539,6 +547,7 @@ static int shard_common_init(gh_ctx *c, int rank, int world, int64_t M_global, i
     c->sh.m0 = m0;
     TRY(dalloc(c, &c->sh.buf, (size_t)c->ld + 8));
     if (!c->sh.hbuf) HIPCHK(c, hipHostMalloc((void **)&c->sh.hbuf, sizeof(double) * ((size_t)c->ld + 8)));
+    c->sh.buf_n = (size_t)c->ld + 8;
     c->chain_ready = false;
     return GH_OK;
 }
@@ -691,7 +700,7 @@ static void reduce_slab(gh_ctx *c, const double *gfix, double *d_out)
 static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
 {
     double *d_out = o.d, *r_out = o.r, *greg_out = o.greg, *scal_out = o.scal;
-    RegArgs ra;
+    RegArgs ra{};
     ra.ms_grad_den_mw = 0;
     ra.kind = c->reg_kind;
     ra.M = c->M;
@@ -715,12 +724,33 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         // all-reduce, then every rank finishes the (replicated) data part identically
         double *buf = c->sh.buf;
         reduce_slab(c, nullptr, buf);
-        reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
-        sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, buf + c->ld);
-        TRY(comm_allreduce(c, buf, c->ld + 2));
+        if (c->sh.halo) {
+            // stencil regulariser: the boundary planes of x travel with the forward partial, the
+            // regulariser (which needs them) is summed by a second, two-double all-reduce
+            gh_ctx::Shard &sh = c->sh;
+            const int64_t P = sh.P, nh = 2 * (int64_t)sh.world * P;
+            double *hb = buf + c->ld + 8;
+            halo_pack_kernel<<<dim3((unsigned)std::min<int64_t>(1024, (nh + 255) / 256)), dim3(256), 0, c->stream>>>(
+                x, c->M, P, sh.rank, sh.world, hb);
+            TRY(comm_allreduce(c, buf, (int64_t)c->ld + 8 + nh));
+            ra.nz = c->shape[0];
+            ra.k0 = sh.m0 / P;
+            ra.xlo = sh.rank > 0 ? hb + ((int64_t)(sh.rank - 1) * 2 + 1) * P : nullptr;
+            ra.xhi = sh.rank + 1 < sh.world ? hb + (int64_t)(sh.rank + 1) * 2 * P : nullptr;
+            ra.alo = sh.alo;
+            ra.ahi = sh.ahi;
+            reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+            sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, sh.rb);
+            TRY(comm_allreduce(c, sh.rb, 2));
+            regpart = sh.rb;
+        } else {
+            reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+            sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, buf + c->ld);
+            TRY(comm_allreduce(c, buf, c->ld + 2));
+            regpart = buf + c->ld;
+        }
         src = buf;
         nseg = 1;
-        regpart = buf + c->ld;
         n_regpart = 1;
     } else if (c->wv.on) {
         // forward through the compressed operator: d_out is already complete
@@ -1156,9 +1186,16 @@ int gh_set_reg(gh_ctx *c, int kind, double alpha, double beta, const int shape3[
     if (!c || !mwapr) return fail(c, GH_ERR_ARG, "gh_set_reg: null pointer");
     if (kind < 0 || kind > 3)
         return fail(c, GH_ERR_ARG, "Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.");
-    if (c->sh.kind != 0 && (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV))
-        return fail(c, GH_ERR_UNSUPPORTED, "Smoothness/TV across cell shards need a halo exchange (not built): use Damping or MS");
-    if (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV) {
+    const bool stencil = (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV);
+    if (c->sh.kind != 0 && stencil) {
+        // the finite-difference stencil crosses the shard boundaries: shards of whole z-planes
+        if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->sh.M_global)
+            return fail(c, GH_ERR_ARG, "gh_set_reg: Smoothness/TV on a sharded model need the GLOBAL shape nz*ny*nx == M_global");
+        const int64_t P = (int64_t)shape3[1] * shape3[2];
+        if (c->M < P || c->M % P != 0 || c->sh.m0 % P != 0)
+            return fail(c, GH_ERR_UNSUPPORTED, "Smoothness/TV on a sharded model need shards of whole z-planes "
+                                               "(%lld cells each): partition the cells with that alignment", (long long)P);
+    } else if (stencil) {
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
             return fail(c, GH_ERR_ARG, "gh_set_reg: Smoothness/TV need shape nz*ny*nx == M (carved meshes are not supported by the finite-difference operator)");
     }
@@ -1174,6 +1211,41 @@ int gh_set_reg(gh_ctx *c, int kind, double alpha, double beta, const int shape3[
         c->shape[0] = shape3[0];
         c->shape[1] = shape3[1];
         c->shape[2] = shape3[2];
+    }
+    c->sh.halo = false;
+    if (c->sh.kind != 0 && stencil) {
+        gh_ctx::Shard &sh = c->sh;
+        const int64_t P = (int64_t)shape3[1] * shape3[2];
+        const size_t need = (size_t)c->ld + 8 + 2 * (size_t)sh.world * (size_t)P;
+        if (need > sh.buf_n) {
+            sh.buf = nullptr;  // (the old block stays in the allocation list until gh_destroy)
+            TRY(dalloc(c, &sh.buf, need));
+            if (sh.hbuf) hipHostFree(sh.hbuf);
+            sh.hbuf = nullptr;
+            HIPCHK(c, hipHostMalloc((void **)&sh.hbuf, sizeof(double) * need));
+            sh.buf_n = need;
+        }
+        if (sh.P != P) {
+            sh.alo = sh.ahi = nullptr;
+            TRY(dalloc(c, &sh.alo, (size_t)P));
+            TRY(dalloc(c, &sh.ahi, (size_t)P));
+        }
+        TRY(dalloc(c, &sh.rb, 2));
+        sh.P = P;
+        // boundary planes of the prior model, once (collective: every rank is in this call)
+        double *hb = sh.buf + c->ld + 8;
+        const int64_t nh = 2 * (int64_t)sh.world * P;
+        halo_pack_kernel<<<dim3((unsigned)std::min<int64_t>(1024, (nh + 255) / 256)), dim3(256), 0, c->stream>>>(
+            c->mwapr, c->M, P, sh.rank, sh.world, hb);
+        TRY(comm_allreduce(c, sh.buf, (int64_t)c->ld + 8 + nh));
+        if (sh.rank > 0)
+            HIPCHK(c, hipMemcpyAsync(sh.alo, hb + ((int64_t)(sh.rank - 1) * 2 + 1) * P, sizeof(double) * (size_t)P,
+                                     hipMemcpyDeviceToDevice, c->stream));
+        if (sh.rank + 1 < sh.world)
+            HIPCHK(c, hipMemcpyAsync(sh.ahi, hb + (int64_t)(sh.rank + 1) * 2 * P, sizeof(double) * (size_t)P,
+                                     hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        sh.halo = true;
     }
     c->have_reg = true;
     c->chain_ready = false;
@@ -1256,7 +1328,7 @@ int gh_reg_eval(gh_ctx *c, int kind, double beta, const int shape3[3], int ms_gr
     double *dx = c->xb[3], *dapr = c->st[3].greg, *dg = c->tmpM;
     TRY(h2d(c, dx, mw, (size_t)c->M));
     TRY(h2d(c, dapr, mwapr, (size_t)c->M));
-    RegArgs ra;
+    RegArgs ra{};
     ra.ms_grad_den_mw = ms_grad_den_mw;
     ra.kind = kind;
     ra.M = c->M;

@@ -352,12 +352,18 @@ struct RegArgs {
     const double *x, *mwapr, *wm2;
     double *greg;     // alpha * grad R
     double *regpart;  // per-block partial of R
+    // cells sharded over GPUs in whole z-planes (stencil kinds): nz is the GLOBAL plane count, k0
+    // the global index of the first local plane, *lo / *hi the plane below / above the local cells
+    // (model and prior model) as received from the neighbouring ranks; all zero when unsharded
+    int64_t k0;
+    const double *xlo, *xhi, *alo, *ahi;
 };
 
 // Regulariser term of cell j at the model a.x (own value xj = a.x[j] passed in; neighbours of the
 // stencil kinds are read from a.x): returns dR/dx_j, adds the cell's share of R to `val`
 // (potential.py:719-736, 775-810).  The finite-difference operator of potential.py:266-361 is never
 // materialised.
+template <bool HALO = false>
 __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double xj, double &val)
 {
     const double v = xj - a.mwapr[j];
@@ -371,16 +377,23 @@ __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double x
         const double deng = a.ms_grad_den_mw ? xj * xj + a.beta : den;
         g = (2.0 * a.beta * w2 * v) / (deng * deng);
     } else {  // Smoothness (1) / TV (3)
-        const int64_t nx = a.nx, ny = a.ny, nz = a.nz;
-        const int64_t i = j % nx, jj = (j / nx) % ny, k = j / (nx * ny);
-        const int64_t stride[3] = {1, nx, nx * ny};
+        const int64_t nx = a.nx, ny = a.ny, nz = a.nz, P = nx * ny;
+        const int64_t i = j % nx, jj = (j / nx) % ny, k = j / P + a.k0;
+        const int64_t stride[3] = {1, nx, P};
         const bool fwd[3] = {i < nx - 1, jj < ny - 1, k < nz - 1};
         const bool bwd[3] = {i > 0, jj > 0, k > 0};
+        // model minus prior model of neighbour q (beyond the local planes: the neighbouring rank's)
+        auto nb = [&](int64_t q) -> double {
+            if (HALO) {
+                if (q >= a.M) return a.xhi[q - a.M] - a.ahi[q - a.M];
+                if (q < 0) return a.xlo[q + P] - a.alo[q + P];
+            }
+            return a.x[q] - a.mwapr[q];
+        };
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             if (fwd[ax]) {
-                const int64_t q = j + stride[ax];
-                const double t = v - (a.x[q] - a.mwapr[q]);
+                const double t = v - nb(j + stride[ax]);
                 if (a.kind == 1) {
                     val += t * t;
                     g += 2.0 * t;
@@ -391,8 +404,7 @@ __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double x
                 }
             }
             if (bwd[ax]) {
-                const int64_t q = j - stride[ax];
-                const double t = (a.x[q] - a.mwapr[q]) - v;
+                const double t = nb(j - stride[ax]) - v;
                 if (a.kind == 1)
                     g -= 2.0 * t;
                 else
@@ -405,19 +417,38 @@ __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double x
 
 // Regulariser value + gradient of one 256-cell block.  `blk`: index of the block, `red`: 4
 // doubles of LDS.
+template <bool HALO = false>
 __device__ __forceinline__ void reg_block(const RegArgs &a, int blk, double *red)
 {
     const int64_t j = (int64_t)blk * 256 + threadIdx.x;
     double val = 0.0;
-    if (j < a.M) a.greg[j] = a.alpha * reg_cell(a, j, a.x[j], val);
+    if (j < a.M) a.greg[j] = a.alpha * reg_cell<HALO>(a, j, a.x[j], val);
     const double tot = block_allreduce_sum(val, red, 4);
     if (threadIdx.x == 0) a.regpart[blk] = tot;
+}
+
+// Boundary planes of a sharded model for the exchange by all-reduce: hb[(2 r + which) * P + off] =
+// first (which = 0) / last (which = 1) plane of rank r's cells; every rank fills its own two
+// slots and zeroes the others, the sum over the ranks is the table of all boundary planes.
+__global__ void __launch_bounds__(256)
+halo_pack_kernel(const double *v, int64_t M, int64_t P, int rank, int world, double *hb)
+{
+    const int64_t n = 2 * (int64_t)world * P;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int64_t slot = idx / P, off = idx - slot * P;
+        double val = 0.0;
+        if ((int)(slot >> 1) == rank) val = (slot & 1) ? v[M - P + off] : v[off];
+        hb[idx] = val;
+    }
 }
 
 __global__ void __launch_bounds__(256) reg_kernel(RegArgs a)
 {
     __shared__ double red[4];
-    reg_block(a, blockIdx.x, red);
+    if (a.xlo != nullptr || a.xhi != nullptr)
+        reg_block<true>(a, blockIdx.x, red);
+    else
+        reg_block<false>(a, blockIdx.x, red);
 }
 
 // One launch for the two independent halves of the per-step epilogue: blocks [0, n_red) sum the

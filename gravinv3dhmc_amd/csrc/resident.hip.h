@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         if (a.kind == 2) w2_j = a.wm2[j0 + tid];
     }
 
-    RegArgs ra;
+    RegArgs ra{};
     ra.ms_grad_den_mw = 0;
     ra.kind = a.kind;
     ra.M = M;

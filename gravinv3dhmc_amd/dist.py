@@ -107,12 +107,17 @@ def run_chains(model_factory, sample_kwargs, ranks=None):
 # One chain sharded over several GPUs: column blocks of G (BASELINE config C5)
 # ---------------------------------------------------------------------------------------------
 
-def column_partition(M, world):
-    """Contiguous, near-equal split of M cells over `world` ranks: list of (m0, m1)."""
-    base, rem = divmod(int(M), int(world))
+def column_partition(M, world, align=1):
+    """Contiguous, near-equal split of M cells over `world` ranks: list of (m0, m1).  align > 1:
+    every block is a multiple of `align` cells (whole z-planes of the mesh: what the
+    Smoothness/TV stencils need when the cells are sharded)."""
+    M, world, align = int(M), int(world), max(1, int(align))
+    if M % align:
+        raise ValueError("%d cells are not a multiple of the alignment %d" % (M, align))
+    base, rem = divmod(M // align, world)
     out, m0 = [], 0
     for g in range(world):
-        m1 = m0 + base + (1 if g < rem else 0)
+        m1 = m0 + (base + (1 if g < rem else 0)) * align
         out.append((m0, m1))
         m0 = m1
     return out
@@ -137,10 +142,13 @@ def _engine_base():
     return Engine
 
 
-def make_sharded_engine(N, M, ranks, device=None, backend="rccl"):
+def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
     """Engine-compatible object whose methods take and return FULL model vectors while the
     device holds only this rank's cells.  backend: "rccl" (all-reduce on the GPU stream over
-    xGMI) or "gloo" (host-staged through torch.distributed; several ranks per GPU, tests)."""
+    xGMI) or "gloo" (host-staged through torch.distributed; several ranks per GPU, tests).
+    align: cells per z-plane (ny*nx) to shard in whole planes, which the Smoothness/TV
+    regularisers need (their stencil crosses the shard boundaries: one boundary plane per
+    neighbour travels with the forward partial's all-reduce)."""
     import ctypes as C
     import numpy as np
     from . import _lib
@@ -149,7 +157,9 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl"):
     class ShardedEngine(Engine):
         def __init__(self):
             self.ranks = ranks
-            self.parts = column_partition(M, ranks.world)
+            self.parts = column_partition(M, ranks.world, align)
+            if min(m1 - m0 for m0, m1 in self.parts) <= 0:
+                raise ValueError("more ranks than z-planes: a rank would hold no cells")
             self.m0, self.m1 = self.parts[ranks.rank]
             self.M_global = int(M)
             Engine.__init__(self, N, self.m1 - self.m0, ranks.device if device is None else device)
@@ -199,7 +209,9 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl"):
             return self._full(Engine.weight(self, weightfactor))
 
         def set_reg(self, regularization, alpha, beta, shape, mwapr):
-            Engine.set_reg(self, regularization, alpha, beta, None, self._loc(mwapr))
+            # Smoothness / TV: the GLOBAL mesh shape; the library checks the plane alignment
+            stencil = regularization in ("Smoothness", "TV")
+            Engine.set_reg(self, regularization, alpha, beta, shape if stencil else None, self._loc(mwapr))
 
         def forward(self, mw):
             return Engine.forward(self, self._loc(mw))

@@ -39,7 +39,8 @@ class GravMagModule(object):
     * mtopo=(x, y, topography) keyword: carve the mesh with a topography surface.
     * device: GPU ordinal (extension; the reference has no such argument).
     * shard: a `dist.Ranks` object: the cells of ONE model are split in column blocks over the
-      ranks' GPUs (each holds N x M/world of G); shard_backend "rccl" or "gloo".
+      ranks' GPUs (each holds N x M/world of G); shard_backend "rccl" or "gloo"; shard_planes=True
+      splits in whole z-planes, which the Smoothness/TV regularisers need on a sharded model.
     * matrix_free: never store G; re-evaluate the prism / tesseroid entries in every potential
       evaluation (for kernels larger than HBM; ~100x slower per step than the dense path).
     """
@@ -48,7 +49,7 @@ class GravMagModule(object):
                  mratio=1, mseg=False, mdivisionsection=[], weightfactor=0.5,
                  coordinate="cartesian", njobs=1, field="gravity",
                  mangle=(90, 0), wavelet=False, device=0, verbose=True, shard=None,
-                 shard_backend="rccl", matrix_free=False, **kwargs):
+                 shard_backend="rccl", matrix_free=False, shard_planes=False, **kwargs):
         self.dobs = dobs
         self.fixed = fixed
         self.grav_fix = grav_fix
@@ -98,7 +99,12 @@ class GravMagModule(object):
             if wavelet:
                 raise NotImplementedError("wavelet forward on a sharded kernel is not supported")
             from ..dist import make_sharded_engine
-            eng = make_sharded_engine(N, bounds.shape[0], shard, backend=shard_backend)
+            align = 1
+            if shard_planes:
+                if bounds.shape[0] != mesh.size:
+                    raise ValueError("shard_planes needs the full (uncarved) mesh")
+                align = int(mesh.shape[1]) * int(mesh.shape[2])
+            eng = make_sharded_engine(N, bounds.shape[0], shard, backend=shard_backend, align=align)
         else:
             eng = Engine(N, bounds.shape[0], device=device)
         if matrix_free:
@@ -177,9 +183,6 @@ class GravMagModule(object):
                 raise ValueError("Smoothness/TV need the full (uncarved) mesh: shape %r has %d "
                                  "cells, model has %d" % (self.mshape, int(np.prod(self.mshape)),
                                                           m_model))
-            if regulization in ("Smoothness", "TV") and hasattr(self._engine, "M_global"):
-                raise NotImplementedError("Smoothness/TV across cell shards need a halo exchange "
-                                          "(not built): use Damping or MS")
             self._engine.set_reg(regulization, alpha, beta, self.mshape, mwapr)
             self._engine._reg_key = key
 

@@ -98,7 +98,12 @@ int gh_weight(gh_ctx *ctx, double weightfactor, double *wm_out);
 int gh_set_data(gh_ctx *ctx, const double *dobs, const double *grav_fix_or_null);
 /* Regulariser: kind (GH_REG_*), alpha (hmc RegulFactor), beta (MS/TV), mesh shape
  * (nz,ny,nx) for Smoothness/TV (must satisfy nz*ny*nx == M), weighted prior
- * mwapr (M).  Needs gh_weight first for MS (uses wm^2 = diag(WmSquare)). */
+ * mwapr (M).  Needs gh_weight first for MS (uses wm^2 = diag(WmSquare)).
+ * On a context that holds a shard of the cells (gh_shard_init*): mwapr is the local part; for
+ * Smoothness/TV shape3 is the GLOBAL mesh shape (nz*ny*nx == M_global), every shard must consist
+ * of whole z-planes (m0 and M multiples of ny*nx, else GH_ERR_UNSUPPORTED) and the call is
+ * collective (the boundary planes of the prior model are exchanged once; those of the model
+ * travel with every evaluation's forward partial). */
 int gh_set_reg(gh_ctx *ctx, int kind, double alpha, double beta, const int shape3[3],
                const double *mwapr);
 /* d = Aw * mw            (potential.py:698, np.dot(self.Aw, mw)) */

@@ -99,6 +99,13 @@ def test_column_partition_and_allgather_single():
     from gravinv3dhmc_amd.dist import Ranks, allgather_slices, column_partition
     assert column_partition(10, 3) == [(0, 4), (4, 7), (7, 10)]
     assert column_partition(2400000, 8)[-1] == (2100000, 2400000)
+    # whole z-planes (Smoothness/TV on a sharded model): C1 over 3 ranks, C5 over 8
+    assert column_partition(6000, 3, align=600) == [(0, 2400), (2400, 4200), (4200, 6000)]
+    c5 = column_partition(2400000, 8, align=40000)
+    assert [(b - a) // 40000 for a, b in c5] == [8, 8, 8, 8, 7, 7, 7, 7] and c5[-1][1] == 2400000
+    import pytest
+    with pytest.raises(ValueError):
+        column_partition(6001, 3, align=600)
     parts = column_partition(7, 1)
     env = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     try:

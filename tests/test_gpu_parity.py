@@ -711,16 +711,22 @@ def test_sharded_engine_rccl_world1_is_bitwise_unsharded(G, monkeypatch):
     assert np.array_equal(a.forward(x), b.forward(x))
     ma, mb = a.misfit_and_grad(x), b.misfit_and_grad(x)
     assert ma[0] == mb[0] and np.array_equal(ma[1], mb[1])
-    with pytest.raises(NotImplementedError):
-        a.set_reg("TV", 1.0, 0.001, p["shape"], 0.001 * wb)
+    # the stencil kinds take the halo path (here: no neighbours, second all-reduce for R)
+    for reg in ("Smoothness", "TV"):
+        a.set_reg(reg, 1.0, 0.001, p["shape"], 0.001 * wb)
+        b.set_reg(reg, 1.0, 0.001, p["shape"], 0.001 * wb)
+        ma, mb = a.misfit_and_grad(x), b.misfit_and_grad(x)
+        assert abs(ma[0] - mb[0]) <= 1e-13 * abs(mb[0]) and relmax(ma[1], mb[1]) < 1e-13
     a.close()
     b.close()
 
 
-def test_sharded_chain_two_ranks_one_gpu():
-    """Two ranks (one process each, both on GPU 0) hold half of the cells each; forward
-    partials are summed over gloo once per evaluation.  Everything must agree with the
-    unsharded engine to rounding and both ranks must print the same chain."""
+def test_sharded_chain_three_ranks_one_gpu():
+    """Three ranks (one process each, all on GPU 0) hold 4 + 3 + 3 of the 10 z-planes of the C1
+    model; forward partials are summed over gloo once per evaluation, and for Smoothness/TV the
+    boundary planes of the model travel with them (the stencil crosses the shard boundaries).
+    Everything must agree with the unsharded engine to rounding for all four regularisers and all
+    ranks must print the same chain; shards that cut through a plane refuse the stencil kinds."""
     import json
     import socket
     import subprocess
@@ -730,7 +736,7 @@ def test_sharded_chain_two_ranks_one_gpu():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "shard_worker.py"), "gloo"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
@@ -738,15 +744,17 @@ def test_sharded_chain_two_ranks_one_gpu():
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
     res = json.loads(line[len("RESULT "):])
-    assert [r["rank"] for r in res] == [0, 1] and [r["M_local"] for r in res] == [3000, 3000]
+    assert [r["rank"] for r in res] == [0, 1, 2] and [r["M_local"] for r in res] == [2400, 1800, 1800]
+    assert [r["M_ragged"] for r in res] == [2000, 2000, 2000]
     for r in res:
         assert r["wm"] == 0.0                     # column norms are per cell: identical bits
         assert r["fwd"] < 1e-13 and r["adj"] == 0.0 and r["potential"] < 1e-12
         assert r["tv_refused"]
         assert r["lines_equal"] and r["misfit"] < 1e-9 and r["model"] < 2e-8
+        assert r["tv_lines_equal"] and r["tv_misfit"] < 1e-9 and r["tv_model"] < 2e-8
         assert r["ref_rows"] < 1e-7               # and they are the reference's rows (8 decimals)
         assert r["spec"]["spec_hits"] > 0
-    print("sharded 2-rank check:", res[0])
+    print("sharded 3-rank check:", res[0])
 
 
 # ------------------------------------------------------------------------------ matrix-free
