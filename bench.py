@@ -138,7 +138,23 @@ def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=12.0):
         t_run += time.time() - t1
         steps += L
     sps_sample = steps / t_run
+    # the same on one BLAS thread (SURVEY 8d asks for both), shorter
+    single = None
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1, user_api="blas"):
+            s1, t1run = 0, 0.0
+            while t1run < target_s / 3 and s1 < 2000:
+                p0 = rng.normal(size=Ms) * 0.001
+                t1 = time.time()
+                x, acc, out, _ = P.leapfrog(x, p0, 0.01, L, 0.0 * wm, 1.0 * wm, 0.5)
+                t1run += time.time() - t1
+                s1 += L
+            single = s1 / t1run * Ms / M
+    except Exception:
+        single = None
     return {"value": sps_sample * Ms / M, "unit": "leapfrog steps/s", "cores": cores,
+            "single_core_value": single,
             "kind": "port",
             "sample": "NumPy/OpenBLAS mirror of potential.py:688-845 + hmc.py:85-177; same N=%d "
                       "observations, every %d-th cell (%d of %d); %d steps in %.1f s (%.2f steps/s "
@@ -310,6 +326,10 @@ def main():
         barrier()
     prof = eng.profile_read()
     eng.profile_enable(False)
+    # what a pure read of the same matrix reaches on this device (outside the timed region)
+    stream_gbps = None
+    if not args.matrix_free and int(N) * int(M) * 8 >= (1 << 30):
+        stream_gbps = eng.stream_read_gbps(nt=True, reps=3)
     elapsed = ranks.max(elapsed)
 
     if rank == 0:
@@ -340,7 +360,11 @@ def main():
                          "launches": prof["sweeps"], "avg_ms": sweep_ms,
                          "algorithmic_bytes_per_launch": bytes_sweep,
                          "reference_formulation_equiv_GBps":
-                             2 * bytes_sweep * args.steps / elapsed / 1e9},
+                             2 * bytes_sweep * args.steps / elapsed / 1e9,
+                         # a plain read-only pass over the same matrix on this device (SURVEY 8d's
+                         # "attainable" microbenchmark; the sweep's access pattern reaches or beats it)
+                         "stream_read_microbench_GBps": stream_gbps,
+                         "vs_stream_read_microbench": achieved / stream_gbps if stream_gbps else None},
         }
         cstat = eng.chain_stats() if CPG == 1 else {}
         if cstat.get("resident_evaluations", 0) > 0:

@@ -2315,6 +2315,15 @@ int gh_debug_resident_timing(gh_ctx *c, long long out32[32], int64_t *launches, 
     return GH_OK;
 }
 
+int gh_debug_stream_read(gh_ctx *c, int blocks, int threads, int nt, int reps, double *ms_out);
+
+int gh_measure_stream_read(gh_ctx *c, int nt, int reps, double *ms_per_pass)
+{
+    if (!c || !ms_per_pass || reps < 1) return fail(c, GH_ERR_ARG, "gh_measure_stream_read: bad arguments");
+    TRY(need(c, c->have_G && !c->mf, "gh_measure_stream_read: needs a stored kernel matrix"));
+    return gh_debug_stream_read(c, c->cus * 2, 1024, nt, reps, ms_per_pass);
+}
+
 int gh_debug_stream_read(gh_ctx *c, int blocks, int threads, int nt, int reps, double *ms_out)
 {
     if (!c || !c->have_G) return GH_ERR_ARG;

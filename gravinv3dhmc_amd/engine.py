@@ -367,6 +367,12 @@ class Engine(object):
     def profile_enable(self, on=True):
         self._chk(self._lib.gh_profile_enable(self._h, 1 if on else 0))
 
+    def stream_read_gbps(self, nt=True, reps=3):
+        """Attainable streaming-read rate (GB/s) of this device over the stored kernel matrix."""
+        ms = C.c_double(0)
+        self._chk(self._lib.gh_measure_stream_read(self._h, 1 if nt else 0, int(reps), C.byref(ms)))
+        return self.N * self.M * 8 / (ms.value * 1e-3) / 1e9
+
     def profile_read(self):
         ms, n, b = C.c_double(0), C.c_int64(0), C.c_int64(0)
         self._chk(self._lib.gh_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(b)))
