@@ -157,7 +157,12 @@ struct gh_ctx {
         unsigned *abort_w = nullptr;
         unsigned tag = 0, tagE = 0;  // granule tags used so far (the buffers keep them across launches)
         int Kcap = 0;
-        int *L = nullptr, *accepted = nullptr, *n_run = nullptr;
+        int *L = nullptr, *accepted = nullptr, *n_run = nullptr, *chain = nullptr;
+        int lds_max = 0;
+        size_t lds_set = 0;   // dynamic LDS size the kernel's attribute currently allows
+        // several chains sharing the resident G (gh_batch_* on small problems)
+        double *bx = nullptr, *bg = nullptr, *bu = nullptr;  // C x M models, C x M gradients, 3 C potentials
+        bool b_on = false, b_state = false;
         double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
         int64_t launches = 0, evals = 0;
         long long *dbg = nullptr;
@@ -1707,8 +1712,9 @@ static bool resident_plan(gh_ctx *c)
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess)
         return false;
     const int cpw = (int)((c->M + c->cus - 1) / c->cus);
-    const size_t lds = resident_lds_doubles(c->ld, cpw) * sizeof(double);
+    const size_t lds = resident_lds_doubles(c->ld, cpw, 1) * sizeof(double);
     if (lds > (size_t)lds_max || cpw > RES_THREADS) return false;
+    r.lds_max = lds_max;
     r.cpw = cpw;
     r.nwg = (int)((c->M + cpw - 1) / cpw);
     if (r.nwg > RES_MAX_WG) return false;
@@ -1721,6 +1727,7 @@ static bool resident_plan(gh_ctx *c)
         (void)hipGetLastError();
         return false;
     }
+    r.lds_set = lds;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), RES_THREADS,
                                                      lds) != hipSuccess || per_cu < 1 ||
@@ -1732,14 +1739,34 @@ static bool resident_plan(gh_ctx *c)
     return true;
 }
 
-// K trajectories in one launch of the resident chain kernel (same contract as gh_chain_run)
-static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
-                              int64_t stop_at_accepts, int64_t record_from, int *accepted, double *out5s,
-                              double *x_out, int *n_run)
+// One launch of the resident chain kernel: K trajectories of C chains (chain_of[k], nullptr: all
+// chain 0) whose current models are the rows of x_dev.  GH_RESIDENT_ABORTED: the kernel gave up
+// waiting for its workgroups, nothing was changed.
+struct ResLaunch {
+    int C = 1, K = 0;
+    const int *chain_of = nullptr, *L = nullptr;
+    const double *p0s = nullptr, *us = nullptr;
+    double dt = 0.0;
+    int64_t stop_at_accepts = 0, accept_count0 = 0;
+    double *x_dev = nullptr, *gcur_dev = nullptr, *ucur_dev = nullptr;
+    int have_state = 0;
+    bool want_x = false;
+};
+
+static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double *out5s, int h_run[4])
 {
     gh_ctx::Resident &r = c->rs;
     const size_t M = (size_t)c->M;
+    const int K = q.K;
     HIPCHK(c, hipSetDevice(c->device));
+    const size_t lds = resident_lds_doubles(c->ld, r.cpw, q.C) * sizeof(double);
+    if (q.C < 1 || q.C > RES_MAX_CHAINS || lds > (size_t)r.lds_max)
+        return fail(c, GH_ERR_ARG, "resident chain kernel: %d chains do not fit the LDS", q.C);
+    if (lds > r.lds_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(resident_for(r.rc)),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        r.lds_set = lds;
+    }
     if (!r.slabg) {
         // (+8 rows / entries: the abort test announces one phantom workgroup per cluster)
         TRY(dalloc(c, &r.slabg, (size_t)(r.nwg + 8) * (size_t)c->ld * 2));
@@ -1758,10 +1785,10 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
         // grown rarely (the host batches a fixed number of trajectories per call); the old blocks
         // stay in the context's allocation list until gh_destroy
         const int cap = std::max(K, 32);
-        r.L = nullptr;
-        r.accepted = nullptr;
+        r.L = r.accepted = r.chain = nullptr;
         r.p0s = r.us = r.out5s = r.xacc = nullptr;
         TRY(dalloc(c, &r.L, (size_t)cap));
+        TRY(dalloc(c, &r.chain, (size_t)cap));
         TRY(dalloc(c, &r.accepted, (size_t)cap));
         TRY(dalloc(c, &r.p0s, (size_t)cap * M, false));
         TRY(dalloc(c, &r.us, (size_t)cap));
@@ -1769,10 +1796,10 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
         TRY(dalloc(c, &r.xacc, (size_t)cap * M, false));
         r.Kcap = cap;
     }
-    const bool want_x = x_out != nullptr || c->ring != nullptr;
     int64_t steps = 0;
-    for (int k = 0; k < K; ++k) steps += L[k];
-    if ((uint64_t)r.tag + (uint64_t)steps + 2 > 0xf0000000ull || (uint64_t)r.tagE + (uint64_t)K + 2 > 0xf0000000ull) {
+    for (int k = 0; k < K; ++k) steps += q.L[k];
+    if ((uint64_t)r.tag + (uint64_t)steps + (uint64_t)q.C + 2 > 0xf0000000ull ||
+        (uint64_t)r.tagE + (uint64_t)K + (uint64_t)q.C + 2 > 0xf0000000ull) {
         // 32-bit tags about to wrap: start the count again on zeroed granules
         HIPCHK(c, hipMemsetAsync(r.slabg, 0, (size_t)r.nwg * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.xslabg, 0, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
@@ -1782,9 +1809,11 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
         r.tag = r.tagE = 0;
     }
     HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.p0s, p0s, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.us, us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.L, L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(r.p0s, q.p0s, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(r.us, q.us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(r.L, q.L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (q.chain_of)
+        HIPCHK(c, hipMemcpyAsync(r.chain, q.chain_of, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
     ResArgs a{};
     a.G = c->G;
     a.ld = c->ld;
@@ -1807,17 +1836,22 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     a.beta = c->beta;
     a.mwapr = c->mwapr;
     a.wm2 = c->wm2;
-    a.x_cur = c->xb[c->xcur];
+    a.C = q.C;
+    a.chain = q.chain_of ? r.chain : nullptr;
+    a.x_cur = q.x_dev;
+    a.gcur_io = q.gcur_dev;
+    a.ucur_io = q.ucur_dev;
+    a.have_state = q.have_state;
     a.K = K;
     a.L = r.L;
     a.p0s = r.p0s;
     a.us = r.us;
-    a.dt = dt;
-    a.stop_at_accepts = stop_at_accepts;
-    a.accept_count0 = c->accept_count;
+    a.dt = q.dt;
+    a.stop_at_accepts = q.stop_at_accepts;
+    a.accept_count0 = q.accept_count0;
     a.accepted = r.accepted;
     a.out5s = r.out5s;
-    a.xacc = want_x ? r.xacc : nullptr;
+    a.xacc = q.want_x ? r.xacc : nullptr;
     a.n_run = r.n_run;
     a.slabg = r.slabg;
     a.xslabg = r.xslabg;
@@ -1833,13 +1867,12 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     // A plain launch: the grid was checked against the occupancy query in resident_plan (one
     // workgroup per CU by its LDS request), which is all hipLaunchCooperativeKernel would add;
     // residency itself is the same for both, and every wait inside the kernel is bounded.
-    hipLaunchKernelGGL(resident_for(r.rc), dim3(r.nwg), dim3(RES_THREADS), r.lds, c->stream, a);
+    hipLaunchKernelGGL(resident_for(r.rc), dim3(r.nwg), dim3(RES_THREADS), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     if (c->prof) HIPCHK(c, hipEventRecord(r.ev1, c->stream));
     unsigned h_sync[4] = {0, 0, 0, 0};
-    int h_run[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(h_sync, r.abort_w, sizeof h_sync, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_run, r.n_run, sizeof h_run, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_run, r.n_run, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(accepted, r.accepted, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out5s, r.out5s, (size_t)K * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1862,6 +1895,28 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
         c->prof_ms_acc += t;
         c->prof_res_evals += h_run[1];
     }
+    return GH_OK;
+}
+
+// K trajectories of the context's chain in one launch (same contract as gh_chain_run)
+static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
+                              int64_t stop_at_accepts, int64_t record_from, int *accepted, double *out5s,
+                              double *x_out, int *n_run)
+{
+    gh_ctx::Resident &r = c->rs;
+    const size_t M = (size_t)c->M;
+    ResLaunch q;
+    q.K = K;
+    q.L = L;
+    q.p0s = p0s;
+    q.us = us;
+    q.dt = dt;
+    q.stop_at_accepts = stop_at_accepts;
+    q.accept_count0 = c->accept_count;
+    q.x_dev = c->xb[c->xcur];
+    q.want_x = x_out != nullptr || c->ring != nullptr;
+    int h_run[4] = {0, 0, 0, 0};
+    TRY(resident_launch(c, q, accepted, out5s, h_run));
     *n_run = h_run[0];
     for (int k = 0; k < h_run[0]; ++k) {
         if (!accepted[k]) continue;
@@ -2149,20 +2204,12 @@ static int batch_upload_rows(gh_ctx *c, const double *rows, int C, double *dst)
     return GH_OK;
 }
 
-int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const double *high)
+// state of the MFMA batch (chain-interleaved layouts) at the models x0s (C rows of M)
+static int batch_init_mfma(gh_ctx *c, int C, const double *x0s)
 {
-    if (!c || !x0s || !low || !high) return fail(c, GH_ERR_ARG, "gh_batch_init: null pointer");
-    if (C < 1 || C > CB) return fail(c, GH_ERR_ARG, "gh_batch_init: 1..16 chains per batch");
-    TRY(need(c, c->have_G && c->have_data && c->have_reg && !c->mf,
-             "gh_batch_init: needs the stored (dense) kernel matrix, gh_set_data and gh_set_reg"));
-    if (c->wv.on || c->sh.kind != 0)
-        return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the dense, unsharded kernel only");
-    HIPCHK(c, hipSetDevice(c->device));
     TRY(batch_alloc(c));
     gh_ctx::Batch &b = c->bt;
     b.C = C;
-    TRY(h2d(c, c->low, low, (size_t)c->M));
-    TRY(h2d(c, c->high, high, (size_t)c->M));
     TRY(batch_upload_rows(c, x0s, C, b.Xc));
     TRY(batch_evaluate(c, b.Xc, b.Dc, b.GREGc, b.Rtc));
     TRY(d2h(c, b.h, b.scal, CB * 4));
@@ -2173,6 +2220,39 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     }
     b.ready = true;
     return GH_OK;
+}
+
+int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const double *high)
+{
+    if (!c || !x0s || !low || !high) return fail(c, GH_ERR_ARG, "gh_batch_init: null pointer");
+    if (C < 1 || C > CB) return fail(c, GH_ERR_ARG, "gh_batch_init: 1..16 chains per batch");
+    TRY(need(c, c->have_G && c->have_data && c->have_reg && !c->mf,
+             "gh_batch_init: needs the stored (dense) kernel matrix, gh_set_data and gh_set_reg"));
+    if (c->wv.on || c->sh.kind != 0)
+        return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the dense, unsharded kernel only");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_work(c));
+    TRY(h2d(c, c->low, low, (size_t)c->M));
+    TRY(h2d(c, c->high, high, (size_t)c->M));
+    gh_ctx::Resident &r = c->rs;
+    r.b_on = false;
+    if (resident_plan(c) &&
+        resident_lds_doubles(c->ld, r.cpw, C) * sizeof(double) <= (size_t)r.lds_max) {
+        // small problem: the chains take turns inside the resident chain kernel (one launch per
+        // round of trajectories, G loaded into LDS once for all of them) -- a sweep of a 30 MB G
+        // per launch would leave the MFMA batch bound by launches
+        static_assert(CB <= RES_MAX_CHAINS, "chains per batch");
+        TRY(dalloc(c, &r.bx, (size_t)CB * (size_t)c->M));
+        TRY(dalloc(c, &r.bg, (size_t)CB * (size_t)c->M));
+        TRY(dalloc(c, &r.bu, 3 * (size_t)CB));
+        TRY(h2d(c, r.bx, x0s, (size_t)C * (size_t)c->M));
+        r.b_on = true;
+        r.b_state = false;
+        c->bt.C = C;
+        c->bt.ready = true;
+        return GH_OK;
+    }
+    return batch_init_mfma(c, C, x0s);
 }
 
 int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, const double *us, int *accepted,
@@ -2187,6 +2267,35 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
     for (int k = 0; k < C; ++k) {
         if (L[k] < 1) return fail(c, GH_ERR_ARG, "gh_batch_trajectory: L must be >= 1");
         Lmax = std::max(Lmax, L[k]);
+    }
+    if (c->rs.b_on) {
+        gh_ctx::Resident &r = c->rs;
+        int chain_of[CB];
+        for (int k = 0; k < C; ++k) chain_of[k] = k;
+        ResLaunch q;
+        q.C = C;
+        q.K = C;
+        q.chain_of = chain_of;
+        q.L = L;
+        q.p0s = p0s;
+        q.us = us;
+        q.dt = dt;
+        q.x_dev = r.bx;
+        q.gcur_dev = r.bg;
+        q.ucur_dev = r.bu;
+        q.have_state = r.b_state ? 1 : 0;
+        int h_run[4] = {0, 0, 0, 0};
+        const int rc = resident_launch(c, q, accepted, out5s, h_run);
+        if (rc == GH_OK) {
+            r.b_state = true;
+            return GH_OK;
+        }
+        if (rc != GH_RESIDENT_ABORTED) return rc;
+        // the kernel gave up (its workgroups were not all resident): carry on with the MFMA batch
+        std::vector<double> xs((size_t)C * (size_t)c->M);
+        TRY(d2h(c, xs.data(), r.bx, xs.size()));
+        r.b_on = false;
+        TRY(batch_init_mfma(c, C, xs.data()));
     }
     const int64_t n16 = c->M * CB;
     TRY(batch_upload_rows(c, p0s, C, b.Pw[0]));
@@ -2286,6 +2395,7 @@ int gh_batch_get_x(gh_ctx *c, int chain, double *x)
     if (!c || !x) return fail(c, GH_ERR_ARG, "gh_batch_get_x: null pointer");
     TRY(need(c, c->bt.ready && chain >= 0 && chain < c->bt.C, "gh_batch_get_x: no such chain"));
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->rs.b_on) return d2h(c, x, c->rs.bx + (size_t)chain * (size_t)c->M, (size_t)c->M);
     batch_extract_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(c->bt.Xc, chain, c->M,
                                                                                            c->tmpM);
     HIPCHK(c, hipGetLastError());

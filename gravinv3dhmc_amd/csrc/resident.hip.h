@@ -54,8 +54,14 @@ struct ResArgs {
     int kind, nz, ny, nx;
     double alpha, beta;
     const double *mwapr, *wm2;
-    // chain
-    double *x_cur;  // M: in = current model, out = model after the last trajectory run
+    // chains: C of them share the launch (and the resident G); trajectory k belongs to chain
+    // chain[k] (nullptr: chain 0) and the chains are advanced in the order of the list
+    int C;
+    const int *chain;
+    double *x_cur;     // C x M: in = current models, out = models after the last trajectories run
+    double *gcur_io;   // C x M full gradient at the current models (kept between launches), or nullptr
+    double *ucur_io;   // 3 C: {U, U_data, R} of the current models
+    int have_state;    // 1: gcur_io / ucur_io are valid for x_cur (skip the evaluation at launch)
     int K;
     const int *L;
     const double *p0s;  // K x M momenta, drawn by the host in the reference's order
@@ -79,9 +85,12 @@ struct ResArgs {
     long long *dbg;  // optional: 2 x 16 accumulated phase times (100 MHz ticks) of the first / last workgroup
 };
 
-static inline size_t resident_lds_doubles(int64_t ld, int cols_per_wg)
+constexpr int RES_MAX_CHAINS = 16;
+
+static inline size_t resident_lds_doubles(int64_t ld, int cols_per_wg, int chains)
 {
-    return (size_t)cols_per_wg * (size_t)ld + (size_t)ld + RES_REDBUF + 16 + 8 * (size_t)cols_per_wg + 8;
+    return (size_t)cols_per_wg * (size_t)ld + (size_t)ld + RES_REDBUF + 16 +
+           (6 + 2 * (size_t)chains) * (size_t)cols_per_wg + 3 * RES_MAX_CHAINS + 8;
 }
 
 // 8-byte write-through store (global_store_dwordx2 sc1)
@@ -210,13 +219,14 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     double *red = redbuf + RES_REDBUF;         // 16
     double *xs = red + 16;                     // position of the running trajectory
     double *ps = xs + cpw;                     // momentum
-    double *xc = ps + cpw;                     // current sample
-    double *gc = xc + cpw;                     // full gradient at the current sample
-    double *gs = gc + cpw;                     // full gradient at the latest evaluation
+    double *gs = ps + cpw;                     // full gradient at the latest evaluation
     double *gr = gs + cpw;                     // alpha * dR/dx at the latest evaluation
     double *lo = gr + cpw;
     double *hi = lo + cpw;
-    int *flag_s = reinterpret_cast<int *>(hi + cpw);  // 1 while no wave of this workgroup gave up
+    double *xc_all = hi + cpw;                 // C x cpw: current sample of every chain
+    double *gc_all = xc_all + (size_t)a.C * cpw;   // C x cpw: full gradient there
+    double *ucs = gc_all + (size_t)a.C * cpw;  // 3 x RES_MAX_CHAINS: {U, U_data, R} of the current samples
+    int *flag_s = reinterpret_cast<int *>(ucs + 3 * RES_MAX_CHAINS);  // 1 while no wave gave up
     const d2 *Gs2 = reinterpret_cast<const d2 *>(Gs);
     d2 *r_s2 = reinterpret_cast<d2 *>(r_s);
 
@@ -242,13 +252,16 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     }
     if (tid < nc) {
         const int64_t j = j0 + tid;
-        const double x0 = a.x_cur[j];
-        xs[tid] = x0;
-        xc[tid] = x0;
+        for (int c = 0; c < a.C; ++c) {
+            xc_all[c * cpw + tid] = a.x_cur[(int64_t)c * M + j];
+            if (a.have_state) gc_all[c * cpw + tid] = a.gcur_io[(int64_t)c * M + j];
+        }
+        xs[tid] = xc_all[tid];
         ps[tid] = 0.0;
         lo[tid] = a.low[j];
         hi[tid] = a.high[j];
     }
+    if (a.have_state && tid < 3 * a.C) ucs[tid] = a.ucur_io[tid];
     if (tid == 0) *flag_s = 1;
 
     // Logical clusters: workgroups with equal w % 8 (the dispatcher deals workgroups round-robin
@@ -587,7 +600,12 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
 
     auto finish = [&](int k_run) {
         __syncthreads();
-        if (tid < nc) a.x_cur[j0 + tid] = xc[tid];
+        if (tid < nc)
+            for (int c = 0; c < a.C; ++c) {
+                a.x_cur[(int64_t)c * M + j0 + tid] = xc_all[c * cpw + tid];
+                if (a.gcur_io) a.gcur_io[(int64_t)c * M + j0 + tid] = gc_all[c * cpw + tid];
+            }
+        if (w == 0 && a.ucur_io && tid < 3 * a.C) a.ucur_io[tid] = ucs[tid];
         if (w == 0 && tid == 0) {
             a.n_run[0] = k_run;
             a.n_run[1] = ev;
@@ -599,19 +617,33 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         }
     };
 
-    // ---- potential and gradient at the current sample
-    if (!evaluate(true)) return;
-    dots(0, 0.0);
+    // ---- potential and gradient at the current sample of every chain (unless kept from the
+    // previous launch)
+    if (!a.have_state) {
+        for (int c = 0; c < a.C; ++c) {
+            __syncthreads();
+            if (tid < nc) xs[tid] = xc_all[c * cpw + tid];
+            if (!evaluate(true)) return;
+            dots(0, 0.0);
+            __syncthreads();
+            if (tid < nc) gc_all[c * cpw + tid] = gs[tid];
+            if (!gather_scalars(Rw, 0.0, 0.0)) return;
+            if (tid == 0) {
+                ucs[3 * c + 0] = ud + a.alpha * Rtot;
+                ucs[3 * c + 1] = ud;
+                ucs[3 * c + 2] = Rtot;
+            }
+        }
+    }
     __syncthreads();
-    if (tid < nc) gc[tid] = gs[tid];
-    if (!gather_scalars(Rw, 0.0, 0.0)) return;
-    double Ucur = ud + a.alpha * Rtot, Ucur_d = ud, Ucur_r = Rtot;
 
     long long accepts = a.accept_count0;
     int k = 0;
     for (; k < a.K; ++k) {
         const int Lk = a.L[k];
         const double u = a.us[k];
+        const int c = a.chain ? a.chain[k] : 0;
+        double *xc = xc_all + c * cpw, *gc = gc_all + c * cpw;
         // momentum of this trajectory, first half step from the kept gradient (hmc.py:95-113)
         double q = 0.0;
         __syncthreads();
@@ -637,15 +669,22 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         }
         const double pp1w = dots(2, 0.5 * a.dt);
         if (!gather_scalars(Rw, pp1w, pp0w)) return;
+        double Ucur = ucs[3 * c + 0], Ucur_d = ucs[3 * c + 1], Ucur_r = ucs[3 * c + 2];
         const double Unew = ud + a.alpha * Rtot;
         const double Hcur = 0.5 * pp0 + Ucur;
         const double Hnew = 0.5 * pp1 + Unew;
         const bool acc = (Hnew < Hcur) || (u < exp(-(Hnew - Hcur)));  // hmc.py:158-177
+        __syncthreads();  // every thread has read ucs
         if (acc) {
             Ucur = Unew;
             Ucur_d = ud;
             Ucur_r = Rtot;
             accepts += 1;
+            if (tid == 0) {
+                ucs[3 * c + 0] = Ucur;
+                ucs[3 * c + 1] = Ucur_d;
+                ucs[3 * c + 2] = Ucur_r;
+            }
             if (tid < nc) {
                 xc[tid] = xs[tid];
                 gc[tid] = gs[tid];

@@ -881,11 +881,15 @@ def test_posterior_window_and_sample_sinks(G, orc, tmp_path, capsys):
 
 # --------------------------------------------------------- several chains per GPU (fp64 MFMA)
 
-@pytest.mark.parametrize("case", ["small_tv", "random_ms", "random_damping_big"])
-def test_batched_chains_match_single_chain_engines(G, case):
-    """gh_batch_*: up to 16 chains share every sweep of G through v_mfma_f64_16x16x4; every chain
-    must reproduce a single-chain context fed the same momenta / lengths / variates
-    (<= 1e-10: the MFMA contracts rows in another order than the wave reduction)."""
+@pytest.mark.parametrize("case,resident", [("small_tv", "0"), ("small_tv", "1"), ("random_ms", "0"),
+                                           ("random_ms", "1"), ("random_damping_big", "1")])
+def test_batched_chains_match_single_chain_engines(G, monkeypatch, case, resident):
+    """gh_batch_*: up to 16 chains share every sweep of G through v_mfma_f64_16x16x4 -- or, on
+    problems small enough for the resident chain kernel (resident = "1": the first two cases),
+    take turns inside one launch of that kernel per round of trajectories.  Every chain must
+    reproduce a single-chain context fed the same momenta / lengths / variates (<= 1e-10: the
+    MFMA contracts rows in another order than the wave reduction)."""
+    monkeypatch.setenv("GRAVHMC_RESIDENT", resident)
     rng = np.random.default_rng(11)
     if case == "small_tv":
         p = gold("potential_small.npz")
@@ -915,6 +919,7 @@ def test_batched_chains_match_single_chain_engines(G, case):
     low, high = 0.0 * wm, hi * wm
     x0s = np.stack([(0.001 + 0.002 * c) * wm for c in range(C)])
     eb.batch_init(x0s, low, high)
+    monkeypatch.setenv("GRAVHMC_RESIDENT", "0")     # the single-chain contexts: sweep path
     singles = []
     for c in range(C):
         e, _ = make()
@@ -936,6 +941,8 @@ def test_batched_chains_match_single_chain_engines(G, case):
     assert n_acc > 0
     if case == "small_tv":
         assert n_rej > 0
+    took_resident = eb.chain_stats()["resident_launches"] > 0
+    assert took_resident == (resident == "1" and case != "random_damping_big")
     for e in singles + [eb]:
         e.close()
 
