@@ -640,6 +640,37 @@ def test_resident_chain_kernel_matches_sweep_path(G, monkeypatch, reg):
         assert am == bm and (reg == "MS" or (sum(bm) == 3 and bm[-1]))
 
 
+@pytest.mark.parametrize("N,M", [(1, 1), (2, 7), (15, 8), (16, 9), (17, 255), (100, 256), (257, 257),
+                                 (1000, 1000), (1024, 3000), (64, 20000), (333, 4099)])
+def test_resident_chain_kernel_shapes(G, monkeypatch, N, M):
+    """Edge shapes of the resident kernel's partition (fewer workgroups than clusters, one-cell
+    workgroups, ragged last workgroup, row chunks of more than 32 rows, N at its limit): same chain
+    as the sweep path."""
+    rng = np.random.default_rng(N * 100003 + M)
+    A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.2, 2.0, size=M))
+    dobs = rng.normal(size=N) * 3
+    trajs = [(int(rng.integers(1, 6)), rng.normal(size=M) * 0.05, float(rng.uniform())) for _ in range(9)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GRAVHMC_RESIDENT", mode)
+        e = G.Engine(N, M)
+        e.upload_G(A)
+        w = e.weight(0.5)
+        e.set_data(dobs)
+        e.set_reg("MS", 0.7, 0.01, None, 0.001 * w)
+        e.chain_init(0.002 * w, 0.0 * w, 0.5 * w)
+        out = []
+        e.run_chain(iter(trajs), 0.01, lambda L, acc, o, x: out.append((acc, o.copy())), batch=4)
+        res[mode] = (out, e.chain_get_x(), e.chain_stats()["resident_launches"])
+        e.close()
+    (a, ax, la), (b, bx, lb) = res["0"], res["1"]
+    assert la == 0 and lb > 0
+    assert len(a) == len(b) == len(trajs)
+    for (a1, o1), (a2, o2) in zip(a, b):
+        assert a1 == a2 and np.abs(o1 - o2).max() <= 1e-11 * np.abs(o1).max()
+    assert relmax(bx, ax) < 1e-11
+
+
 def test_resident_chain_kernel_times_out_cleanly(G, monkeypatch, capfd):
     """Every wait inside the resident kernel is bounded.  With the test hook the workgroups wait for
     partners that never run: the kernel gives up after 2 s without touching the chain, the context
