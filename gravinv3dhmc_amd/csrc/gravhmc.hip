@@ -150,7 +150,7 @@ struct gh_ctx {
     // resident chain kernel (resident.hip.h): G held in LDS across a whole batch of trajectories
     struct Resident {
         int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
-        int cpw = 0, nwg = 0, rc = 0;
+        int cpw = 0, nwg = 0, rc = 0, ct = 0;  // ct: columns per wave kept in registers
         size_t lds = 0;
         ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xccg = nullptr;
         double *xpub = nullptr;
@@ -1684,17 +1684,33 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
 typedef void (*resident_fn)(ResArgs);
 enum { GH_RESIDENT_ABORTED = 1000 };  // internal: chain_run_resident gave up, state untouched
 
-static resident_fn resident_for(int rc)
+// rc: double2 chunks per lane and column; cw: columns a wave keeps in registers (0: none, dots
+// read LDS).  Only register copies of at most 20 double2 (80 VGPRs: no spills) are compiled.
+extern "C++" {
+template <int RC>
+static resident_fn resident_for_rc(int cw)
+{
+    switch (cw) {
+    case 1: return resident_chain_kernel<RC, 1>;
+    case 2: if constexpr (RC * 2 <= 20) return resident_chain_kernel<RC, 2>; break;
+    case 3: if constexpr (RC * 3 <= 20) return resident_chain_kernel<RC, 3>; break;
+    case 4: if constexpr (RC * 4 <= 20) return resident_chain_kernel<RC, 4>; break;
+    }
+    return resident_chain_kernel<RC, 0>;
+}
+}  // extern "C++"
+
+static resident_fn resident_for(int rc, int cw)
 {
     switch (rc) {
-    case 1: return resident_chain_kernel<1>;
-    case 2: return resident_chain_kernel<2>;
-    case 3: return resident_chain_kernel<3>;
-    case 4: return resident_chain_kernel<4>;
-    case 5: return resident_chain_kernel<5>;
-    case 6: return resident_chain_kernel<6>;
-    case 7: return resident_chain_kernel<7>;
-    case 8: return resident_chain_kernel<8>;
+    case 1: return resident_for_rc<1>(cw);
+    case 2: return resident_for_rc<2>(cw);
+    case 3: return resident_for_rc<3>(cw);
+    case 4: return resident_for_rc<4>(cw);
+    case 5: return resident_for_rc<5>(cw);
+    case 6: return resident_for_rc<6>(cw);
+    case 7: return resident_for_rc<7>(cw);
+    case 8: return resident_for_rc<8>(cw);
     }
     return nullptr;
 }
@@ -1719,8 +1735,10 @@ static bool resident_plan(gh_ctx *c)
     r.nwg = (int)((c->M + cpw - 1) / cpw);
     if (r.nwg > RES_MAX_WG) return false;
     r.rc = (int)((c->ld / 2 + 63) / 64);
+    // columns per wave for the register copy of the dots pass (0: the wave has more than 4)
+    r.ct = (env_int("GRAVHMC_RESIDENT_REGS", 1) && cpw <= 4 * RES_WAVES) ? (cpw + RES_WAVES - 1) / RES_WAVES : 0;
     r.lds = lds;
-    resident_fn f = resident_for(r.rc);
+    resident_fn f = resident_for(r.rc, r.ct);
     if (!f) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -1763,7 +1781,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     if (q.C < 1 || q.C > RES_MAX_CHAINS || lds > (size_t)r.lds_max)
         return fail(c, GH_ERR_ARG, "resident chain kernel: %d chains do not fit the LDS", q.C);
     if (lds > r.lds_set) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(resident_for(r.rc)),
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(resident_for(r.rc, r.ct)),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         r.lds_set = lds;
     }
@@ -1867,7 +1885,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     // A plain launch: the grid was checked against the occupancy query in resident_plan (one
     // workgroup per CU by its LDS request), which is all hipLaunchCooperativeKernel would add;
     // residency itself is the same for both, and every wait inside the kernel is bounded.
-    hipLaunchKernelGGL(resident_for(r.rc), dim3(r.nwg), dim3(RES_THREADS), lds, c->stream, a);
+    hipLaunchKernelGGL(resident_for(r.rc, r.ct), dim3(r.nwg), dim3(RES_THREADS), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     if (c->prof) HIPCHK(c, hipEventRecord(r.ev1, c->stream));
     unsigned h_sync[4] = {0, 0, 0, 0};

@@ -198,8 +198,13 @@ __device__ __forceinline__ double res_block_sum(double v, double *red)
     return t;
 }
 
-// RC = double2 chunks a lane holds of one column / of r: 64*RC*2 >= ld
-template <int RC>
+// RC = double2 chunks a lane holds of one column / of r: 64*RC*2 >= ld.
+// CW > 0: every wave keeps its (at most CW = ceil(columns per workgroup / 8)) columns of the
+// wave-per-column dots pass in registers (4 CW RC VGPRs) as well: LDS bandwidth bounds the local
+// part of a step, and with this copy the LDS one is read once per step (by the forward pass)
+// instead of twice.  Measured at C1 (RC 5, CW 3): 8.3 -> 7.1 us per evaluation; a register copy
+// for the forward pass instead (thread = row pair, 96 VGPRs) gave 7.7, both together spill.
+template <int RC, int CW>
 __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -263,6 +268,19 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     }
     if (a.have_state && tid < 3 * a.C) ucs[tid] = a.ucur_io[tid];
     if (tid == 0) *flag_s = 1;
+    d2 gq_reg[CW > 0 ? CW : 1][RC];
+    if (CW > 0) {
+        __syncthreads();  // Gs complete
+#pragma unroll
+        for (int q = 0; q < CW; ++q) {
+            const int c = wave + q * RES_WAVES;
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                const int e = lane + 64 * k;
+                gq_reg[q][k] = (c < nc && e < ld2) ? Gs2[c * ld2 + e] : d2{0.0, 0.0};
+            }
+        }
+    }
 
     // Logical clusters: workgroups with equal w % 8 (the dispatcher deals workgroups round-robin
     // over the 8 XCDs, so a cluster normally shares one L2).  The reduction order is defined by the
@@ -496,9 +514,9 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         return true;
     };
 
-    // Wave-per-column dots with r_s -> full gradient (four columns of a wave in flight).
-    // what = 0: store it in gs; 1: leapfrog update with momentum coefficient cu; 2: last half
-    // momentum step (returns this workgroup's sum of p^2, stores the gradient in gs).
+    // Wave-per-column dots with r_s (four columns of a wave in flight), then one thread per column:
+    // full gradient and, what = 0: store it in gs; 1: leapfrog update with momentum coefficient
+    // cu; 2: last half momentum step (returns this workgroup's sum of p^2, gradient in gs).
     auto dots = [&](int what, double cu) -> double {
         __syncthreads();  // r_s, gr complete
         d2 rr[RC];
@@ -507,64 +525,79 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             const int e = lane + 64 * k;
             rr[k] = (e < ld2) ? r_s2[e] : d2{0.0, 0.0};
         }
-        double ppw = 0.0;
-        for (int cb = wave; cb < nc; cb += 4 * RES_WAVES) {
-            double s[4];
+        if (CW > 0) {
+            double s[CW > 0 ? CW : 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = cb + q * RES_WAVES;
+            for (int q = 0; q < CW; ++q) {
                 s[q] = 0.0;
-                if (c < nc) {
 #pragma unroll
-                    for (int k = 0; k < RC; ++k) {
-                        const int e = lane + 64 * k;
-                        if (e < ld2) {
-                            const d2 g = Gs2[c * ld2 + e];
-                            s[q] += g.x * rr[k].x;
-                            s[q] += g.y * rr[k].y;
+                for (int k = 0; k < RC; ++k) {
+                    s[q] += gq_reg[q][k].x * rr[k].x;
+                    s[q] += gq_reg[q][k].y * rr[k].y;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CW; ++q) s[q] = wave_sum_dpp(s[q]);
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                const int c = wave + q * RES_WAVES;
+                if (lane == 0 && c < nc) gs[c] = s[q];
+            }
+        } else {
+            for (int cb = wave; cb < nc; cb += 4 * RES_WAVES) {
+                double s[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cb + q * RES_WAVES;
+                    s[q] = 0.0;
+                    if (c < nc) {
+#pragma unroll
+                        for (int k = 0; k < RC; ++k) {
+                            const int e = lane + 64 * k;
+                            if (e < ld2) {
+                                const d2 g = Gs2[c * ld2 + e];
+                                s[q] += g.x * rr[k].x;
+                                s[q] += g.y * rr[k].y;
+                            }
                         }
                     }
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s[q] = wave_sum_dpp(s[q]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = cb + q * RES_WAVES;
-                if (c >= nc) continue;
-                const double g = 2.0 * s[q] + gr[c];
-                if (what == 1) {
-                    double pj = ps[c] - cu * g;
-                    double xj = xs[c] + a.dt * pj;
-                    const double chi = hi[c], clo = lo[c];
-                    if (xj > chi) {
-                        xj = chi;
-                        pj = -pj;
-                    } else if (xj < clo) {
-                        xj = clo;
-                        pj = -pj;
-                    }
-                    if (lane == 0) {
-                        ps[c] = pj;
-                        xs[c] = xj;
-                    }
-                } else {
-                    if (what == 2) {
-                        const double pf = ps[c] - cu * g;
-                        ppw += pf * pf;
-                    }
-                    if (lane == 0) gs[c] = g;
+                for (int q = 0; q < 4; ++q) s[q] = wave_sum_dpp(s[q]);
+                if (lane < 4) {
+                    const int c = cb + lane * RES_WAVES;
+                    const double sv = lane == 0 ? s[0] : lane == 1 ? s[1] : lane == 2 ? s[2] : s[3];
+                    if (c < nc) gs[c] = sv;
                 }
             }
         }
+        __syncthreads();
+        double pp = 0.0;
+        if (tid < nc) {
+            const double g = 2.0 * gs[tid] + gr[tid];
+            if (what == 1) {
+                double pj = ps[tid] - cu * g;
+                double xj = xs[tid] + a.dt * pj;
+                const double chi = hi[tid], clo = lo[tid];
+                if (xj > chi) {
+                    xj = chi;
+                    pj = -pj;
+                } else if (xj < clo) {
+                    xj = clo;
+                    pj = -pj;
+                }
+                ps[tid] = pj;
+                xs[tid] = xj;
+            } else {
+                if (what == 2) {
+                    const double pf = ps[tid] - cu * g;
+                    pp = pf * pf;
+                }
+                gs[tid] = g;
+            }
+        }
         if (what != 2) return 0.0;
-        __syncthreads();
-        if (lane == 0) red[wave] = ppw;
-        __syncthreads();
-        double t = 0.0;
-        for (int v = 0; v < RES_WAVES; ++v) t += red[v];
-        __syncthreads();
-        return t;
+        return res_block_sum(pp, red);
     };
 
     // all-gather of {R share, p'p after, p'p before} over the workgroups, summed in a fixed order
