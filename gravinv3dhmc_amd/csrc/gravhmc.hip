@@ -128,6 +128,8 @@ struct gh_ctx {
         int *indices = nullptr;
         double *data = nullptr;
         double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
+        double *F = nullptr;  // dense model-space form Awcp W (ld x M, column-major), built on demand
+        bool F_valid = false;
     } wv;
 
     // several chains sharing every sweep of G (fp64 MFMA path, batch.hip.h)
@@ -680,6 +682,43 @@ static int wavelet_forward(gh_ctx *c, const double *x, double *d_out)
     spmv_kernel<<<dim3((unsigned)((c->ld + 3) / 4)), dim3(256), 0, c->stream>>>(
         w.indptr, w.indices, w.data, w.coeff, c->N, c->ld, d_out);
     HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+// F = Awcp W as a dense N x M matrix: column j is the compressed forward of the unit model e_j
+// (exactly the operator the reference applies, thresholding included; only the association of the
+// sums differs from DWT-then-SpMV).  For problems small enough for the resident chain kernel, which
+// keeps it in LDS: 64 unit vectors per batch of DWT passes + one batched SpMV.
+static int wavelet_dense_form(gh_ctx *c)
+{
+    gh_ctx::Wavelet &w = c->wv;
+    if (w.F_valid) return GH_OK;
+    const int64_t M = c->M, Mp = w.Mp, B = 64;
+    TRY(dalloc(c, &w.F, (size_t)c->ld * (size_t)M));
+    double *X = nullptr, *C = nullptr, *S1 = nullptr, *S2 = nullptr;
+    HIPCHK(c, hipMalloc((void **)&X, sizeof(double) * (size_t)(B * M)));
+    HIPCHK(c, hipMalloc((void **)&C, sizeof(double) * (size_t)(B * Mp)));
+    HIPCHK(c, hipMalloc((void **)&S1, sizeof(double) * (size_t)(B * Mp)));
+    HIPCHK(c, hipMalloc((void **)&S2, sizeof(double) * (size_t)(B * Mp)));
+    int rc = GH_OK;
+    for (int64_t j0 = 0; j0 < M && rc == GH_OK; j0 += B) {
+        const int64_t nb = std::min(B, M - j0);
+        unit_rows_kernel<<<dim3((unsigned)std::min<int64_t>(1024, (nb * M + 255) / 256)), dim3(256), 0, c->stream>>>(
+            X, M, j0, nb);
+        hipMemsetAsync(C, 0, sizeof(double) * (size_t)(nb * Mp), c->stream);
+        rc = run_dwt(c, X, M, nb, C, S1, S2);
+        if (rc != GH_OK) break;
+        spmv_kernel<<<dim3((unsigned)((c->ld + 3) / 4), (unsigned)nb), dim3(256), 0, c->stream>>>(
+            w.indptr, w.indices, w.data, C, c->N, c->ld, w.F + j0 * c->ld, Mp, c->ld);
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(X);
+    hipFree(C);
+    hipFree(S1);
+    hipFree(S2);
+    if (rc != GH_OK) return rc;
+    if (e != hipSuccess) return fail(c, GH_ERR_HIP, "wavelet_dense_form: %s", hipGetErrorString(e));
+    w.F_valid = true;
     return GH_OK;
 }
 
@@ -1442,6 +1481,8 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     TRY(dalloc(c, &w.s1, (size_t)Mp));
     TRY(dalloc(c, &w.s2, (size_t)Mp));
     w.on = true;
+    w.F_valid = false;
+    c->rs.state = 0;  // plan the resident chain kernel again (it would need the dense form)
     c->chain_ready = false;
     if (nnz_out) *nnz_out = w.nnz;
     if (ncols_out) *ncols_out = Mp;
@@ -1723,7 +1764,7 @@ static bool resident_plan(gh_ctx *c)
     if (r.state != 0) return r.state > 0;
     r.state = -1;
     if (env_int("GRAVHMC_RESIDENT", 1) == 0) return false;
-    if (c->mf || c->wv.on || c->sh.kind != 0 || c->n_panels != 1 || c->ld > 1024 || !c->G) return false;
+    if (c->mf || c->sh.kind != 0 || c->n_panels != 1 || c->ld > 1024 || !c->G) return false;
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess)
         return false;
@@ -1737,6 +1778,10 @@ static bool resident_plan(gh_ctx *c)
     r.rc = (int)((c->ld / 2 + 63) / 64);
     // columns per wave for the register copy of the dots pass (0: the wave has more than 4)
     r.ct = (env_int("GRAVHMC_RESIDENT_REGS", 1) && cpw <= 4 * RES_WAVES) ? (cpw + RES_WAVES - 1) / RES_WAVES : 0;
+    if (r.ct * ((int)((c->ld / 2 + 63) / 64)) > 20) r.ct = 0;  // (what resident_for compiles)
+    // wavelet-compressed forward: LDS holds its dense model-space form, the dots need their own
+    // (register) copy of Aw
+    if (c->wv.on && (r.ct == 0 || wavelet_dense_form(c) != GH_OK)) return false;
     r.lds = lds;
     resident_fn f = resident_for(r.rc, r.ct);
     if (!f) return false;
@@ -1834,6 +1879,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
         HIPCHK(c, hipMemcpyAsync(r.chain, q.chain_of, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
     ResArgs a{};
     a.G = c->G;
+    a.Gl = c->wv.on ? c->wv.F : c->G;
     a.ld = c->ld;
     a.N = c->N;
     a.M = c->M;

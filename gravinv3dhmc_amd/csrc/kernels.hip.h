@@ -363,7 +363,9 @@ struct RegArgs {
 // stencil kinds are read from a.x): returns dR/dx_j, adds the cell's share of R to `val`
 // (potential.py:719-736, 775-810).  The finite-difference operator of potential.py:266-361 is never
 // materialised.
-template <bool HALO = false>
+// SC1: the neighbours' model values are read with agent-scope (sc1) loads that bypass this CU's L1
+// (resident chain kernel: other workgroups wrote them, write-through, earlier in the same launch).
+template <bool HALO = false, bool SC1 = false>
 __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double xj, double &val)
 {
     const double v = xj - a.mwapr[j];
@@ -387,6 +389,11 @@ __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double x
             if (HALO) {
                 if (q >= a.M) return a.xhi[q - a.M] - a.ahi[q - a.M];
                 if (q < 0) return a.xlo[q + P] - a.alo[q + P];
+            }
+            if (SC1) {
+                const unsigned long long b = __hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(a.x + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return __longlong_as_double((long long)b) - a.mwapr[q];
             }
             return a.x[q] - a.mwapr[q];
         };
@@ -1042,14 +1049,17 @@ csr_fill_kernel(const double *C, int64_t ncols, double thr, const int64_t *indpt
     (void)base_s;
 }
 
-// y = A x for CSR A: one wave per row, fixed-order lane-strided partial sums + butterfly
+// y = A x for CSR A: one wave per row, fixed-order lane-strided partial sums + butterfly.
+// gridDim.y > 1: a batch of vectors, x and y advance by xb / yb doubles per batch entry.
 __global__ void __launch_bounds__(256)
 spmv_kernel(const int64_t *indptr, const int *indices, const double *data, const double *x,
-            int64_t nrows, int64_t ld, double *y)
+            int64_t nrows, int64_t ld, double *y, int64_t xb = 0, int64_t yb = 0)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= ld) return;
+    x += (int64_t)blockIdx.y * xb;
+    y += (int64_t)blockIdx.y * yb;
     double s = 0.0;
     if (row < nrows) {
         const int64_t k1 = indptr[row + 1];
@@ -1057,6 +1067,16 @@ spmv_kernel(const int64_t *indptr, const int *indices, const double *data, const
     }
     s = wave_allreduce_sum(s);
     if (lane == 0) y[row] = s;
+}
+
+// rows j0 .. j0+nb-1 of the M x M identity (unit model vectors), row stride M
+__global__ void __launch_bounds__(256) unit_rows_kernel(double *X, int64_t M, int64_t j0, int64_t nb)
+{
+    const int64_t n = nb * M;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int64_t b = idx / M, j = idx - b * M;
+        X[idx] = (j == j0 + b) ? 1.0 : 0.0;
+    }
 }
 
 // Diagnostic only (gh_debug_stream_read): pure streaming read of G, no reductions/barriers --

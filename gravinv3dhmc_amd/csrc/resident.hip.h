@@ -45,7 +45,10 @@ constexpr long long RES_TIMEOUT_TICKS = 200000000LL;  // 2 s of the 100 MHz wall
 using u64 = unsigned long long;
 
 struct ResArgs {
-    const double *G;
+    const double *G;   // Aw: the dots pass (adjoint)
+    const double *Gl;  // the forward pass' operator, held in LDS: Aw itself, or the dense model-space
+                       // form F = Awcp W of the wavelet-compressed forward (then CW > 0: the dots
+                       // read Aw from their register copy)
     int64_t ld, N, M;
     int cols_per_wg, nwg;
     int try_local;  // 1: keep intra-cluster traffic in the XCD's L2 when the placement allows it
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
 
     // ---- load the workgroup's columns (contiguous in the column-major G) and per-cell vectors
     {
-        const d2 *src = reinterpret_cast<const d2 *>(a.G + j0 * a.ld);
+        const d2 *src = reinterpret_cast<const d2 *>(a.Gl + j0 * a.ld);
         d2 *dst = reinterpret_cast<d2 *>(Gs);
         const int tot = nc * ld2;
         for (int e = tid; e < tot; e += RES_THREADS) dst[e] = __builtin_nontemporal_load(src + e);
@@ -270,14 +273,14 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     if (tid == 0) *flag_s = 1;
     d2 gq_reg[CW > 0 ? CW : 1][RC];
     if (CW > 0) {
-        __syncthreads();  // Gs complete
 #pragma unroll
         for (int q = 0; q < CW; ++q) {
             const int c = wave + q * RES_WAVES;
+            const d2 *col = reinterpret_cast<const d2 *>(a.G + (j0 + c) * a.ld);
 #pragma unroll
             for (int k = 0; k < RC; ++k) {
                 const int e = lane + 64 * k;
-                gq_reg[q][k] = (c < nc && e < ld2) ? Gs2[c * ld2 + e] : d2{0.0, 0.0};
+                gq_reg[q][k] = (c < nc && e < ld2) ? col[e] : d2{0.0, 0.0};
             }
         }
     }
@@ -494,15 +497,12 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             r_s2[tid] = rv;
         }
         if (stencil) {
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            // regulariser of the own cells at xs, neighbours from the published model
+            // regulariser of the own cells at xs, neighbours from the published model: those
+            // stores were write-through and drained before the partials that d -- which has just
+            // been read -- depends on, and the loads bypass L1: no fence needed
             if (tid < nc) {
                 ra.x = a.xpub + (int64_t)par * M;
-                gr[tid] = a.alpha * reg_cell(ra, j0 + tid, xs[tid], val);
+                gr[tid] = a.alpha * reg_cell<false, true>(ra, j0 + tid, xs[tid], val);
             }
         }
         if (last) {

@@ -640,6 +640,38 @@ def test_resident_chain_kernel_matches_sweep_path(G, monkeypatch, reg):
         assert am == bm and (reg == "MS" or (sum(bm) == 3 and bm[-1]))
 
 
+@pytest.mark.parametrize("wavelet", ["1D", "3D"])
+def test_resident_chain_kernel_with_wavelet_forward(G, monkeypatch, wavelet):
+    """Wavelet-compressed forward inside the resident kernel: LDS holds the dense model-space form
+    F = Awcp W of the compressed operator (column j = compressed forward of the unit model e_j,
+    thresholding included), the dots read Aw from their register copy.  Same chain as the
+    sweep path's DWT + SpMV to rounding, and F itself against gh_forward_wavelet."""
+    p = gold("potential_small.npz")
+    wm = p["wm"]
+    M = wm.size
+    rng = np.random.default_rng(21)
+    trajs = [(int(rng.integers(1, 9)), rng.normal(size=M) * 0.3, float(rng.uniform())) for _ in range(30)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GRAVHMC_RESIDENT", mode)
+        gm = _module_small(G, p, wavelet=wavelet)
+        eng = gm._engine
+        eng.set_reg("TV", 1.0, 0.001, p["shape"], 0.001 * wm)
+        eng.chain_init(0.001 * wm, 0.0 * wm, 0.02 * wm)
+        out = []
+        eng.run_chain(iter(trajs), 0.02, lambda L, acc, o, x: out.append((acc, o.copy(), x)), want_x=True, batch=8)
+        res[mode] = (out, eng.chain_get_x(), eng.chain_get_dsyn(), eng.chain_stats()["resident_launches"])
+        eng.close()
+    (a, ax, ad, la), (b, bx, bd, lb) = res["0"], res["1"]
+    assert la == 0 and lb > 0
+    n_acc = sum(t[0] for t in a)
+    assert 0 < n_acc < len(trajs)
+    for (a1, o1, x1), (a2, o2, x2) in zip(a, b):
+        assert a1 == a2 and np.abs(o1 - o2).max() <= 1e-11 * np.abs(o1).max()
+        assert (x1 is None) == (x2 is None) and (x1 is None or relmax(x2, x1) < 1e-11)
+    assert relmax(bx, ax) < 1e-11 and relmax(bd, ad) < 1e-11
+
+
 @pytest.mark.parametrize("N,M", [(1, 1), (2, 7), (15, 8), (16, 9), (17, 255), (100, 256), (257, 257),
                                  (1000, 1000), (1024, 3000), (64, 20000), (333, 4099)])
 def test_resident_chain_kernel_shapes(G, monkeypatch, N, M):
