@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -161,7 +163,6 @@ struct gh_ctx {
         int Kcap = 0;
         int *L = nullptr, *accepted = nullptr, *n_run = nullptr, *chain = nullptr;
         int lds_max = 0;
-        size_t lds_set = 0;   // dynamic LDS size the kernel's attribute currently allows
         // several chains sharing the resident G (gh_batch_* on small problems)
         double *bx = nullptr, *bg = nullptr, *bu = nullptr;  // C x M models, C x M gradients, 3 C potentials
         bool b_on = false, b_state = false;
@@ -302,6 +303,20 @@ static int env_int(const char *name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to a context: several
+// contexts of one process share an instantiation, so the allowance is only ever raised.
+static hipError_t allow_dynamic_lds(const void *func, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<const void *, size_t> allowed;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &cur = allowed[func];
+    if (bytes <= cur) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
+
 // Choose team width / registers per thread from ld, and the column partition from M.
 static int configure_sweep(gh_ctx *c)
 {
@@ -348,8 +363,7 @@ static int configure_sweep(gh_ctx *c)
     if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
     sweep_fn f = sweep_for(c);
     if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(f),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), c->lds_bytes));
     return GH_OK;
 }
 
@@ -1785,12 +1799,10 @@ static bool resident_plan(gh_ctx *c)
     r.lds = lds;
     resident_fn f = resident_for(r.rc, r.ct);
     if (!f) return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
+    if (allow_dynamic_lds(reinterpret_cast<const void *>(f), lds) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    r.lds_set = lds;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), RES_THREADS,
                                                      lds) != hipSuccess || per_cu < 1 ||
@@ -1825,11 +1837,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     const size_t lds = resident_lds_doubles(c->ld, r.cpw, q.C) * sizeof(double);
     if (q.C < 1 || q.C > RES_MAX_CHAINS || lds > (size_t)r.lds_max)
         return fail(c, GH_ERR_ARG, "resident chain kernel: %d chains do not fit the LDS", q.C);
-    if (lds > r.lds_set) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(resident_for(r.rc, r.ct)),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        r.lds_set = lds;
-    }
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(resident_for(r.rc, r.ct)), lds));
     if (!r.slabg) {
         // (+8 rows / entries: the abort test announces one phantom workgroup per cluster)
         TRY(dalloc(c, &r.slabg, (size_t)(r.nwg + 8) * (size_t)c->ld * 2));

@@ -586,6 +586,24 @@ def test_speculative_chaining_is_bit_identical(G, monkeypatch):
         eng.close()
 
 
+def test_two_contexts_share_a_kernel_instantiation(G):
+    """The dynamic-LDS allowance is a property of the kernel, not of a context: a second context
+    with a smaller request on the same sweep instantiation (N = 9000 and 10000: both 16-wave teams
+    with five double2 per thread) must not take the first one's 80 KB away."""
+    rng = np.random.default_rng(4)
+    engs = []
+    for N in (10000, 9000):
+        A = np.asfortranarray(rng.normal(size=(N, 96)))
+        e = G.Engine(N, 96)
+        e.upload_G(A)
+        engs.append((e, A))
+    for e, A in engs + engs[::-1]:
+        x = rng.normal(size=96)
+        assert relmax(e.forward(x), A @ x) < 1e-13
+    for e, _ in engs:
+        e.close()
+
+
 # ------------------------------------------------------------ resident chain kernel
 
 @pytest.mark.parametrize("reg", ["Damping", "MS", "Smoothness", "TV"])
