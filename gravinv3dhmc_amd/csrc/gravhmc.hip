@@ -21,894 +21,13 @@
 
 using namespace ghk;
 
-static thread_local std::string g_create_error;
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
-
-struct gh_ctx {
-    int device = 0;
-    int64_t N = 0, M = 0, ld = 0;
-    int cus = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    std::vector<void *> allocs;
-
-    // geometry / kernel
-    double *obs[3] = {nullptr, nullptr, nullptr};
-    double *bounds = nullptr;
-    int cell_kind = -1;
-    double ratio = 1.6;
-    bool have_obs = false, have_cells = false, have_G = false, weighted = false;
-    double *G = nullptr;
-    int64_t warn_cells = 0, leaves = 0;
-    bool mf = false;          // matrix-free: entries are re-evaluated, G is never stored
-    bool dense_ok = true;     // N fits the register-resident sweep (<= 16384 rows)
-    double *tconv = nullptr;  // tesseroid obs converted to (lon rad, sin lat, cos lat, radius)
-    int64_t mf_cells_per_chunk = 0;
-
-    // sweep configuration
-    int TW = 0, EPT2 = 0, PF = 1;
-    int n_panels = 1;        // row panels of the dense sweep (N > 16384 rows: > 1, two reads of G per step)
-    int64_t panel_rows = 0;
-    double *gbuf = nullptr;   // gradient accumulated over the panels
-    bool NT = false;
-    int n_teams = 0, grid = 0;
-    int n_teams_sweep = 0;   // teams of the sweep launch (n_teams may be larger: size of the pp partials)
-    int64_t cols_per_team = 0;
-    size_t lds_bytes = 0;
-
-    // problem vectors
-    double *dobs_c = nullptr, *gfix = nullptr, *mwapr = nullptr, *wm = nullptr, *wm2 = nullptr;
-    double *low = nullptr, *high = nullptr;
-    bool have_data = false, have_fix = false, have_reg = false;
-    int reg_kind = 0, shape[3] = {1, 1, 1};
-    double alpha = 1.0, beta = 0.01;
-
-    // chain state: three (r, greg, d, scal) sets and three x buffers rotate between "current
-    // sample", "proposal" and "speculative first step of the next trajectory"; set/buffer 3 is
-    // private to gh_misfit_and_grad.  Swapping indices makes accept/reject free.
-    struct StateSet {
-        double *r = nullptr, *greg = nullptr, *d = nullptr, *scal = nullptr;
-    } st[4];
-    double *xb[4] = {nullptr, nullptr, nullptr, nullptr};
-    double *pb[2] = {nullptr, nullptr};
-    double *pn = nullptr;  // momentum of the NEXT trajectory (gh_chain_prefetch_momentum)
-    int cur = 0, xcur = 0;
-    bool pn_valid = false, spec_valid = false;
-    double pn_probe[3] = {0, 0, 0}, spec_probe[3] = {0, 0, 0};
-    double spec_dt = 0.0, spec_pp0 = 0.0, pn_pp0 = 0.0, spec_U[3] = {0, 0, 0};
-    int spec_set = 0, spec_x = 0, spec_p = 0;
-    int64_t spec_hits = 0, spec_misses = 0, accept_count = 0;
-    double *slab2 = nullptr;
-    int slab2_rows = 0;
-    double *slab = nullptr, *dpart = nullptr, *regpart = nullptr, *pp_part = nullptr,
-           *ppn_part = nullptr, *pp0_part = nullptr, *scal_all = nullptr;
-    double *tmpM = nullptr, *tmpN = nullptr;
-    int n_dpart = 0, n_regpart = 0, n_pp0 = 0;
-    double *h_scal = nullptr;  // pinned: scalars + partial sums
-    size_t h_scal_n = 0;
-    bool chain_ready = false;
-    double U_cur[3] = {0, 0, 0};
-
-    // column-block sharding of ONE chain over several GPUs: this context holds
-    // the cells [m0, m0 + M) of M_global; N-vectors are replicated, the forward partials are
-    // summed across ranks once per potential evaluation.
-    struct Shard {
-        int kind = 0;  // 0 single GPU, 1 RCCL all-reduce on the stream, 2 host callback
-        int rank = 0, world = 1;
-        int64_t M_global = 0, m0 = 0;
-        ncclComm_t comm = nullptr;
-        gh_allreduce_fn cb = nullptr;
-        void *user = nullptr;
-        double *buf = nullptr;    // device: [d partial (ld) | R partial | pad | boundary planes (halo)]
-        double *hbuf = nullptr;   // pinned staging for the callback path
-        size_t buf_n = 0;         // doubles in buf / hbuf
-        // Smoothness / TV on cells sharded in whole z-planes: the ranks exchange their boundary
-        // planes of the model once per evaluation (inside the forward partial's all-reduce)
-        bool halo = false;
-        int64_t P = 0;            // cells per plane (ny * nx)
-        double *alo = nullptr, *ahi = nullptr;  // prior model of the planes below / above
-        double *rb = nullptr;     // regulariser partial for its own (2-double) all-reduce
-        int64_t collectives = 0;
-    } sh;
-
-    // wavelet-compressed forward operator (compressor1D/3D): CSR N x Mp on the device
-    struct Wavelet {
-        bool on = false;
-        int dims = 0, levels = 2;
-        int shape[3] = {1, 1, 1};
-        int X[5][3];      // X[i]: extents of the blocks level i produces (X[0] = model shape)
-        int offd[5][3];   // packed offset of level i's detail pieces (pywt.coeffs_to_array)
-        int D[3] = {1, 1, 1};
-        bool tax[3] = {false, false, true};  // transformed axes
-        int64_t Mp = 0, nnz = 0;
-        double thr = 1e-3;
-        int64_t *indptr = nullptr;
-        int *indices = nullptr;
-        double *data = nullptr;
-        double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
-        double *F = nullptr;  // dense model-space form Awcp W (ld x M, column-major), built on demand
-        bool F_valid = false;
-    } wv;
-
-    // several chains sharing every sweep of G (fp64 MFMA path, batch.hip.h)
-    struct Batch {
-        int C = 0;
-        double *Xc = nullptr, *Rtc = nullptr, *GREGc = nullptr, *Dc = nullptr;   // current states
-        double *Xw[2] = {nullptr, nullptr}, *Pw[2] = {nullptr, nullptr};
-        double *Rtw = nullptr, *GREGw = nullptr, *Dw = nullptr, *scal = nullptr;
-        double *slab = nullptr, *regpart = nullptr, *pp_part = nullptr, *pp0_part = nullptr;
-        double *stage = nullptr;  // C x M rows as the host passes them
-        double *Gb = nullptr;     // second copy of G in MFMA operand order (adjoint), if HBM allows
-        double *h = nullptr;      // pinned
-        int n_colblocks = 0, n_regblocks = 0, n_waves = 0, n_pp0 = 0;
-        int64_t cols_per_block = 0;
-        double U[CB][3];
-        bool ready = false;
-        int64_t sweeps = 0;
-    } bt;
-
-    // resident chain kernel (resident.hip.h): G held in LDS across a whole batch of trajectories
-    struct Resident {
-        int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
-        int cpw = 0, nwg = 0, rc = 0, ct = 0;  // ct: columns per wave kept in registers
-        size_t lds = 0;
-        ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xccg = nullptr;
-        double *xpub = nullptr;
-        unsigned *abort_w = nullptr;
-        unsigned tag = 0, tagE = 0;  // granule tags used so far (the buffers keep them across launches)
-        int Kcap = 0;
-        int *L = nullptr, *accepted = nullptr, *n_run = nullptr, *chain = nullptr;
-        int lds_max = 0;
-        // several chains sharing the resident G (gh_batch_* on small problems)
-        double *bx = nullptr, *bg = nullptr, *bu = nullptr;  // C x M models, C x M gradients, 3 C potentials
-        bool b_on = false, b_state = false;
-        double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
-        int64_t launches = 0, evals = 0;
-        long long *dbg = nullptr;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    } rs;
-    int64_t prof_res_evals = 0;
-
-    // ring of the last K accepted samples (posterior statistics without text I/O)
-    double *ring = nullptr, *ring_mean = nullptr, *ring_sd = nullptr;
-    int ring_K = 0, ring_next = 0;
-    int64_t ring_count = 0;
-
-    // profiling of the sweeps
-    bool prof = false;
-    int prof_stride = 1;
-    int64_t prof_seen = 0;
-    std::vector<hipEvent_t> ev;
-    size_t ev_used = 0;
-    double prof_ms_acc = 0.0;
-    int64_t prof_launches = 0;
-};
-
-static int fail(gh_ctx *c, int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
-    return code;
-}
-
-#define HIPCHK(c, call)                                                                     \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail((c), e_ == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP,         \
-                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
-                        __LINE__);                                                          \
-    } while (0)
-
-template <typename T>
-static int dalloc(gh_ctx *c, T **out, size_t count, bool zero = true)
-{
-    if (*out) return GH_OK;
-    void *p = nullptr;
-    size_t bytes = (count ? count : 1) * sizeof(T);
-    HIPCHK(c, hipMalloc(&p, bytes));
-    c->allocs.push_back(p);
-    if (zero) HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->stream));
-    *out = static_cast<T *>(p);
-    return GH_OK;
-}
-
-#define TRY(x)                 \
-    do {                       \
-        int rc_ = (x);         \
-        if (rc_ != GH_OK) return rc_; \
-    } while (0)
-
-static int h2d(gh_ctx *c, double *dst, const double *src, size_t n)
-{
-    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller-owned pageable memory: do not outlive the call
-    return GH_OK;
-}
-
-static int d2h(gh_ctx *c, double *dst, const double *src, size_t n)
-{
-    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return GH_OK;
-}
-
-// ----------------------------------------------------------------- sweep dispatch
-
-typedef void (*sweep_fn)(SweepArgs);
-typedef void (*weight_fn)(double *, int64_t, int64_t, int64_t, int, double, double *);
-
-template <int TW, int PF, bool NT>
-static sweep_fn pick_sweep_e(int ept2)
-{
-    switch (ept2) {
-    case 1: return sweep_kernel<TW, 1, PF, NT>;
-    case 2: return sweep_kernel<TW, 2, PF, NT>;
-    case 3: return sweep_kernel<TW, 3, PF, NT>;
-    case 4: return sweep_kernel<TW, 4, PF, NT>;
-    case 5: return sweep_kernel<TW, 5, PF, NT>;
-    case 6: return sweep_kernel<TW, 6, PF, NT>;
-    case 8: return sweep_kernel<TW, 8, PF, NT>;
-    }
-    return nullptr;
-}
-
-template <int TW>
-static sweep_fn pick_sweep(int ept2, int pf, bool nt)
-{
-    if (pf == 2) return nt ? pick_sweep_e<TW, 2, true>(ept2) : pick_sweep_e<TW, 2, false>(ept2);
-    return nt ? pick_sweep_e<TW, 1, true>(ept2) : pick_sweep_e<TW, 1, false>(ept2);
-}
-
-template <int TW>
-static weight_fn pick_weight(int ept2)
-{
-    switch (ept2) {
-    case 1: return weight_kernel<TW, 1>;
-    case 2: return weight_kernel<TW, 2>;
-    case 3: return weight_kernel<TW, 3>;
-    case 4: return weight_kernel<TW, 4>;
-    case 5: return weight_kernel<TW, 5>;
-    case 6: return weight_kernel<TW, 6>;
-    case 8: return weight_kernel<TW, 8>;
-    }
-    return nullptr;
-}
-
-static sweep_fn sweep_for(const gh_ctx *c)
-{
-    if (c->TW == 1) return pick_sweep<1>(c->EPT2, c->PF, c->NT);
-    if (c->TW == 4) return pick_sweep<4>(c->EPT2, c->PF, c->NT);
-    return pick_sweep<16>(c->EPT2, c->PF, c->NT);
-}
-
-static weight_fn weight_for(const gh_ctx *c)
-{
-    if (c->TW == 1) return pick_weight<1>(c->EPT2);
-    if (c->TW == 4) return pick_weight<4>(c->EPT2);
-    return pick_weight<16>(c->EPT2);
-}
-
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
-// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to a context: several
-// contexts of one process share an instantiation, so the allowance is only ever raised.
-static hipError_t allow_dynamic_lds(const void *func, size_t bytes)
-{
-    static std::mutex mu;
-    static std::map<const void *, size_t> allowed;
-    std::lock_guard<std::mutex> lock(mu);
-    size_t &cur = allowed[func];
-    if (bytes <= cur) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) cur = bytes;
-    return e;
-}
-
-// Choose team width / registers per thread from ld, and the column partition from M.
-static int configure_sweep(gh_ctx *c)
-{
-    const int64_t ld = c->ld;
-    int tw, per;  // rows one unit of EPT2 covers = tw*64*2
-    c->n_panels = 1;
-    c->panel_rows = ld;
-    if (ld <= 1024) tw = 1;
-    else if (ld <= 4096) tw = 4;
-    else if (ld <= 16384) tw = 16;
-    else {
-        // more rows than a team can hold in registers: row panels of <= 16384 rows.  The dot
-        // product of a column then spans several launches, so the adjoint and the forward can no
-        // longer share one read of G (two reads per step, like the reference's formulation).
-        tw = 16;
-        c->n_panels = (int)((ld + 10239) / 10240);  // <= 10240 rows: 5 double2 per thread, no spills
-        c->panel_rows = ((ld + c->n_panels - 1) / c->n_panels + 15) / 16 * 16;
-    }
-    per = tw * 128;
-    int e = (int)((c->panel_rows + per - 1) / per);
-    if (e == 7) e = 8;
-    c->TW = tw;
-    c->EPT2 = e;
-    // two columns in flight per team where the registers allow it (16-wave teams with <= 5 double2
-    // per thread: 122 VGPRs, no spills; measured at 6 and 8 double2: 5.4 / 3.1 TB/s against 6.5 / 6.1
-    // with one column in flight)
-    c->PF = env_int("GRAVHMC_PF", (tw == 16 && e <= 5) ? 2 : 1) == 2 ? 2 : 1;
-    // G larger than the Infinity Cache is streamed once per sweep: bypass-friendly loads
-    c->NT = env_int("GRAVHMC_NT", c->ld * c->M * 8 > (int64_t)(512 << 20) ? 1 : 0) != 0;
-    const int wg_teams = (tw == 1) ? 4 : 1;
-    // resident workgroups per CU we size the grid for (register/LDS budget of the kernel)
-    int wg_per_cu = (tw == 16) ? 1 : 4;
-    wg_per_cu = env_int("GRAVHMC_WG_PER_CU", wg_per_cu);
-    int64_t max_teams = (int64_t)c->cus * wg_per_cu * wg_teams;
-    int64_t min_cols = env_int("GRAVHMC_MIN_COLS", tw == 1 ? 2 : 1);
-    int64_t cpt = (c->M + max_teams - 1) / max_teams;
-    if (cpt < min_cols) cpt = min_cols;
-    c->cols_per_team = cpt;
-    c->n_teams = (int)((c->M + cpt - 1) / cpt);
-    c->n_teams_sweep = c->n_teams;
-    c->grid = (c->n_teams + wg_teams - 1) / wg_teams;
-    if (c->n_panels > 1) c->n_teams = std::max(c->n_teams, (int)((c->M + 255) / 256));  // vec_update partials
-    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : c->panel_rows + 2 * (tw + 8)) * sizeof(double);
-    if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
-    sweep_fn f = sweep_for(c);
-    if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), c->lds_bytes));
-    return GH_OK;
-}
-
-static MfGeom mf_geom(const gh_ctx *c)
-{
-    MfGeom g;
-    g.kind = c->cell_kind;
-    g.N = c->N;
-    g.M = c->M;
-    if (c->cell_kind == GH_CELL_TESSEROID) {
-        g.o0 = c->tconv;
-        g.o1 = c->tconv + c->N;
-        g.o2 = c->tconv + 2 * c->N;
-        g.o3 = c->tconv + 3 * c->N;
-    } else {
-        g.o0 = c->obs[0];
-        g.o1 = c->obs[1];
-        g.o2 = c->obs[2];
-        g.o3 = nullptr;
-    }
-    g.bounds6 = c->bounds;
-    g.ratio = c->ratio;
-    return g;
-}
-
-// matrix-free counterpart of one sweep: adjoint/update pass, then forward pass
-static int launch_mf(gh_ctx *c, SweepArgs &a)
-{
-    const MfGeom g = mf_geom(c);
-    const double *wm = c->weighted ? c->wm : nullptr;
-    bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-    if (a.mode & SW_ADJ) {
-        if (!wm) return fail(c, GH_ERR_ARG, "matrix-free adjoint needs gh_weight first");
-        mf_adjoint_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(g, a, wm);
-    }
-    if (a.mode & SW_FWD) {
-        const double *x = (a.mode & SW_UPD) ? a.x_out : a.x_in;
-        mf_forward_kernel<<<dim3((unsigned)((c->ld + 255) / 256), (unsigned)c->grid), dim3(256), 0,
-                            c->stream>>>(g, x, wm, c->mf_cells_per_chunk, c->ld, a.slab);
-    }
-    if (timed) {
-        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_used += 2;
-    }
-    HIPCHK(c, hipGetLastError());
-    return GH_OK;
-}
-
-static int launch_sweep_one(gh_ctx *c, SweepArgs &a)
-{
-    a.G = c->G;
-    a.ld = c->ld;
-    a.M = c->M;
-    a.cols_per_team = c->cols_per_team;
-    a.n_teams = c->n_teams_sweep;
-    const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
-    sweep_fn f = sweep_for(c);
-    // short sweeps: an event pair costs about as much as the kernel, time every 16th launch only
-    bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-    hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), c->lds_bytes, c->stream, a);
-    if (timed) {
-        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_used += 2;
-    }
-    if (c->prof) c->prof_launches += 1;
-    HIPCHK(c, hipGetLastError());
-    return GH_OK;
-}
-
-static int launch_sweep(gh_ctx *c, SweepArgs &a)
-{
-    if (c->mf) return launch_mf(c, a);
-    if (c->n_panels == 1) {
-        a.row0 = 0;
-        a.rows = c->ld;
-        return launch_sweep_one(c, a);
-    }
-    // row panels: adjoint of every panel into gbuf, elementwise update, forward of every panel
-    const SweepArgs full = a;
-    if (full.mode & SW_ADJ) {
-        double *gdst = (full.mode & SW_GOUT) ? full.g_out : c->gbuf;
-        for (int p = 0; p < c->n_panels; ++p) {
-            SweepArgs s = full;
-            s.mode = SW_ADJ | SW_GOUT | (p ? SW_GACC : 0);
-            s.greg = p ? nullptr : full.greg;
-            s.g_out = gdst;
-            s.row0 = (int64_t)p * c->panel_rows;
-            s.rows = std::min<int64_t>(c->panel_rows, c->ld - s.row0);
-            TRY(launch_sweep_one(c, s));
-        }
-        if (full.mode & (SW_UPD | SW_PFIN)) {
-            SweepArgs u = full;
-            vec_update_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(u, gdst, c->M);
-            HIPCHK(c, hipGetLastError());
-        }
-    }
-    if (full.mode & SW_FWD) {
-        for (int p = 0; p < c->n_panels; ++p) {
-            SweepArgs s = full;
-            s.mode = SW_FWD;
-            s.x_in = (full.mode & SW_UPD) ? full.x_out : full.x_in;
-            s.row0 = (int64_t)p * c->panel_rows;
-            s.rows = std::min<int64_t>(c->panel_rows, c->ld - s.row0);
-            TRY(launch_sweep_one(c, s));
-        }
-    }
-    return GH_OK;
-}
-
-// ------------------------------------------------------------------ collective layer
-
-struct RcclApi {
-    void *handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
-                              hipStream_t) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-};
-
-// RCCL is bound at run time: the copy already in the process (e.g. the one torch.distributed
-// loaded) wins, else the ROCm installation's.
-static RcclApi *rccl_api(std::string &err)
-{
-    static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
-        for (const char *n : names) {
-            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (api.handle) break;
-        }
-        if (api.handle) {
-            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
-            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
-            api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
-            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
-            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
-        }
-    }
-    if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.AllReduce) {
-        err = "RCCL (librccl.so) could not be loaded";
-        return nullptr;
-    }
-    return &api;
-}
-
-// In-place sum over ranks of `count` doubles at device pointer `buf`, ordered on the stream.
-static int comm_allreduce(gh_ctx *c, double *buf, int64_t count)
-{
-    gh_ctx::Shard &sh = c->sh;
-    if (sh.kind == 0) return GH_OK;
-    sh.collectives += 1;
-    if (sh.kind == 1) {
-        std::string err;
-        RcclApi *api = rccl_api(err);
-        if (!api) return fail(c, GH_ERR_COMM, "%s", err.c_str());
-        ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, sh.comm, c->stream);
-        if (r != ncclSuccess)
-            return fail(c, GH_ERR_COMM, "ncclAllReduce: %s", api->GetErrorString ? api->GetErrorString(r) : "error");
-        return GH_OK;
-    }
-    // host-staged reducer (e.g. gloo): device -> pinned host -> callback -> device
-    if ((size_t)count > sh.buf_n) return fail(c, GH_ERR_ARG, "all-reduce larger than the staging buffer");
-    HIPCHK(c, hipMemcpyAsync(sh.hbuf, buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (sh.cb(sh.user, sh.hbuf, count) != 0) return fail(c, GH_ERR_COMM, "all-reduce callback failed");
-    HIPCHK(c, hipMemcpyAsync(buf, sh.hbuf, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    return GH_OK;
-}
-
-// The same for a few host scalars (count <= ld).
-static int comm_allreduce_host(gh_ctx *c, double *hv, int64_t count)
-{
-    gh_ctx::Shard &sh = c->sh;
-    if (sh.kind == 0) return GH_OK;
-    if (count > c->ld) return fail(c, GH_ERR_ARG, "gh_shard_allreduce: count too large");
-    if (sh.kind == 2) {
-        sh.collectives += 1;
-        if (sh.cb(sh.user, hv, count) != 0) return fail(c, GH_ERR_COMM, "all-reduce callback failed");
-        return GH_OK;
-    }
-    HIPCHK(c, hipMemcpyAsync(sh.buf, hv, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    TRY(comm_allreduce(c, sh.buf, count));
-    HIPCHK(c, hipMemcpyAsync(hv, sh.buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return GH_OK;
-}
-
-static int shard_common_init(gh_ctx *c, int rank, int world, int64_t M_global, int64_t m0)
-{
-    if (world < 1 || rank < 0 || rank >= world) return fail(c, GH_ERR_ARG, "gh_shard_init: bad rank/world");
-    if (m0 < 0 || m0 + c->M > M_global) return fail(c, GH_ERR_ARG, "gh_shard_init: cell range outside the model");
-    if (c->wv.on) return fail(c, GH_ERR_UNSUPPORTED, "sharding with the wavelet forward is not supported");
-    c->sh.rank = rank;
-    c->sh.world = world;
-    c->sh.M_global = M_global;
-    c->sh.m0 = m0;
-    TRY(dalloc(c, &c->sh.buf, (size_t)c->ld + 8));
-    if (!c->sh.hbuf) HIPCHK(c, hipHostMalloc((void **)&c->sh.hbuf, sizeof(double) * ((size_t)c->ld + 8)));
-    c->sh.buf_n = (size_t)c->ld + 8;
-    c->chain_ready = false;
-    return GH_OK;
-}
-
-// ------------------------------------------------------------------ wavelet forward
-
-static void wavelet_plan(gh_ctx::Wavelet &w)
-{
-    for (int k = 0; k < 3; ++k) w.X[0][k] = w.shape[k];
-    for (int i = 1; i <= w.levels; ++i)
-        for (int k = 0; k < 3; ++k) w.X[i][k] = w.tax[k] ? (w.X[i - 1][k] + 1) / 2 : w.X[i - 1][k];
-    int a[3];
-    for (int k = 0; k < 3; ++k) a[k] = w.X[w.levels][k];
-    for (int i = w.levels; i >= 1; --i)
-        for (int k = 0; k < 3; ++k) {
-            w.offd[i][k] = a[k];
-            if (w.tax[k]) a[k] += w.X[i][k];
-        }
-    for (int k = 0; k < 3; ++k) w.D[k] = a[k];
-    w.Mp = (int64_t)a[0] * a[1] * a[2];
-}
-
-// Multi-level DWT of `batch` model-shaped vectors x (batch stride xb) into the packed
-// coefficient layout C (batch stride Mp, must be zero-initialised: odd lengths leave gaps).
-static int run_dwt(gh_ctx *c, const double *x, int64_t xb, int64_t batch, double *C, double *S1,
-                   double *S2)
-{
-    const gh_ctx::Wavelet &w = c->wv;
-    const int64_t Cs[3] = {(int64_t)w.D[1] * w.D[2], (int64_t)w.D[2], 1};
-    int axes[3], na = 0;
-    for (int k = 0; k < 3; ++k)
-        if (w.tax[k]) axes[na++] = k;
-    for (int lev = 1; lev <= w.levels; ++lev) {
-        const double *src = (lev == 1) ? x : C;
-        int64_t src_b = (lev == 1) ? xb : w.Mp;
-        int e[3] = {w.X[lev - 1][0], w.X[lev - 1][1], w.X[lev - 1][2]};
-        int64_t ss[3];
-        if (lev == 1) {
-            ss[0] = (int64_t)e[1] * e[2];
-            ss[1] = e[2];
-            ss[2] = 1;
-        } else {
-            ss[0] = Cs[0];
-            ss[1] = Cs[1];
-            ss[2] = Cs[2];
-        }
-        if (na == 1 && lev > 1) {
-            // single pass reading and writing C would overlap: stage the input block
-            const int64_t len = (int64_t)e[0] * e[1] * e[2];  // contiguous: only the last axis varies
-            for (int64_t b = 0; b < batch; ++b)
-                HIPCHK(c, hipMemcpyAsync(S1 + b * w.Mp, C + b * w.Mp, len * sizeof(double),
-                                         hipMemcpyDeviceToDevice, c->stream));
-            src = S1;
-            ss[0] = (int64_t)e[1] * e[2];
-            ss[1] = e[2];
-            ss[2] = 1;
-        }
-        for (int p = 0; p < na; ++p) {
-            const int ax = axes[p];
-            const bool last = (p == na - 1);
-            double *dst = last ? C : ((p & 1) ? S2 : S1);
-            if (!last && dst == src) dst = (dst == S1) ? S2 : S1;
-            DwtArgs a{};
-            a.in = src;
-            a.out = dst;
-            a.batch = batch;
-            a.in_bstride = src_b;
-            a.out_bstride = w.Mp;
-            a.axis = ax;
-            const int h = (e[ax] + 1) / 2;
-            int oe[3] = {e[0], e[1], e[2]};
-            oe[ax] = 2 * h;
-            for (int k = 0; k < 3; ++k) {
-                a.e[k] = e[k];
-                a.in_s[k] = ss[k];
-                a.in_off[k][0] = a.in_off[k][1] = 0;
-                a.in_split[k] = 0x7fffffff;
-            }
-            if (last) {
-                for (int k = 0; k < 3; ++k) {
-                    a.out_s[k] = Cs[k];
-                    a.out_off[k][0] = 0;
-                    if (w.tax[k]) {
-                        a.out_split[k] = w.X[lev][k];
-                        a.out_off[k][1] = w.offd[lev][k];
-                    } else {
-                        a.out_split[k] = 0x7fffffff;
-                        a.out_off[k][1] = 0;
-                    }
-                }
-            } else {
-                a.out_s[0] = (int64_t)oe[1] * oe[2];
-                a.out_s[1] = oe[2];
-                a.out_s[2] = 1;
-                for (int k = 0; k < 3; ++k) {
-                    a.out_off[k][0] = 0;
-                    a.out_off[k][1] = (k == ax) ? h : 0;
-                    a.out_split[k] = 0x7fffffff;
-                }
-            }
-            const int64_t total = (int64_t)oe[0] * oe[1] * oe[2] / 2 * batch;
-            const int64_t blocks = std::min<int64_t>((total + 255) / 256, 1 << 20);
-            dwt_axis_kernel<<<dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, c->stream>>>(a);
-            // the next pass reads what this one wrote: dense block of extents oe
-            src = dst;
-            src_b = w.Mp;
-            e[0] = oe[0];
-            e[1] = oe[1];
-            e[2] = oe[2];
-            ss[0] = a.out_s[0];
-            ss[1] = a.out_s[1];
-            ss[2] = a.out_s[2];
-        }
-    }
-    HIPCHK(c, hipGetLastError());
-    return GH_OK;
-}
-
-// d = Awcp @ W(x): compressor3D.py:47-68 / compressor1D.py:45-60
-static int wavelet_forward(gh_ctx *c, const double *x, double *d_out)
-{
-    gh_ctx::Wavelet &w = c->wv;
-    HIPCHK(c, hipMemsetAsync(w.coeff, 0, sizeof(double) * (size_t)w.Mp, c->stream));
-    TRY(run_dwt(c, x, c->M, 1, w.coeff, w.s1, w.s2));
-    spmv_kernel<<<dim3((unsigned)((c->ld + 3) / 4)), dim3(256), 0, c->stream>>>(
-        w.indptr, w.indices, w.data, w.coeff, c->N, c->ld, d_out);
-    HIPCHK(c, hipGetLastError());
-    return GH_OK;
-}
-
-// F = Awcp W as a dense N x M matrix: column j is the compressed forward of the unit model e_j
-// (exactly the operator the reference applies, thresholding included; only the association of the
-// sums differs from DWT-then-SpMV).  For problems small enough for the resident chain kernel, which
-// keeps it in LDS: 64 unit vectors per batch of DWT passes + one batched SpMV.
-static int wavelet_dense_form(gh_ctx *c)
-{
-    gh_ctx::Wavelet &w = c->wv;
-    if (w.F_valid) return GH_OK;
-    const int64_t M = c->M, Mp = w.Mp, B = 64;
-    TRY(dalloc(c, &w.F, (size_t)c->ld * (size_t)M));
-    double *X = nullptr, *C = nullptr, *S1 = nullptr, *S2 = nullptr;
-    HIPCHK(c, hipMalloc((void **)&X, sizeof(double) * (size_t)(B * M)));
-    HIPCHK(c, hipMalloc((void **)&C, sizeof(double) * (size_t)(B * Mp)));
-    HIPCHK(c, hipMalloc((void **)&S1, sizeof(double) * (size_t)(B * Mp)));
-    HIPCHK(c, hipMalloc((void **)&S2, sizeof(double) * (size_t)(B * Mp)));
-    int rc = GH_OK;
-    for (int64_t j0 = 0; j0 < M && rc == GH_OK; j0 += B) {
-        const int64_t nb = std::min(B, M - j0);
-        unit_rows_kernel<<<dim3((unsigned)std::min<int64_t>(1024, (nb * M + 255) / 256)), dim3(256), 0, c->stream>>>(
-            X, M, j0, nb);
-        hipMemsetAsync(C, 0, sizeof(double) * (size_t)(nb * Mp), c->stream);
-        rc = run_dwt(c, X, M, nb, C, S1, S2);
-        if (rc != GH_OK) break;
-        spmv_kernel<<<dim3((unsigned)((c->ld + 3) / 4), (unsigned)nb), dim3(256), 0, c->stream>>>(
-            w.indptr, w.indices, w.data, C, c->N, c->ld, w.F + j0 * c->ld, Mp, c->ld);
-    }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    hipFree(X);
-    hipFree(C);
-    hipFree(S1);
-    hipFree(S2);
-    if (rc != GH_OK) return rc;
-    if (e != hipSuccess) return fail(c, GH_ERR_HIP, "wavelet_dense_form: %s", hipGetErrorString(e));
-    w.F_valid = true;
-    return GH_OK;
-}
-
-// slab -> d ; regulariser ; residual + scalars.  x: position the forward belongs to.
-// slab (c->grid rows) -> d_out (+ per-block partial sums of d + grav_fix).  Many slab rows
-// (small problems spread over many workgroups) are summed in two passes so that no thread walks
-// hundreds of rows serially.
-static void reduce_slab(gh_ctx *c, const double *gfix, double *d_out)
-{
-    const int rows = c->grid;
-    if (rows > 64 && c->slab2) {
-        const int nseg = c->slab2_rows;
-        reduce_slab_kernel<<<dim3(c->n_dpart, nseg), dim3(32, 8), 0, c->stream>>>(c->slab, rows, c->ld, c->N,
-                                                                                  nullptr, c->slab2, c->dpart);
-        reduce_slab_kernel<<<dim3(c->n_dpart, 1), dim3(32, 8), 0, c->stream>>>(c->slab2, nseg, c->ld, c->N,
-                                                                               gfix, d_out, c->dpart);
-    } else {
-        reduce_slab_kernel<<<dim3(c->n_dpart, 1), dim3(32, 8), 0, c->stream>>>(c->slab, rows, c->ld, c->N, gfix,
-                                                                               d_out, c->dpart);
-    }
-}
-
-static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
-{
-    double *d_out = o.d, *r_out = o.r, *greg_out = o.greg, *scal_out = o.scal;
-    RegArgs ra{};
-    ra.ms_grad_den_mw = 0;
-    ra.kind = c->reg_kind;
-    ra.M = c->M;
-    ra.nz = c->shape[0];
-    ra.ny = c->shape[1];
-    ra.nx = c->shape[2];
-    ra.alpha = c->alpha;
-    ra.beta = c->beta;
-    ra.x = x;
-    ra.mwapr = c->mwapr;
-    ra.wm2 = c->wm2;
-    ra.greg = greg_out;
-    ra.regpart = c->regpart;
-    const double *gfix = c->have_fix ? c->gfix : nullptr;
-    const double *regpart = c->regpart;
-    int n_regpart = c->n_regpart;
-    const double *src;
-    int nseg;
-    if (c->sh.kind != 0) {
-        // sharded cells: local forward partial and local regulariser sum travel in ONE
-        // all-reduce, then every rank finishes the (replicated) data part identically
-        double *buf = c->sh.buf;
-        reduce_slab(c, nullptr, buf);
-        if (c->sh.halo) {
-            // stencil regulariser: the boundary planes of x travel with the forward partial, the
-            // regulariser (which needs them) is summed by a second, two-double all-reduce
-            gh_ctx::Shard &sh = c->sh;
-            const int64_t P = sh.P, nh = 2 * (int64_t)sh.world * P;
-            double *hb = buf + c->ld + 8;
-            halo_pack_kernel<<<dim3((unsigned)std::min<int64_t>(1024, (nh + 255) / 256)), dim3(256), 0, c->stream>>>(
-                x, c->M, P, sh.rank, sh.world, hb);
-            TRY(comm_allreduce(c, buf, (int64_t)c->ld + 8 + nh));
-            ra.nz = c->shape[0];
-            ra.k0 = sh.m0 / P;
-            ra.xlo = sh.rank > 0 ? hb + ((int64_t)(sh.rank - 1) * 2 + 1) * P : nullptr;
-            ra.xhi = sh.rank + 1 < sh.world ? hb + (int64_t)(sh.rank + 1) * 2 * P : nullptr;
-            ra.alo = sh.alo;
-            ra.ahi = sh.ahi;
-            reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
-            sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, sh.rb);
-            TRY(comm_allreduce(c, sh.rb, 2));
-            regpart = sh.rb;
-        } else {
-            reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
-            sum_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(c->regpart, c->n_regpart, buf + c->ld);
-            TRY(comm_allreduce(c, buf, c->ld + 2));
-            regpart = buf + c->ld;
-        }
-        src = buf;
-        nseg = 1;
-        n_regpart = 1;
-    } else if (c->wv.on) {
-        // forward through the compressed operator: d_out is already complete
-        TRY(wavelet_forward(c, x, d_out));
-        reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
-        src = d_out;
-        nseg = 1;
-    } else if (c->grid > 64 && c->slab2) {
-        // many slab rows: first stage of the reduction and the regulariser share one launch,
-        // finish_kernel sums the 16 segments
-        nseg = c->slab2_rows;
-        reduce_reg_kernel<<<dim3((unsigned)(c->n_dpart * nseg + c->n_regpart)), dim3(256), 0, c->stream>>>(
-            c->slab, c->grid, c->ld, nseg, c->n_dpart, c->slab2, ra);
-        src = c->slab2;
-    } else {
-        reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
-        src = c->slab;
-        nseg = c->grid;
-    }
-    FinishArgs fa;
-    fa.N = c->N;
-    fa.ld = c->ld;
-    fa.nseg = nseg;
-    fa.n_regpart = n_regpart;
-    fa.src = src;
-    fa.gfix = gfix;
-    fa.dobs_c = c->dobs_c;
-    fa.regpart = regpart;
-    fa.alpha = c->alpha;
-    fa.d = d_out;
-    fa.r = r_out;
-    fa.scal = scal_out;
-    finish_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(fa);
-    HIPCHK(c, hipGetLastError());
-    return GH_OK;
-}
-
-// forward sweep of x (device) + finalize
-static int eval_forward(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
-{
-    if (!c->wv.on) {
-        SweepArgs a{};
-        a.mode = SW_FWD;
-        a.x_in = x;
-        a.slab = c->slab;
-        TRY(launch_sweep(c, a));
-    }
-    return finalize(c, x, o);
-}
-
-static int ensure_work(gh_ctx *c)
-{
-    const size_t M = (size_t)c->M, ld = (size_t)c->ld;
-    TRY(dalloc(c, &c->scal_all, 16));
-    for (int i = 0; i < 4; ++i) {
-        TRY(dalloc(c, &c->st[i].r, ld));
-        TRY(dalloc(c, &c->st[i].greg, M));
-        TRY(dalloc(c, &c->st[i].d, ld));
-        c->st[i].scal = c->scal_all + 4 * i;
-        TRY(dalloc(c, &c->xb[i], M));
-    }
-    TRY(dalloc(c, &c->pb[0], M));
-    TRY(dalloc(c, &c->pb[1], M));
-    TRY(dalloc(c, &c->pn, M));
-    if (c->n_panels > 1) TRY(dalloc(c, &c->gbuf, M));
-    TRY(dalloc(c, &c->slab, (size_t)c->grid * ld));
-    if (c->grid > 64) {
-        c->slab2_rows = 16;
-        TRY(dalloc(c, &c->slab2, (size_t)c->slab2_rows * ld));
-    }
-    c->n_dpart = (int)((c->ld + 31) / 32);
-    c->n_regpart = (int)((c->M + 255) / 256);
-    c->n_pp0 = (int)std::min<int64_t>(1024, (c->M + 255) / 256);
-    TRY(dalloc(c, &c->dpart, (size_t)c->n_dpart));
-    TRY(dalloc(c, &c->regpart, (size_t)c->n_regpart));
-    TRY(dalloc(c, &c->pp_part, (size_t)c->n_teams));
-    TRY(dalloc(c, &c->ppn_part, (size_t)c->n_teams));
-    TRY(dalloc(c, &c->pp0_part, (size_t)c->n_pp0));
-    TRY(dalloc(c, &c->tmpM, M));
-    TRY(dalloc(c, &c->tmpN, ld));
-    TRY(dalloc(c, &c->low, M));
-    TRY(dalloc(c, &c->high, M));
-    if (!c->mwapr) {
-        TRY(dalloc(c, &c->mwapr, M));
-    }
-    if (!c->wm2) {
-        TRY(dalloc(c, &c->wm2, M));
-    }
-    if (!c->h_scal) {
-        c->h_scal_n = 16 + 2 * (size_t)c->n_teams + (size_t)c->n_pp0;
-        HIPCHK(c, hipHostMalloc((void **)&c->h_scal, c->h_scal_n * sizeof(double)));
-    }
-    return GH_OK;
-}
-
-static int need(gh_ctx *c, bool cond, const char *what)
-{
-    if (!cond) return fail(c, GH_ERR_ARG, "%s", what);
-    return GH_OK;
-}
+#include "host_ctx.h"
+#include "host_sweep.h"
+#include "host_comm.h"
+#include "host_wavelet.h"
+#include "host_eval.h"
+#include "host_resident.h"
+#include "host_batch.h"
 
 // ------------------------------------------------------------------------- C-ABI
 
@@ -1736,284 +855,6 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     return GH_OK;
 }
 
-typedef void (*resident_fn)(ResArgs);
-enum { GH_RESIDENT_ABORTED = 1000 };  // internal: chain_run_resident gave up, state untouched
-
-// rc: double2 chunks per lane and column; cw: columns a wave keeps in registers (0: none, dots
-// read LDS).  Only register copies of at most 20 double2 (80 VGPRs: no spills) are compiled.
-extern "C++" {
-template <int RC>
-static resident_fn resident_for_rc(int cw)
-{
-    switch (cw) {
-    case 1: return resident_chain_kernel<RC, 1>;
-    case 2: if constexpr (RC * 2 <= 20) return resident_chain_kernel<RC, 2>; break;
-    case 3: if constexpr (RC * 3 <= 20) return resident_chain_kernel<RC, 3>; break;
-    case 4: if constexpr (RC * 4 <= 20) return resident_chain_kernel<RC, 4>; break;
-    }
-    return resident_chain_kernel<RC, 0>;
-}
-}  // extern "C++"
-
-static resident_fn resident_for(int rc, int cw)
-{
-    switch (rc) {
-    case 1: return resident_for_rc<1>(cw);
-    case 2: return resident_for_rc<2>(cw);
-    case 3: return resident_for_rc<3>(cw);
-    case 4: return resident_for_rc<4>(cw);
-    case 5: return resident_for_rc<5>(cw);
-    case 6: return resident_for_rc<6>(cw);
-    case 7: return resident_for_rc<7>(cw);
-    case 8: return resident_for_rc<8>(cw);
-    }
-    return nullptr;
-}
-
-// Can this problem run on the resident chain kernel?  Dense stored G on one device, N <= 1024,
-// and one column block per CU that fits the CU's LDS next to the kernel's scratch.
-static bool resident_plan(gh_ctx *c)
-{
-    gh_ctx::Resident &r = c->rs;
-    if (r.state != 0) return r.state > 0;
-    r.state = -1;
-    if (env_int("GRAVHMC_RESIDENT", 1) == 0) return false;
-    if (c->mf || c->sh.kind != 0 || c->n_panels != 1 || c->ld > 1024 || !c->G) return false;
-    int lds_max = 0;
-    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess)
-        return false;
-    const int cpw = (int)((c->M + c->cus - 1) / c->cus);
-    const size_t lds = resident_lds_doubles(c->ld, cpw, 1) * sizeof(double);
-    if (lds > (size_t)lds_max || cpw > RES_THREADS) return false;
-    r.lds_max = lds_max;
-    r.cpw = cpw;
-    r.nwg = (int)((c->M + cpw - 1) / cpw);
-    if (r.nwg > RES_MAX_WG) return false;
-    r.rc = (int)((c->ld / 2 + 63) / 64);
-    // columns per wave for the register copy of the dots pass (0: the wave has more than 4)
-    r.ct = (env_int("GRAVHMC_RESIDENT_REGS", 1) && cpw <= 4 * RES_WAVES) ? (cpw + RES_WAVES - 1) / RES_WAVES : 0;
-    if (r.ct * ((int)((c->ld / 2 + 63) / 64)) > 20) r.ct = 0;  // (what resident_for compiles)
-    // wavelet-compressed forward: LDS holds its dense model-space form, the dots need their own
-    // (register) copy of Aw
-    if (c->wv.on && (r.ct == 0 || wavelet_dense_form(c) != GH_OK)) return false;
-    r.lds = lds;
-    resident_fn f = resident_for(r.rc, r.ct);
-    if (!f) return false;
-    if (allow_dynamic_lds(reinterpret_cast<const void *>(f), lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), RES_THREADS,
-                                                     lds) != hipSuccess || per_cu < 1 ||
-        (int64_t)per_cu * c->cus < r.nwg) {
-        (void)hipGetLastError();
-        return false;
-    }
-    r.state = 1;
-    return true;
-}
-
-// One launch of the resident chain kernel: K trajectories of C chains (chain_of[k], nullptr: all
-// chain 0) whose current models are the rows of x_dev.  GH_RESIDENT_ABORTED: the kernel gave up
-// waiting for its workgroups, nothing was changed.
-struct ResLaunch {
-    int C = 1, K = 0;
-    const int *chain_of = nullptr, *L = nullptr;
-    const double *p0s = nullptr, *us = nullptr;
-    double dt = 0.0;
-    int64_t stop_at_accepts = 0, accept_count0 = 0;
-    double *x_dev = nullptr, *gcur_dev = nullptr, *ucur_dev = nullptr;
-    int have_state = 0;
-    bool want_x = false;
-};
-
-static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double *out5s, int h_run[4])
-{
-    gh_ctx::Resident &r = c->rs;
-    const size_t M = (size_t)c->M;
-    const int K = q.K;
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t lds = resident_lds_doubles(c->ld, r.cpw, q.C) * sizeof(double);
-    if (q.C < 1 || q.C > RES_MAX_CHAINS || lds > (size_t)r.lds_max)
-        return fail(c, GH_ERR_ARG, "resident chain kernel: %d chains do not fit the LDS", q.C);
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(resident_for(r.rc, r.ct)), lds));
-    if (!r.slabg) {
-        // (+8 rows / entries: the abort test announces one phantom workgroup per cluster)
-        TRY(dalloc(c, &r.slabg, (size_t)(r.nwg + 8) * (size_t)c->ld * 2));
-        TRY(dalloc(c, &r.xslabg, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
-        TRY(dalloc(c, &r.dclg, (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
-        TRY(dalloc(c, &r.scalg, (size_t)r.nwg * 8));
-        TRY(dalloc(c, &r.xccg, (size_t)r.nwg + 8));
-        TRY(dalloc(c, &r.xpub, 2 * M));
-        TRY(dalloc(c, &r.abort_w, 4));
-        TRY(dalloc(c, &r.n_run, 4));
-        if (env_int("GRAVHMC_RESIDENT_TIMING", 0)) TRY(dalloc(c, &r.dbg, 32));
-        HIPCHK(c, hipEventCreate(&r.ev0));
-        HIPCHK(c, hipEventCreate(&r.ev1));
-    }
-    if (K > r.Kcap) {
-        // grown rarely (the host batches a fixed number of trajectories per call); the old blocks
-        // stay in the context's allocation list until gh_destroy
-        const int cap = std::max(K, 32);
-        r.L = r.accepted = r.chain = nullptr;
-        r.p0s = r.us = r.out5s = r.xacc = nullptr;
-        TRY(dalloc(c, &r.L, (size_t)cap));
-        TRY(dalloc(c, &r.chain, (size_t)cap));
-        TRY(dalloc(c, &r.accepted, (size_t)cap));
-        TRY(dalloc(c, &r.p0s, (size_t)cap * M, false));
-        TRY(dalloc(c, &r.us, (size_t)cap));
-        TRY(dalloc(c, &r.out5s, (size_t)cap * 5));
-        TRY(dalloc(c, &r.xacc, (size_t)cap * M, false));
-        r.Kcap = cap;
-    }
-    int64_t steps = 0;
-    for (int k = 0; k < K; ++k) steps += q.L[k];
-    if ((uint64_t)r.tag + (uint64_t)steps + (uint64_t)q.C + 2 > 0xf0000000ull ||
-        (uint64_t)r.tagE + (uint64_t)K + (uint64_t)q.C + 2 > 0xf0000000ull) {
-        // 32-bit tags about to wrap: start the count again on zeroed granules
-        HIPCHK(c, hipMemsetAsync(r.slabg, 0, (size_t)r.nwg * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.xslabg, 0, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.dclg, 0, (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.scalg, 0, (size_t)r.nwg * 8 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.xccg, 0, (size_t)r.nwg * sizeof(ghk::u64), c->stream));
-        r.tag = r.tagE = 0;
-    }
-    HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.p0s, q.p0s, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.us, q.us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.L, q.L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    if (q.chain_of)
-        HIPCHK(c, hipMemcpyAsync(r.chain, q.chain_of, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    ResArgs a{};
-    a.G = c->G;
-    a.Gl = c->wv.on ? c->wv.F : c->G;
-    a.ld = c->ld;
-    a.N = c->N;
-    a.M = c->M;
-    a.cols_per_wg = r.cpw;
-    a.nwg = r.nwg;
-    // test hook: the workgroups wait for partners that do not exist, time out and abort
-    if (env_int("GRAVHMC_RESIDENT_TEST_ABORT", 0)) a.nwg += 8;
-    a.try_local = env_int("GRAVHMC_RESIDENT_LOCAL", 1);
-    a.gfix = c->have_fix ? c->gfix : nullptr;
-    a.dobs_c = c->dobs_c;
-    a.low = c->low;
-    a.high = c->high;
-    a.kind = c->reg_kind;
-    a.nz = c->shape[0];
-    a.ny = c->shape[1];
-    a.nx = c->shape[2];
-    a.alpha = c->alpha;
-    a.beta = c->beta;
-    a.mwapr = c->mwapr;
-    a.wm2 = c->wm2;
-    a.C = q.C;
-    a.chain = q.chain_of ? r.chain : nullptr;
-    a.x_cur = q.x_dev;
-    a.gcur_io = q.gcur_dev;
-    a.ucur_io = q.ucur_dev;
-    a.have_state = q.have_state;
-    a.K = K;
-    a.L = r.L;
-    a.p0s = r.p0s;
-    a.us = r.us;
-    a.dt = q.dt;
-    a.stop_at_accepts = q.stop_at_accepts;
-    a.accept_count0 = q.accept_count0;
-    a.accepted = r.accepted;
-    a.out5s = r.out5s;
-    a.xacc = q.want_x ? r.xacc : nullptr;
-    a.n_run = r.n_run;
-    a.slabg = r.slabg;
-    a.xslabg = r.xslabg;
-    a.dclg = r.dclg;
-    a.scalg = r.scalg;
-    a.xccg = r.xccg;
-    a.xpub = r.xpub;
-    a.tag0 = r.tag;
-    a.tagE0 = r.tagE;
-    a.abort_w = r.abort_w;
-    a.dbg = r.dbg;
-    if (c->prof) HIPCHK(c, hipEventRecord(r.ev0, c->stream));
-    // A plain launch: the grid was checked against the occupancy query in resident_plan (one
-    // workgroup per CU by its LDS request), which is all hipLaunchCooperativeKernel would add;
-    // residency itself is the same for both, and every wait inside the kernel is bounded.
-    hipLaunchKernelGGL(resident_for(r.rc, r.ct), dim3(r.nwg), dim3(RES_THREADS), lds, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    if (c->prof) HIPCHK(c, hipEventRecord(r.ev1, c->stream));
-    unsigned h_sync[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(h_sync, r.abort_w, sizeof h_sync, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_run, r.n_run, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(accepted, r.accepted, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out5s, r.out5s, (size_t)K * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (h_sync[0] != 0u) {
-        // A workgroup waited 2 s for the others: they were not all resident (another process holding
-        // compute units of this device).  Nothing of the chain state was written; this context goes
-        // back to the sweep-per-launch path for good and the caller's batch is run there.
-        r.state = -1;
-        fprintf(stderr, "libgravhmc: resident chain kernel timed out waiting for its workgroups; "
-                        "continuing on the sweep-per-launch path\n");
-        return GH_RESIDENT_ABORTED;
-    }
-    r.tag += (unsigned)h_run[1];
-    r.tagE += (unsigned)h_run[2];
-    r.launches += 1;
-    r.evals += h_run[1];
-    if (c->prof) {
-        float t = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&t, r.ev0, r.ev1));
-        c->prof_ms_acc += t;
-        c->prof_res_evals += h_run[1];
-    }
-    return GH_OK;
-}
-
-// K trajectories of the context's chain in one launch (same contract as gh_chain_run)
-static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
-                              int64_t stop_at_accepts, int64_t record_from, int *accepted, double *out5s,
-                              double *x_out, int *n_run)
-{
-    gh_ctx::Resident &r = c->rs;
-    const size_t M = (size_t)c->M;
-    ResLaunch q;
-    q.K = K;
-    q.L = L;
-    q.p0s = p0s;
-    q.us = us;
-    q.dt = dt;
-    q.stop_at_accepts = stop_at_accepts;
-    q.accept_count0 = c->accept_count;
-    q.x_dev = c->xb[c->xcur];
-    q.want_x = x_out != nullptr || c->ring != nullptr;
-    int h_run[4] = {0, 0, 0, 0};
-    TRY(resident_launch(c, q, accepted, out5s, h_run));
-    *n_run = h_run[0];
-    for (int k = 0; k < h_run[0]; ++k) {
-        if (!accepted[k]) continue;
-        c->accept_count += 1;
-        if (c->ring && c->accept_count > record_from) {
-            ring_store_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
-                r.xacc + (size_t)k * M, c->weighted ? c->wm : nullptr, c->M,
-                c->ring + (size_t)c->ring_next * M);
-            c->ring_next = (c->ring_next + 1) % c->ring_K;
-            c->ring_count += 1;
-        }
-        if (x_out)
-            HIPCHK(c, hipMemcpyAsync(x_out + (size_t)k * M, r.xacc + (size_t)k * M, M * sizeof(double),
-                                     hipMemcpyDeviceToHost, c->stream));
-    }
-    // bring the per-launch state (d, r, scalars of the current sample) back in step with x
-    c->spec_valid = c->pn_valid = false;
-    TRY(eval_forward(c, c->xb[c->xcur], c->st[c->cur]));
-    TRY(d2h(c, c->h_scal, c->st[c->cur].scal, 4));
-    c->U_cur[0] = c->h_scal[2];
-    c->U_cur[1] = c->h_scal[0];
-    c->U_cur[2] = c->h_scal[1];
-    return GH_OK;
-}
-
 int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
                  const double *p0_lookahead, int64_t stop_at_accepts, int64_t record_from, int *accepted,
                  double *out5s, double *x_out, int *n_run)
@@ -2131,166 +972,6 @@ int gh_posterior_read(gh_ctx *c, int64_t *n_in_window, int64_t *n_total, double 
     HIPCHK(c, hipGetLastError());
     if (mean) TRY(d2h(c, mean, c->ring_mean, (size_t)c->M));
     if (sd) TRY(d2h(c, sd, c->ring_sd, (size_t)c->M));
-    return GH_OK;
-}
-
-// --------------------------------------------------------------- batched chains (MFMA)
-
-static int batch_alloc(gh_ctx *c)
-{
-    gh_ctx::Batch &b = c->bt;
-    const size_t M16 = (size_t)c->M * CB, L16 = (size_t)c->ld * CB;
-    if (b.Xc) return GH_OK;
-    TRY(dalloc(c, &b.Xc, M16));
-    TRY(dalloc(c, &b.Rtc, L16));
-    TRY(dalloc(c, &b.GREGc, M16));
-    TRY(dalloc(c, &b.Dc, L16));
-    for (int i = 0; i < 2; ++i) {
-        TRY(dalloc(c, &b.Xw[i], M16));
-        TRY(dalloc(c, &b.Pw[i], M16));
-    }
-    TRY(dalloc(c, &b.Rtw, L16));
-    TRY(dalloc(c, &b.GREGw, M16));
-    TRY(dalloc(c, &b.Dw, L16));
-    TRY(dalloc(c, &b.scal, CB * 4));
-    TRY(dalloc(c, &b.stage, M16));
-    // forward: 512-row blocks x column blocks, about 4 workgroups per CU in total
-    const int rowblocks = (int)((c->ld + 511) / 512);
-    int colblocks = std::max(1, (c->cus * 4 + rowblocks - 1) / rowblocks);
-    int64_t cpb = (c->M + colblocks - 1) / colblocks;
-    cpb = (cpb + 15) / 16 * 16;
-    b.cols_per_block = cpb;
-    b.n_colblocks = (int)((c->M + cpb - 1) / cpb);
-    TRY(dalloc(c, &b.slab, (size_t)b.n_colblocks * L16));
-    b.n_regblocks = (int)((c->M + 15) / 16);
-    TRY(dalloc(c, &b.regpart, (size_t)b.n_regblocks * CB));
-    const int64_t ntiles = (c->M + 15) / 16;
-    const int64_t npairs = (ntiles + 1) / 2;  // a wave owns two adjacent column tiles
-    const int wgs = (int)std::min<int64_t>((npairs + 3) / 4, (int64_t)c->cus * 4);
-    b.n_waves = wgs * 4;
-    TRY(dalloc(c, &b.pp_part, (size_t)b.n_waves * CB));
-    b.n_pp0 = (int)std::min<int64_t>(512, (c->M + 15) / 16);
-    TRY(dalloc(c, &b.pp0_part, (size_t)b.n_pp0 * CB));
-    HIPCHK(c, hipHostMalloc((void **)&b.h, sizeof(double) * (size_t)(CB * 4 + (b.n_waves + b.n_pp0) * CB)));
-    // the adjoint GEMM wants G in MFMA operand order; 288 GB of HBM usually has room for the
-    // second copy (C2: 40 GB + 40 GB).  Without it the kernel reads the column-major matrix.
-    if (env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
-        size_t free_b = 0, total_b = 0;
-        const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)2 << 30)) {
-            void *ptr = nullptr;
-            if (hipMalloc(&ptr, need_b) == hipSuccess) {
-                c->allocs.push_back(ptr);
-                b.Gb = static_cast<double *>(ptr);
-                batch_relayout_kernel<<<dim3(1 << 16), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, (int)(c->ld / 16),
-                                                                                  ntiles, b.Gb);
-                HIPCHK(c, hipGetLastError());
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-    }
-    TRY(dalloc(c, &c->tmpM, (size_t)c->M));
-    TRY(dalloc(c, &c->low, (size_t)c->M));
-    TRY(dalloc(c, &c->high, (size_t)c->M));
-    if (!c->mwapr) TRY(dalloc(c, &c->mwapr, (size_t)c->M));
-    if (!c->wm2) TRY(dalloc(c, &c->wm2, (size_t)c->M));
-    return GH_OK;
-}
-
-static int batch_time_begin(gh_ctx *c, bool &timed)
-{
-    timed = c->prof && c->ev_used + 2 <= c->ev.size();
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-    return GH_OK;
-}
-
-static int batch_time_end(gh_ctx *c, bool timed)
-{
-    if (timed) {
-        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_used += 2;
-    }
-    c->bt.sweeps += 1;
-    return GH_OK;
-}
-
-// forward of all chains at X, then regulariser and residuals into (D, GREG, Rt, scal)
-static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, double *Rt)
-{
-    gh_ctx::Batch &b = c->bt;
-    BatchFwdArgs f;
-    f.G = c->G;
-    f.ld = c->ld;
-    f.M = c->M;
-    f.N = c->N;
-    f.X = X;
-    f.cols_per_block = b.cols_per_block;
-    f.slab = b.slab;
-    bool timed;
-    TRY(batch_time_begin(c, timed));
-    batch_forward_kernel<<<dim3((unsigned)((c->ld + 511) / 512), (unsigned)b.n_colblocks), dim3(256), 0,
-                           c->stream>>>(f);
-    TRY(batch_time_end(c, timed));
-    const int64_t n16 = c->ld * CB;
-    batch_reduce_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.slab, b.n_colblocks,
-                                                                                        n16, D);
-    BatchRegArgs ra;
-    ra.kind = c->reg_kind;
-    ra.M = c->M;
-    ra.nz = c->shape[0];
-    ra.ny = c->shape[1];
-    ra.nx = c->shape[2];
-    ra.alpha = c->alpha;
-    ra.beta = c->beta;
-    ra.X = X;
-    ra.mwapr = c->mwapr;
-    ra.wm2 = c->wm2;
-    ra.GREG = GREG;
-    ra.regpart = b.regpart;
-    batch_reg_kernel<<<dim3((unsigned)b.n_regblocks), dim3(256), 0, c->stream>>>(ra);
-    BatchFinishArgs fa;
-    fa.N = c->N;
-    fa.ld = c->ld;
-    fa.n_regpart = b.n_regblocks;
-    fa.D = D;
-    fa.gfix = c->have_fix ? c->gfix : nullptr;
-    fa.dobs_c = c->dobs_c;
-    fa.regpart = b.regpart;
-    fa.alpha = c->alpha;
-    fa.Rt = Rt;
-    fa.scal = b.scal;
-    batch_finish_kernel<<<dim3(CB), dim3(1024), 0, c->stream>>>(fa);
-    HIPCHK(c, hipGetLastError());
-    return GH_OK;
-}
-
-static int batch_upload_rows(gh_ctx *c, const double *rows, int C, double *dst)
-{
-    gh_ctx::Batch &b = c->bt;
-    HIPCHK(c, hipMemcpyAsync(b.stage, rows, sizeof(double) * (size_t)C * (size_t)c->M, hipMemcpyHostToDevice,
-                             c->stream));
-    const int64_t n16 = c->M * CB;
-    batch_interleave_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.stage, C, c->M, dst);
-    HIPCHK(c, hipGetLastError());
-    return GH_OK;
-}
-
-// state of the MFMA batch (chain-interleaved layouts) at the models x0s (C rows of M)
-static int batch_init_mfma(gh_ctx *c, int C, const double *x0s)
-{
-    TRY(batch_alloc(c));
-    gh_ctx::Batch &b = c->bt;
-    b.C = C;
-    TRY(batch_upload_rows(c, x0s, C, b.Xc));
-    TRY(batch_evaluate(c, b.Xc, b.Dc, b.GREGc, b.Rtc));
-    TRY(d2h(c, b.h, b.scal, CB * 4));
-    for (int k = 0; k < CB; ++k) {
-        b.U[k][0] = b.h[4 * k + 2];
-        b.U[k][1] = b.h[4 * k + 0];
-        b.U[k][2] = b.h[4 * k + 1];
-    }
-    b.ready = true;
     return GH_OK;
 }
 

@@ -1,0 +1,223 @@
+// libgravhmc host side: the context (one GPU + one stream + one inversion problem resident in
+// HBM) and the small helpers every other part uses.  Included once by gravhmc.hip.
+#pragma once
+
+static thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct gh_ctx {
+    int device = 0;
+    int64_t N = 0, M = 0, ld = 0;
+    int cus = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+
+    // geometry / kernel
+    double *obs[3] = {nullptr, nullptr, nullptr};
+    double *bounds = nullptr;
+    int cell_kind = -1;
+    double ratio = 1.6;
+    bool have_obs = false, have_cells = false, have_G = false, weighted = false;
+    double *G = nullptr;
+    int64_t warn_cells = 0, leaves = 0;
+    bool mf = false;          // matrix-free: entries are re-evaluated, G is never stored
+    bool dense_ok = true;     // N fits the register-resident sweep (<= 16384 rows)
+    double *tconv = nullptr;  // tesseroid obs converted to (lon rad, sin lat, cos lat, radius)
+    int64_t mf_cells_per_chunk = 0;
+
+    // sweep configuration
+    int TW = 0, EPT2 = 0, PF = 1;
+    int n_panels = 1;        // row panels of the dense sweep (N > 16384 rows: > 1, two reads of G per step)
+    int64_t panel_rows = 0;
+    double *gbuf = nullptr;   // gradient accumulated over the panels
+    bool NT = false;
+    int n_teams = 0, grid = 0;
+    int n_teams_sweep = 0;   // teams of the sweep launch (n_teams may be larger: size of the pp partials)
+    int64_t cols_per_team = 0;
+    size_t lds_bytes = 0;
+
+    // problem vectors
+    double *dobs_c = nullptr, *gfix = nullptr, *mwapr = nullptr, *wm = nullptr, *wm2 = nullptr;
+    double *low = nullptr, *high = nullptr;
+    bool have_data = false, have_fix = false, have_reg = false;
+    int reg_kind = 0, shape[3] = {1, 1, 1};
+    double alpha = 1.0, beta = 0.01;
+
+    // chain state: three (r, greg, d, scal) sets and three x buffers rotate between "current
+    // sample", "proposal" and "speculative first step of the next trajectory"; set/buffer 3 is
+    // private to gh_misfit_and_grad.  Swapping indices makes accept/reject free.
+    struct StateSet {
+        double *r = nullptr, *greg = nullptr, *d = nullptr, *scal = nullptr;
+    } st[4];
+    double *xb[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *pb[2] = {nullptr, nullptr};
+    double *pn = nullptr;  // momentum of the NEXT trajectory (gh_chain_prefetch_momentum)
+    int cur = 0, xcur = 0;
+    bool pn_valid = false, spec_valid = false;
+    double pn_probe[3] = {0, 0, 0}, spec_probe[3] = {0, 0, 0};
+    double spec_dt = 0.0, spec_pp0 = 0.0, pn_pp0 = 0.0, spec_U[3] = {0, 0, 0};
+    int spec_set = 0, spec_x = 0, spec_p = 0;
+    int64_t spec_hits = 0, spec_misses = 0, accept_count = 0;
+    double *slab2 = nullptr;
+    int slab2_rows = 0;
+    double *slab = nullptr, *dpart = nullptr, *regpart = nullptr, *pp_part = nullptr,
+           *ppn_part = nullptr, *pp0_part = nullptr, *scal_all = nullptr;
+    double *tmpM = nullptr, *tmpN = nullptr;
+    int n_dpart = 0, n_regpart = 0, n_pp0 = 0;
+    double *h_scal = nullptr;  // pinned: scalars + partial sums
+    size_t h_scal_n = 0;
+    bool chain_ready = false;
+    double U_cur[3] = {0, 0, 0};
+
+    // column-block sharding of ONE chain over several GPUs: this context holds
+    // the cells [m0, m0 + M) of M_global; N-vectors are replicated, the forward partials are
+    // summed across ranks once per potential evaluation.
+    struct Shard {
+        int kind = 0;  // 0 single GPU, 1 RCCL all-reduce on the stream, 2 host callback
+        int rank = 0, world = 1;
+        int64_t M_global = 0, m0 = 0;
+        ncclComm_t comm = nullptr;
+        gh_allreduce_fn cb = nullptr;
+        void *user = nullptr;
+        double *buf = nullptr;    // device: [d partial (ld) | R partial | pad | boundary planes (halo)]
+        double *hbuf = nullptr;   // pinned staging for the callback path
+        size_t buf_n = 0;         // doubles in buf / hbuf
+        // Smoothness / TV on cells sharded in whole z-planes: the ranks exchange their boundary
+        // planes of the model once per evaluation (inside the forward partial's all-reduce)
+        bool halo = false;
+        int64_t P = 0;            // cells per plane (ny * nx)
+        double *alo = nullptr, *ahi = nullptr;  // prior model of the planes below / above
+        double *rb = nullptr;     // regulariser partial for its own (2-double) all-reduce
+        int64_t collectives = 0;
+    } sh;
+
+    // wavelet-compressed forward operator (compressor1D/3D): CSR N x Mp on the device
+    struct Wavelet {
+        bool on = false;
+        int dims = 0, levels = 2;
+        int shape[3] = {1, 1, 1};
+        int X[5][3];      // X[i]: extents of the blocks level i produces (X[0] = model shape)
+        int offd[5][3];   // packed offset of level i's detail pieces (pywt.coeffs_to_array)
+        int D[3] = {1, 1, 1};
+        bool tax[3] = {false, false, true};  // transformed axes
+        int64_t Mp = 0, nnz = 0;
+        double thr = 1e-3;
+        int64_t *indptr = nullptr;
+        int *indices = nullptr;
+        double *data = nullptr;
+        double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
+        double *F = nullptr;  // dense model-space form Awcp W (ld x M, column-major), built on demand
+        bool F_valid = false;
+    } wv;
+
+    // several chains sharing every sweep of G (fp64 MFMA path, batch.hip.h)
+    struct Batch {
+        int C = 0;
+        double *Xc = nullptr, *Rtc = nullptr, *GREGc = nullptr, *Dc = nullptr;   // current states
+        double *Xw[2] = {nullptr, nullptr}, *Pw[2] = {nullptr, nullptr};
+        double *Rtw = nullptr, *GREGw = nullptr, *Dw = nullptr, *scal = nullptr;
+        double *slab = nullptr, *regpart = nullptr, *pp_part = nullptr, *pp0_part = nullptr;
+        double *stage = nullptr;  // C x M rows as the host passes them
+        double *Gb = nullptr;     // second copy of G in MFMA operand order (adjoint), if HBM allows
+        double *h = nullptr;      // pinned
+        int n_colblocks = 0, n_regblocks = 0, n_waves = 0, n_pp0 = 0;
+        int64_t cols_per_block = 0;
+        double U[CB][3];
+        bool ready = false;
+        int64_t sweeps = 0;
+    } bt;
+
+    // resident chain kernel (resident.hip.h): G held in LDS across a whole batch of trajectories
+    struct Resident {
+        int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
+        int cpw = 0, nwg = 0, rc = 0, ct = 0;  // ct: columns per wave kept in registers
+        size_t lds = 0;
+        ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xccg = nullptr;
+        double *xpub = nullptr;
+        unsigned *abort_w = nullptr;
+        unsigned tag = 0, tagE = 0;  // granule tags used so far (the buffers keep them across launches)
+        int Kcap = 0;
+        int *L = nullptr, *accepted = nullptr, *n_run = nullptr, *chain = nullptr;
+        int lds_max = 0;
+        // several chains sharing the resident G (gh_batch_* on small problems)
+        double *bx = nullptr, *bg = nullptr, *bu = nullptr;  // C x M models, C x M gradients, 3 C potentials
+        bool b_on = false, b_state = false;
+        double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
+        int64_t launches = 0, evals = 0;
+        long long *dbg = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    } rs;
+    int64_t prof_res_evals = 0;
+
+    // ring of the last K accepted samples (posterior statistics without text I/O)
+    double *ring = nullptr, *ring_mean = nullptr, *ring_sd = nullptr;
+    int ring_K = 0, ring_next = 0;
+    int64_t ring_count = 0;
+
+    // profiling of the sweeps
+    bool prof = false;
+    int prof_stride = 1;
+    int64_t prof_seen = 0;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_ms_acc = 0.0;
+    int64_t prof_launches = 0;
+};
+
+static int fail(gh_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), e_ == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP,         \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                        __LINE__);                                                          \
+    } while (0)
+
+template <typename T>
+static int dalloc(gh_ctx *c, T **out, size_t count, bool zero = true)
+{
+    if (*out) return GH_OK;
+    void *p = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(c, hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    if (zero) HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    *out = static_cast<T *>(p);
+    return GH_OK;
+}
+
+#define TRY(x)                 \
+    do {                       \
+        int rc_ = (x);         \
+        if (rc_ != GH_OK) return rc_; \
+    } while (0)
+
+static int h2d(gh_ctx *c, double *dst, const double *src, size_t n)
+{
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller-owned pageable memory: do not outlive the call
+    return GH_OK;
+}
+
+static int d2h(gh_ctx *c, double *dst, const double *src, size_t n)
+{
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}

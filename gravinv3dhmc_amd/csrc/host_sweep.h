@@ -1,0 +1,237 @@
+// libgravhmc host side: choice of the sweep instantiation, column partition, launches (dense,
+// row panels, matrix-free).  Included once by gravhmc.hip.
+#pragma once
+
+// ----------------------------------------------------------------- sweep dispatch
+
+typedef void (*sweep_fn)(SweepArgs);
+typedef void (*weight_fn)(double *, int64_t, int64_t, int64_t, int, double, double *);
+
+template <int TW, int PF, bool NT>
+static sweep_fn pick_sweep_e(int ept2)
+{
+    switch (ept2) {
+    case 1: return sweep_kernel<TW, 1, PF, NT>;
+    case 2: return sweep_kernel<TW, 2, PF, NT>;
+    case 3: return sweep_kernel<TW, 3, PF, NT>;
+    case 4: return sweep_kernel<TW, 4, PF, NT>;
+    case 5: return sweep_kernel<TW, 5, PF, NT>;
+    case 6: return sweep_kernel<TW, 6, PF, NT>;
+    case 8: return sweep_kernel<TW, 8, PF, NT>;
+    }
+    return nullptr;
+}
+
+template <int TW>
+static sweep_fn pick_sweep(int ept2, int pf, bool nt)
+{
+    if (pf == 2) return nt ? pick_sweep_e<TW, 2, true>(ept2) : pick_sweep_e<TW, 2, false>(ept2);
+    return nt ? pick_sweep_e<TW, 1, true>(ept2) : pick_sweep_e<TW, 1, false>(ept2);
+}
+
+template <int TW>
+static weight_fn pick_weight(int ept2)
+{
+    switch (ept2) {
+    case 1: return weight_kernel<TW, 1>;
+    case 2: return weight_kernel<TW, 2>;
+    case 3: return weight_kernel<TW, 3>;
+    case 4: return weight_kernel<TW, 4>;
+    case 5: return weight_kernel<TW, 5>;
+    case 6: return weight_kernel<TW, 6>;
+    case 8: return weight_kernel<TW, 8>;
+    }
+    return nullptr;
+}
+
+static sweep_fn sweep_for(const gh_ctx *c)
+{
+    if (c->TW == 1) return pick_sweep<1>(c->EPT2, c->PF, c->NT);
+    if (c->TW == 4) return pick_sweep<4>(c->EPT2, c->PF, c->NT);
+    return pick_sweep<16>(c->EPT2, c->PF, c->NT);
+}
+
+static weight_fn weight_for(const gh_ctx *c)
+{
+    if (c->TW == 1) return pick_weight<1>(c->EPT2);
+    if (c->TW == 4) return pick_weight<4>(c->EPT2);
+    return pick_weight<16>(c->EPT2);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to a context: several
+// contexts of one process share an instantiation, so the allowance is only ever raised.
+static hipError_t allow_dynamic_lds(const void *func, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<const void *, size_t> allowed;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &cur = allowed[func];
+    if (bytes <= cur) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
+
+// Choose team width / registers per thread from ld, and the column partition from M.
+static int configure_sweep(gh_ctx *c)
+{
+    const int64_t ld = c->ld;
+    int tw, per;  // rows one unit of EPT2 covers = tw*64*2
+    c->n_panels = 1;
+    c->panel_rows = ld;
+    if (ld <= 1024) tw = 1;
+    else if (ld <= 4096) tw = 4;
+    else if (ld <= 16384) tw = 16;
+    else {
+        // more rows than a team can hold in registers: row panels of <= 16384 rows.  The dot
+        // product of a column then spans several launches, so the adjoint and the forward can no
+        // longer share one read of G (two reads per step, like the reference's formulation).
+        tw = 16;
+        c->n_panels = (int)((ld + 10239) / 10240);  // <= 10240 rows: 5 double2 per thread, no spills
+        c->panel_rows = ((ld + c->n_panels - 1) / c->n_panels + 15) / 16 * 16;
+    }
+    per = tw * 128;
+    int e = (int)((c->panel_rows + per - 1) / per);
+    if (e == 7) e = 8;
+    c->TW = tw;
+    c->EPT2 = e;
+    // two columns in flight per team where the registers allow it (16-wave teams with <= 5 double2
+    // per thread: 122 VGPRs, no spills; measured at 6 and 8 double2: 5.4 / 3.1 TB/s against 6.5 / 6.1
+    // with one column in flight)
+    c->PF = env_int("GRAVHMC_PF", (tw == 16 && e <= 5) ? 2 : 1) == 2 ? 2 : 1;
+    // G larger than the Infinity Cache is streamed once per sweep: bypass-friendly loads
+    c->NT = env_int("GRAVHMC_NT", c->ld * c->M * 8 > (int64_t)(512 << 20) ? 1 : 0) != 0;
+    const int wg_teams = (tw == 1) ? 4 : 1;
+    // resident workgroups per CU we size the grid for (register/LDS budget of the kernel)
+    int wg_per_cu = (tw == 16) ? 1 : 4;
+    wg_per_cu = env_int("GRAVHMC_WG_PER_CU", wg_per_cu);
+    int64_t max_teams = (int64_t)c->cus * wg_per_cu * wg_teams;
+    int64_t min_cols = env_int("GRAVHMC_MIN_COLS", tw == 1 ? 2 : 1);
+    int64_t cpt = (c->M + max_teams - 1) / max_teams;
+    if (cpt < min_cols) cpt = min_cols;
+    c->cols_per_team = cpt;
+    c->n_teams = (int)((c->M + cpt - 1) / cpt);
+    c->n_teams_sweep = c->n_teams;
+    c->grid = (c->n_teams + wg_teams - 1) / wg_teams;
+    if (c->n_panels > 1) c->n_teams = std::max(c->n_teams, (int)((c->M + 255) / 256));  // vec_update partials
+    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : c->panel_rows + 2 * (tw + 8)) * sizeof(double);
+    if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
+    sweep_fn f = sweep_for(c);
+    if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), c->lds_bytes));
+    return GH_OK;
+}
+
+static MfGeom mf_geom(const gh_ctx *c)
+{
+    MfGeom g;
+    g.kind = c->cell_kind;
+    g.N = c->N;
+    g.M = c->M;
+    if (c->cell_kind == GH_CELL_TESSEROID) {
+        g.o0 = c->tconv;
+        g.o1 = c->tconv + c->N;
+        g.o2 = c->tconv + 2 * c->N;
+        g.o3 = c->tconv + 3 * c->N;
+    } else {
+        g.o0 = c->obs[0];
+        g.o1 = c->obs[1];
+        g.o2 = c->obs[2];
+        g.o3 = nullptr;
+    }
+    g.bounds6 = c->bounds;
+    g.ratio = c->ratio;
+    return g;
+}
+
+// matrix-free counterpart of one sweep: adjoint/update pass, then forward pass
+static int launch_mf(gh_ctx *c, SweepArgs &a)
+{
+    const MfGeom g = mf_geom(c);
+    const double *wm = c->weighted ? c->wm : nullptr;
+    bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    if (a.mode & SW_ADJ) {
+        if (!wm) return fail(c, GH_ERR_ARG, "matrix-free adjoint needs gh_weight first");
+        mf_adjoint_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(g, a, wm);
+    }
+    if (a.mode & SW_FWD) {
+        const double *x = (a.mode & SW_UPD) ? a.x_out : a.x_in;
+        mf_forward_kernel<<<dim3((unsigned)((c->ld + 255) / 256), (unsigned)c->grid), dim3(256), 0,
+                            c->stream>>>(g, x, wm, c->mf_cells_per_chunk, c->ld, a.slab);
+    }
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+static int launch_sweep_one(gh_ctx *c, SweepArgs &a)
+{
+    a.G = c->G;
+    a.ld = c->ld;
+    a.M = c->M;
+    a.cols_per_team = c->cols_per_team;
+    a.n_teams = c->n_teams_sweep;
+    const int threads = (c->TW == 1 ? 4 : c->TW) * 64;
+    sweep_fn f = sweep_for(c);
+    // short sweeps: an event pair costs about as much as the kernel, time every 16th launch only
+    bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), c->lds_bytes, c->stream, a);
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+    }
+    if (c->prof) c->prof_launches += 1;
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+static int launch_sweep(gh_ctx *c, SweepArgs &a)
+{
+    if (c->mf) return launch_mf(c, a);
+    if (c->n_panels == 1) {
+        a.row0 = 0;
+        a.rows = c->ld;
+        return launch_sweep_one(c, a);
+    }
+    // row panels: adjoint of every panel into gbuf, elementwise update, forward of every panel
+    const SweepArgs full = a;
+    if (full.mode & SW_ADJ) {
+        double *gdst = (full.mode & SW_GOUT) ? full.g_out : c->gbuf;
+        for (int p = 0; p < c->n_panels; ++p) {
+            SweepArgs s = full;
+            s.mode = SW_ADJ | SW_GOUT | (p ? SW_GACC : 0);
+            s.greg = p ? nullptr : full.greg;
+            s.g_out = gdst;
+            s.row0 = (int64_t)p * c->panel_rows;
+            s.rows = std::min<int64_t>(c->panel_rows, c->ld - s.row0);
+            TRY(launch_sweep_one(c, s));
+        }
+        if (full.mode & (SW_UPD | SW_PFIN)) {
+            SweepArgs u = full;
+            vec_update_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(u, gdst, c->M);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    if (full.mode & SW_FWD) {
+        for (int p = 0; p < c->n_panels; ++p) {
+            SweepArgs s = full;
+            s.mode = SW_FWD;
+            s.x_in = (full.mode & SW_UPD) ? full.x_out : full.x_in;
+            s.row0 = (int64_t)p * c->panel_rows;
+            s.rows = std::min<int64_t>(c->panel_rows, c->ld - s.row0);
+            TRY(launch_sweep_one(c, s));
+        }
+    }
+    return GH_OK;
+}
