@@ -990,7 +990,7 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     gh_ctx::Resident &r = c->rs;
     r.b_on = false;
     if (resident_plan(c) &&
-        resident_lds_doubles(c->ld, r.cpw, C) * sizeof(double) <= (size_t)r.lds_max) {
+        resident_lds_doubles(c->ld, r.cpw, C, r.lds_cols, r.split) * sizeof(double) <= (size_t)r.lds_max) {
         // small problem: the chains take turns inside the resident chain kernel (one launch per
         // round of trajectories, G loaded into LDS once for all of them) -- a sweep of a 30 MB G
         // per launch would leave the MFMA batch bound by launches

@@ -136,6 +136,8 @@ struct gh_ctx {
     struct Resident {
         int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
         int cpw = 0, nwg = 0, rc = 0, ct = 0;  // ct: columns per wave kept in registers
+        int lds_cols = 0;     // columns of a workgroup held in LDS
+        bool split = false;   // one copy: the first 8 ct columns in registers only, the rest in LDS
         size_t lds = 0;
         ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xccg = nullptr;
         double *xpub = nullptr;

@@ -47,19 +47,35 @@ static bool resident_plan(gh_ctx *c)
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess)
         return false;
     const int cpw = (int)((c->M + c->cus - 1) / c->cus);
-    const size_t lds = resident_lds_doubles(c->ld, cpw, 1) * sizeof(double);
-    if (lds > (size_t)lds_max || cpw > RES_THREADS) return false;
+    if (cpw > RES_THREADS) return false;
     r.lds_max = lds_max;
     r.cpw = cpw;
     r.nwg = (int)((c->M + cpw - 1) / cpw);
     if (r.nwg > RES_MAX_WG) return false;
     r.rc = (int)((c->ld / 2 + 63) / 64);
-    // columns per wave for the register copy of the dots pass (0: the wave has more than 4)
-    r.ct = (env_int("GRAVHMC_RESIDENT_REGS", 1) && cpw <= 4 * RES_WAVES) ? (cpw + RES_WAVES - 1) / RES_WAVES : 0;
-    if (r.ct * ((int)((c->ld / 2 + 63) / 64)) > 20) r.ct = 0;  // (what resident_for compiles)
-    // wavelet-compressed forward: LDS holds its dense model-space form, the dots need their own
-    // (register) copy of Aw
-    if (c->wv.on && (r.ct == 0 || wavelet_dense_form(c) != GH_OK)) return false;
+    const bool regs = env_int("GRAVHMC_RESIDENT_REGS", 1) != 0;
+    size_t lds = resident_lds_doubles(c->ld, cpw, 1, cpw, false) * sizeof(double);
+    r.split = false;
+    r.lds_cols = cpw;
+    if (lds <= (size_t)lds_max) {
+        // every column in LDS; where the registers allow it (what resident_for compiles), the
+        // waves keep a second copy of their columns for the dots pass
+        r.ct = (regs && cpw <= 4 * RES_WAVES) ? (cpw + RES_WAVES - 1) / RES_WAVES : 0;
+        if (r.ct * r.rc > 20) r.ct = 0;
+        // wavelet-compressed forward: LDS holds its dense model-space form, the dots need their own
+        // (register) copy of Aw
+        if (c->wv.on && (r.ct == 0 || wavelet_dense_form(c) != GH_OK)) return false;
+    } else {
+        // too large for the LDS alone: ONE copy, as many columns as the registers take (up to 20
+        // double2 per lane) with the waves, the rest in LDS next to 8 x ld doubles of scratch
+        if (!regs || c->wv.on) return false;
+        r.ct = std::min(4, 20 / r.rc);
+        if (r.ct < 1) return false;
+        r.lds_cols = std::max(0, cpw - r.ct * RES_WAVES);
+        r.split = true;
+        lds = resident_lds_doubles(c->ld, cpw, 1, r.lds_cols, true) * sizeof(double);
+        if (lds > (size_t)lds_max) return false;
+    }
     r.lds = lds;
     resident_fn f = resident_for(r.rc, r.ct);
     if (!f) return false;
@@ -98,7 +114,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     const size_t M = (size_t)c->M;
     const int K = q.K;
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t lds = resident_lds_doubles(c->ld, r.cpw, q.C) * sizeof(double);
+    const size_t lds = resident_lds_doubles(c->ld, r.cpw, q.C, r.lds_cols, r.split) * sizeof(double);
     if (q.C < 1 || q.C > RES_MAX_CHAINS || lds > (size_t)r.lds_max)
         return fail(c, GH_ERR_ARG, "resident chain kernel: %d chains do not fit the LDS", q.C);
     HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(resident_for(r.rc, r.ct)), lds));
@@ -156,6 +172,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     a.N = c->N;
     a.M = c->M;
     a.cols_per_wg = r.cpw;
+    a.split = r.split ? 1 : 0;
     a.nwg = r.nwg;
     // test hook: the workgroups wait for partners that do not exist, time out and abort
     if (env_int("GRAVHMC_RESIDENT_TEST_ABORT", 0)) a.nwg += 8;

@@ -51,6 +51,8 @@ struct ResArgs {
                        // read Aw from their register copy)
     int64_t ld, N, M;
     int cols_per_wg, nwg;
+    int split;      // 1 (CW > 0, Gl == G): ONE copy of the workgroup's columns, the first 8 CW of them in
+                    // the waves' registers, only the rest in LDS -- for kernels up to ~1.8x the LDS
     int try_local;  // 1: keep intra-cluster traffic in the XCD's L2 when the placement allows it
     const double *gfix, *dobs_c, *low, *high;
     // regulariser (x is set per evaluation inside the kernel)
@@ -90,9 +92,11 @@ struct ResArgs {
 
 constexpr int RES_MAX_CHAINS = 16;
 
-static inline size_t resident_lds_doubles(int64_t ld, int cols_per_wg, int chains)
+// lds_cols: columns of the workgroup held in LDS (all of them, or those beyond the register-held
+// ones in split mode, which also needs 8 x ld doubles of scratch for the waves' forward partials)
+static inline size_t resident_lds_doubles(int64_t ld, int cols_per_wg, int chains, int lds_cols, bool split)
 {
-    return (size_t)cols_per_wg * (size_t)ld + (size_t)ld + RES_REDBUF + 16 +
+    return (size_t)lds_cols * (size_t)ld + (split ? 8 * (size_t)ld : 0) + (size_t)ld + RES_REDBUF + 16 +
            (6 + 2 * (size_t)chains) * (size_t)cols_per_wg + 3 * RES_MAX_CHAINS + 8;
 }
 
@@ -221,8 +225,14 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     const int nwg = a.nwg;
     const bool stencil = (a.kind == 1 || a.kind == 3);
 
-    double *Gs = smem;                         // cpw x ld
-    double *r_s = Gs + (size_t)cpw * ld;       // ld
+    // split mode: columns [0, 8 CW) of the workgroup live in the waves' registers only
+    const bool split = CW > 0 && a.split != 0;
+    const int lds_c0 = split ? CW * RES_WAVES : 0;             // first column held in LDS
+    const int lds_cols = cpw > lds_c0 ? cpw - lds_c0 : 0;      // capacity (columns)
+    const int nl = nc > lds_c0 ? nc - lds_c0 : 0;              // LDS columns of this workgroup
+    double *Gs = smem;                                   // lds_cols x ld
+    double *fsc = Gs + (size_t)lds_cols * ld;            // split: 8 x ld forward partials of the waves
+    double *r_s = fsc + (split ? 8 * (size_t)ld : 0);    // ld
     double *redbuf = r_s + ld;                 // 16 x 33
     double *red = redbuf + RES_REDBUF;         // 16
     double *xs = red + 16;                     // position of the running trajectory
@@ -253,9 +263,9 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
 
     // ---- load the workgroup's columns (contiguous in the column-major G) and per-cell vectors
     {
-        const d2 *src = reinterpret_cast<const d2 *>(a.Gl + j0 * a.ld);
+        const d2 *src = reinterpret_cast<const d2 *>(a.Gl + (j0 + lds_c0) * a.ld);
         d2 *dst = reinterpret_cast<d2 *>(Gs);
-        const int tot = nc * ld2;
+        const int tot = nl * ld2;
         for (int e = tid; e < tot; e += RES_THREADS) dst[e] = __builtin_nontemporal_load(src + e);
     }
     if (tid < nc) {
@@ -375,11 +385,46 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        if (split) {
+            // forward share of the register-held columns: per wave over its columns, then summed
+            // over the waves through LDS in a fixed order
+            d2 dacc[RC];
+#pragma unroll
+            for (int k = 0; k < RC; ++k) dacc[k] = d2{0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < (CW > 0 ? CW : 1); ++q) {
+                const int c = wave + q * RES_WAVES;
+                if (c < nc) {
+                    const double x = xs[c];
+#pragma unroll
+                    for (int k = 0; k < RC; ++k) {
+                        dacc[k].x += gq_reg[q][k].x * x;
+                        dacc[k].y += gq_reg[q][k].y * x;
+                    }
+                }
+            }
+            d2 *f2 = reinterpret_cast<d2 *>(fsc) + wave * ld2;
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                const int e = lane + 64 * k;
+                if (e < ld2) f2[e] = dacc[k];
+            }
+            __syncthreads();
+        }
         if (tid < ld2) {
             d2 acc = d2{0.0, 0.0};
-            for (int c = 0; c < nc; ++c) {
+            if (split) {
+                const d2 *f2 = reinterpret_cast<const d2 *>(fsc);
+#pragma unroll
+                for (int v = 0; v < RES_WAVES; ++v) {
+                    const d2 t = f2[v * ld2 + tid];
+                    acc.x += t.x;
+                    acc.y += t.y;
+                }
+            }
+            for (int c = 0; c < nl; ++c) {
                 const d2 g = Gs2[c * ld2 + tid];
-                const double x = xs[c];
+                const double x = xs[lds_c0 + c];
                 acc.x += g.x * x;
                 acc.y += g.y * x;
             }
@@ -543,8 +588,10 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 const int c = wave + q * RES_WAVES;
                 if (lane == 0 && c < nc) gs[c] = s[q];
             }
-        } else {
-            for (int cb = wave; cb < nc; cb += 4 * RES_WAVES) {
+        }
+        if (CW == 0 || split) {
+            // the columns held in LDS only
+            for (int cb = lds_c0 + wave; cb < nc; cb += 4 * RES_WAVES) {
                 double s[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -555,7 +602,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                         for (int k = 0; k < RC; ++k) {
                             const int e = lane + 64 * k;
                             if (e < ld2) {
-                                const d2 g = Gs2[c * ld2 + e];
+                                const d2 g = Gs2[(c - lds_c0) * ld2 + e];
                                 s[q] += g.x * rr[k].x;
                                 s[q] += g.y * rr[k].y;
                             }

@@ -691,11 +691,13 @@ def test_resident_chain_kernel_with_wavelet_forward(G, monkeypatch, wavelet):
 
 
 @pytest.mark.parametrize("N,M", [(1, 1), (2, 7), (15, 8), (16, 9), (17, 255), (100, 256), (257, 257),
-                                 (1000, 1000), (1024, 3000), (64, 20000), (333, 4099)])
+                                 (1000, 1000), (1024, 3000), (64, 20000), (333, 4099),
+                                 (625, 10427), (1024, 6000), (1000, 5000)])
 def test_resident_chain_kernel_shapes(G, monkeypatch, N, M):
     """Edge shapes of the resident kernel's partition (fewer workgroups than clusters, one-cell
-    workgroups, ragged last workgroup, row chunks of more than 32 rows, N at its limit): same chain
-    as the sweep path."""
+    workgroups, ragged last workgroup, row chunks of more than 32 rows, N at its limit) and, last
+    three, kernels larger than the LDS (52, 49, 40 MB: one copy split between the waves' registers
+    and LDS): same chain as the sweep path."""
     rng = np.random.default_rng(N * 100003 + M)
     A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.2, 2.0, size=M))
     dobs = rng.normal(size=N) * 3
