@@ -1267,6 +1267,69 @@ int gh_shard_allreduce(gh_ctx *c, double *host_buf, int64_t count)
     return comm_allreduce_host(c, host_buf, count);
 }
 
+int64_t gh_format_row_fixed8(const double *v, int64_t n, char *out, int64_t cap)
+{
+    if (!v || !out || n < 0) return -1;
+    static const char DIG2[] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+        "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+        "8081828384858687888990919293949596979899";
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (cap - pos < 32) return -1;  // (the fast path writes at most 28 bytes; snprintf checks itself)
+        const double x = v[i];
+        const double a = std::fabs(x);
+        bool fast = a < 9.0e15;  // (false for NaN and infinities too)
+        uint64_t ip = 0;
+        uint32_t fr = 0;
+        if (fast) {
+            ip = (uint64_t)a;  // floor of a non-negative value
+            const double scaled = (a - (double)ip) * 1e8;  // a - floor(a) is exact; the product is within 1 ulp (1.5e-8)
+            const double r = (scaled + 6755399441055744.0) - 6755399441055744.0;  // to nearest, ties to even
+            // certain only away from the rounding boundary (and from a tie, which printf breaks on
+            // the exact binary value)
+            if (std::fabs(std::fabs(scaled - r) - 0.5) < 1e-7) fast = false;
+            fr = (uint32_t)r;
+            if (fr >= 100000000u) {
+                fr -= 100000000u;
+                ip += 1;
+            }
+        }
+        if (!fast) {
+            const int k = snprintf(out + pos, (size_t)(cap - pos), "%.8f", x);
+            if (k < 0 || k >= cap - pos - 2) return -1;
+            pos += k;
+        } else {
+            if (std::signbit(x)) out[pos++] = '-';
+            if (ip < 10) {
+                out[pos++] = (char)('0' + ip);
+            } else {
+                char tmp[24];
+                int nd = 0;
+                do {
+                    tmp[nd++] = (char)('0' + ip % 10);
+                    ip /= 10;
+                } while (ip);
+                while (nd) out[pos++] = tmp[--nd];
+            }
+            out[pos++] = '.';
+            const uint32_t hi4 = fr / 10000u, lo4 = fr % 10000u;
+            const uint32_t d0 = hi4 / 100u, d1 = hi4 % 100u, d2 = lo4 / 100u, d3 = lo4 % 100u;
+            memcpy(out + pos, DIG2 + 2 * d0, 2);
+            memcpy(out + pos + 2, DIG2 + 2 * d1, 2);
+            memcpy(out + pos + 4, DIG2 + 2 * d2, 2);
+            memcpy(out + pos + 6, DIG2 + 2 * d3, 2);
+            pos += 8;
+        }
+        out[pos++] = (i + 1 < n) ? ' ' : '\n';
+    }
+    if (n == 0) {
+        if (cap < 1) return -1;
+        out[pos++] = '\n';
+    }
+    return pos;
+}
+
 int gh_profile_enable(gh_ctx *c, int enable)
 {
     if (!c) return GH_ERR_ARG;

@@ -17,6 +17,8 @@ import sys
 import numpy as np
 from scipy.sparse import coo_matrix
 
+from ..utils import write_rows_fixed8
+
 
 class HamitonianMC(object):
     def __init__(self, UserDefinedModel):
@@ -101,12 +103,13 @@ class HamitonianMC(object):
 
     # ------------------------------------------------------------------ sample files
     def _save_models_add(self, x):
-        with open(self.save_folder + "/" + "model" + ".dat", "a") as f:
-            np.savetxt(f, x, fmt='%.8f', delimiter=' ')
+        # the bytes np.savetxt(f, x, fmt='%.8f', delimiter=' ') writes (hmc.py:241-245)
+        with open(self.save_folder + "/" + "model" + ".dat", "ab") as f:
+            write_rows_fixed8(f, x)
 
     def _save_misfit_add(self, misfit):
-        with open(self.save_folder + "/" + "misfit" + ".dat", "a") as f:
-            np.savetxt(f, misfit, fmt='%.8f', delimiter=' ')
+        with open(self.save_folder + "/" + "misfit" + ".dat", "ab") as f:
+            write_rows_fixed8(f, misfit)
 
     def _to_mw(self, x):
         if self.constraint == 'logarithmic':

@@ -242,6 +242,18 @@ int gh_shard_init_callback(gh_ctx *ctx, gh_allreduce_fn fn, void *user, int rank
  * lets the host combine per-rank scalars through the same communicator. */
 int gh_shard_allreduce(gh_ctx *ctx, double *host_buf, int64_t count);
 
+/* ---- sample files ---------------------------------------------------------------------- */
+
+/* One text row of the reference's model.dat / misfit.dat (np.savetxt(fmt='%.8f', delimiter=' '),
+ * hmc.py:241-249): n values as printf("%.8f") would print them, separated by one blank, closed by
+ * '\n'.  Host only, no context: at 5*10^5 cells a row is 5.5 MB of text per accepted sample
+ *  and np.savetxt's ~85 ns per value would cost as much as the trajectory on the GPU.
+ * Every value is rounded from its exact binary expansion like printf does (values whose scaled
+ * fraction lies within 1e-7 of a rounding boundary, and non-finite or huge ones, go through
+ * snprintf).  Returns the number of bytes written, or -1 if `cap` (>= 24 n + 2 is always enough
+ * for |v| < 1e13) is too small. */
+int64_t gh_format_row_fixed8(const double *v, int64_t n, char *out, int64_t cap);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 
 /* HIP-event timing of the G sweeps (the dominant kernel) on the context's stream.

@@ -139,3 +139,34 @@ def test_utils_carve_roundtrip_and_regular():
     x, y, z = utils.regular((0, 2000, 0, 3000), (20, 30), z=0.0)
     yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 3000, 30), np.linspace(0, 2000, 20))]
     assert np.array_equal(x, xp) and np.array_equal(y, yp) and z.shape == (600,) and not z.any()
+
+
+def test_fixed8_row_formatter_is_savetxt_bit_for_bit(tmp_path):
+    """gh_format_row_fixed8 (the sampler's model.dat / misfit.dat rows) must write exactly the bytes
+    np.savetxt(fmt='%.8f', delimiter=' ') writes: random values of several magnitudes, values on and
+    next to the rounding boundaries (ties are broken by printf on the exact binary value), signed
+    zeros, non-finite and huge values, 1-D input (one value per line)."""
+    import io
+    from gravinv3dhmc_amd.utils import format_rows_fixed8, write_rows_fixed8
+    rng = np.random.default_rng(0)
+
+    def ref(a):
+        s = io.BytesIO()
+        np.savetxt(s, a, fmt='%.8f', delimiter=' ')
+        return s.getvalue()
+
+    cases = [rng.normal(size=(3, 1000)), rng.normal(size=(2, 777)) * 1e-9, rng.normal(size=(1, 500)) * 1e6,
+             np.array([[0.0, -0.0, 1e-9, -1e-9, 0.5e-8, 1.5e-8, 2.5e-8, -0.5e-8, 0.999999995,
+                        0.9999999949999, 1.0, 123456789.125, -7.00000001, 99999999.999999995]]),
+             np.array([[np.nan, np.inf, -np.inf, 1e300, -1e16, 9.1e15, 8.9e15]]),
+             rng.normal(size=7),
+             (rng.integers(-10**9, 10**9, size=(4, 2000)) + 0.5) * 1e-8,
+             rng.integers(0, 10**6, size=(2, 5000)) * 1e-8 * 0.5,
+             np.nextafter((rng.integers(0, 10**8, size=(1, 3000)) + 0.5) * 1e-8, 1.0)]
+    for c in cases:
+        assert format_rows_fixed8(c) == ref(c)
+    f = tmp_path / "rows.dat"
+    with open(f, "ab") as fh:
+        write_rows_fixed8(fh, cases[0])
+        write_rows_fixed8(fh, cases[3])
+    assert f.read_bytes() == ref(cases[0]) + ref(cases[3])
