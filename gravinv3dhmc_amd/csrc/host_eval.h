@@ -142,7 +142,9 @@ static int ensure_work(gh_ctx *c)
     if (c->n_panels > 1) TRY(dalloc(c, &c->gbuf, M));
     TRY(dalloc(c, &c->slab, (size_t)c->grid * ld));
     if (c->grid > 64) {
-        c->slab2_rows = 16;
+        // segments left for the single-block finish_kernel: as many as keep its read at ~128 KB
+        // (C1: 16 x 608 rows; C2: 1 x 10^4 -- sixteen there made that one block read 1.3 MB, 57 us)
+        c->slab2_rows = (int)std::max<int64_t>(1, std::min<int64_t>(16, 16384 / (int64_t)ld));
         TRY(dalloc(c, &c->slab2, (size_t)c->slab2_rows * ld));
     }
     c->n_dpart = (int)((c->ld + 31) / 32);
