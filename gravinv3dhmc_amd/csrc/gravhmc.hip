@@ -85,6 +85,8 @@ void gh_destroy(gh_ctx *c)
     for (void *p : c->allocs) hipFree(p);
     if (c->h_scal) hipHostFree(c->h_scal);
     for (hipEvent_t ev : c->ev) hipEventDestroy(ev);
+    if (c->copy_ev) hipEventDestroy(c->copy_ev);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->rs.ev0) hipEventDestroy(c->rs.ev0);
     if (c->rs.ev1) hipEventDestroy(c->rs.ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -710,8 +712,11 @@ static inline int other_of3(int a, int b)
     return 0;
 }
 
-int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u, int *accepted,
-                        double out5[5])
+// p0_next (or nullptr): momentum of the NEXT trajectory, valid until this call returns.  Announced
+// this way (gh_chain_run) it is uploaded on a second stream while this trajectory's sweeps run --
+// through the public gh_chain_prefetch_momentum the upload happens before them, with the GPU idle.
+static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, double u, const double *p0_next,
+                                 int *accepted, double out5[5])
 {
     if (!c || !p0 || !accepted || !out5) return fail(c, GH_ERR_ARG, "gh_chain_trajectory: null pointer");
     TRY(need(c, c->chain_ready, "gh_chain_trajectory: call gh_chain_init first"));
@@ -767,9 +772,27 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     // announced the next trajectory's momentum, the same sweep also takes that trajectory's
     // first leapfrog step from the proposal (valid if the proposal is accepted): the gradient
     // at the proposal is needed by both, so the extra sweep per trajectory disappears.
-    const bool spec = c->pn_valid;
-    const double probe[3] = {c->pn_probe[0], c->pn_probe[1], c->pn_probe[2]};
-    const double pn_pp0 = c->pn_pp0;
+    bool spec = c->pn_valid;
+    double probe[3] = {c->pn_probe[0], c->pn_probe[1], c->pn_probe[2]};
+    double pn_pp0 = c->pn_pp0;
+    bool pn_deferred = false;
+    if (p0_next) {
+        if (!c->copy_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+        }
+        // (c->pn was last read by the previous trajectory's final sweep, which has completed)
+        HIPCHK(c, hipMemcpyAsync(c->pn, p0_next, M * sizeof(double), hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->copy_ev, c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
+        // its initial kinetic energy, summed exactly like gh_chain_prefetch_momentum does
+        sumsq_kernel<<<dim3(c->n_pp0), dim3(256), 0, c->stream>>>(c->pn, c->M, c->pn0_part);
+        probe[0] = p0_next[0];
+        probe[1] = p0_next[c->M / 2];
+        probe[2] = p0_next[c->M - 1];
+        spec = true;
+        pn_deferred = true;
+    }
     const int xs = other_of3(c->xcur, xin), ss = other_of3(c->cur, sin);
     {
         SweepArgs a{};
@@ -805,7 +828,15 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     if (!use_spec)
         HIPCHK(c, hipMemcpyAsync(h + 16 + 2 * nt, c->pp0_part, (size_t)c->n_pp0 * sizeof(double),
                                  hipMemcpyDeviceToHost, c->stream));
+    if (pn_deferred)
+        HIPCHK(c, hipMemcpyAsync(h + 16 + 2 * nt + c->n_pp0, c->pn0_part, (size_t)c->n_pp0 * sizeof(double),
+                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (pn_deferred) {
+        double s = 0.0;
+        for (int t = 0; t < c->n_pp0; ++t) s += h[16 + 2 * nt + c->n_pp0 + t];
+        pn_pp0 = s;
+    }
     double pp1 = 0.0, pp0 = 0.0;
     for (int t = 0; t < nt; ++t) pp1 += h[16 + t];
     if (use_spec)
@@ -855,6 +886,12 @@ int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u,
     return GH_OK;
 }
 
+int gh_chain_trajectory(gh_ctx *c, const double *p0, double dt, int L, double u, int *accepted,
+                        double out5[5])
+{
+    return chain_trajectory_impl(c, p0, dt, L, u, nullptr, accepted, out5);
+}
+
 int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt,
                  const double *p0_lookahead, int64_t stop_at_accepts, int64_t record_from, int *accepted,
                  double *out5s, double *x_out, int *n_run)
@@ -883,8 +920,7 @@ int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double
     }
     for (int k = 0; k < K; ++k) {
         const double *nxt = (k + 1 < K) ? p0s + (size_t)(k + 1) * M : p0_lookahead;
-        if (nxt) TRY(gh_chain_prefetch_momentum(c, nxt));
-        TRY(gh_chain_trajectory(c, p0s + (size_t)k * M, dt, L[k], us[k], &accepted[k], out5s + 5 * k));
+        TRY(chain_trajectory_impl(c, p0s + (size_t)k * M, dt, L[k], us[k], nxt, &accepted[k], out5s + 5 * k));
         *n_run = k + 1;
         if (accepted[k]) {
             c->accept_count += 1;

@@ -14,6 +14,8 @@ struct gh_ctx {
     int64_t N = 0, M = 0, ld = 0;
     int cus = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // upload of the next trajectory's momentum beside the sweeps
+    hipEvent_t copy_ev = nullptr;
     std::string err;
     std::vector<void *> allocs;
 
@@ -66,7 +68,7 @@ struct gh_ctx {
     double *slab2 = nullptr;
     int slab2_rows = 0;
     double *slab = nullptr, *dpart = nullptr, *regpart = nullptr, *pp_part = nullptr,
-           *ppn_part = nullptr, *pp0_part = nullptr, *scal_all = nullptr;
+           *ppn_part = nullptr, *pp0_part = nullptr, *pn0_part = nullptr, *scal_all = nullptr;
     double *tmpM = nullptr, *tmpN = nullptr;
     int n_dpart = 0, n_regpart = 0, n_pp0 = 0;
     double *h_scal = nullptr;  // pinned: scalars + partial sums

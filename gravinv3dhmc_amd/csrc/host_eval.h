@@ -155,6 +155,7 @@ static int ensure_work(gh_ctx *c)
     TRY(dalloc(c, &c->pp_part, (size_t)c->n_teams));
     TRY(dalloc(c, &c->ppn_part, (size_t)c->n_teams));
     TRY(dalloc(c, &c->pp0_part, (size_t)c->n_pp0));
+    TRY(dalloc(c, &c->pn0_part, (size_t)c->n_pp0));
     TRY(dalloc(c, &c->tmpM, M));
     TRY(dalloc(c, &c->tmpN, ld));
     TRY(dalloc(c, &c->low, M));
@@ -166,7 +167,7 @@ static int ensure_work(gh_ctx *c)
         TRY(dalloc(c, &c->wm2, M));
     }
     if (!c->h_scal) {
-        c->h_scal_n = 16 + 2 * (size_t)c->n_teams + (size_t)c->n_pp0;
+        c->h_scal_n = 16 + 2 * (size_t)c->n_teams + 2 * (size_t)c->n_pp0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_scal, c->h_scal_n * sizeof(double)));
     }
     return GH_OK;

@@ -222,28 +222,36 @@ class Engine(object):
         return {"spec_hits": a.value, "spec_misses": b.value,
                 "resident_launches": la.value, "resident_evaluations": ev.value}
 
-    def _run_batch(self, batch, lookahead, dt, stop_at, record_from, want_x):
-        """One gh_chain_run call over a list of (L, p0, u); returns per-trajectory results."""
+    def _prepare_batch(self, batch, lookahead, want_x):
+        """Arguments of one gh_chain_run call over a list of (L, p0, u), marshalled on the calling
+        thread (the 4 MB per momentum of C2 are copied here, not between two batches on the GPU)."""
         K = len(batch)
-        Ls = (C.c_int * K)(*[int(b[0]) for b in batch])
         p0s = np.ascontiguousarray(np.stack([self._loc_vec(b[1]) for b in batch]))
-        us = np.ascontiguousarray([float(b[2]) for b in batch], dtype=np.float64)
-        look = self._loc_vec(lookahead[1]) if lookahead is not None else None
-        acc = (C.c_int * K)()
-        out5 = np.empty((K, 5))
-        xs = np.empty((K, p0s.shape[1])) if want_x else None
-        n_run = C.c_int(0)
-        self._chk(self._lib.gh_chain_run(self._h, K, Ls, ptr(p0s), ptr(us), float(dt), ptr(look),
-                                         int(stop_at), int(record_from), acc, ptr(out5), ptr(xs),
-                                         C.byref(n_run)))
+        return {"K": K, "Ls": (C.c_int * K)(*[int(b[0]) for b in batch]), "p0s": p0s,
+                "us": np.ascontiguousarray([float(b[2]) for b in batch], dtype=np.float64),
+                "look": self._loc_vec(lookahead[1]) if lookahead is not None else None,
+                "acc": (C.c_int * K)(), "out5": np.empty((K, 5)),
+                "xs": np.empty((K, p0s.shape[1])) if want_x else None, "n_run": C.c_int(0)}
+
+    def _run_batch(self, batch, lookahead, dt, stop_at, record_from, want_x, prepared=None, entered=None):
+        """One gh_chain_run call over a list of (L, p0, u); returns per-trajectory results.
+        `entered` (threading.Event) is set right before the library call (which releases the GIL)."""
+        a = prepared if prepared is not None else self._prepare_batch(batch, lookahead, want_x)
+        if entered is not None:
+            entered.set()
+        self._chk(self._lib.gh_chain_run(self._h, a["K"], a["Ls"], ptr(a["p0s"]), ptr(a["us"]), float(dt),
+                                         ptr(a["look"]), int(stop_at), int(record_from), a["acc"],
+                                         ptr(a["out5"]), ptr(a["xs"]), C.byref(a["n_run"])))
+        acc, out5, xs = a["acc"], a["out5"], a["xs"]
         return [(bool(acc[k]), out5[k].copy(), xs[k].copy() if (want_x and acc[k]) else None)
-                for k in range(n_run.value)]
+                for k in range(a["n_run"].value)]
 
     def default_batch(self):
-        """Trajectories per gh_chain_run call: enough to hide the per-call cost (Python round trip,
-        momentum upload, for small problems the launch of the resident chain kernel), few enough
-        that the host draw of the next batch still overlaps the GPU (C2: 1, C1: 128)."""
-        return int(max(1, min(128, (6 << 20) // (8 * max(1, self.M)))))
+        """Trajectories per gh_chain_run call: enough to hide the per-call cost (Python round trip:
+        ~0.5 ms of idle GPU per call at C2; momentum upload; for small problems the launch of the
+        resident chain kernel), few enough that the host draw of the next batch still overlaps the
+        GPU (C2: 4, C1: 128)."""
+        return int(max(4, min(128, (6 << 20) // (8 * max(1, self.M)))))
 
     def _loc_vec(self, v):
         return f64(v)
@@ -276,21 +284,30 @@ class Engine(object):
 
         cur = take(batch)
         look = take(1) if cur else []
+        prepared = self._prepare_batch(cur, look[0] if look else None, want_x) if cur else None
         while cur:
             res = {}
+            entered = threading.Event()
 
-            def work(cur=cur, look=look):
+            def work(cur=cur, look=look, prepared=prepared, entered=entered):
                 try:
                     res["r"] = self._run_batch(cur, look[0] if look else None, dt, stop_at_accepts,
-                                               record_from, want_x)
+                                               record_from, want_x, prepared, entered)
                 except BaseException as e:  # re-raised in the caller's thread
                     res["e"] = e
+                finally:
+                    entered.set()
 
             th = threading.Thread(target=work)
             th.start()
-            # the lookahead trajectory opens the next batch; the rest is drawn while the GPU runs
+            # the GPU has its work before this thread goes back to drawing (the legacy generator
+            # holds the GIL for the ~10 ms a C2 momentum takes)
+            entered.wait()
+            # the lookahead trajectory opens the next batch; the rest is drawn and marshalled
+            # while the GPU runs
             nxt = (look + take(batch - 1)) if look else []
             nlook = take(1) if nxt else []
+            nprepared = self._prepare_batch(nxt, nlook[0] if nlook else None, want_x) if nxt else None
             th.join()
             if "e" in res:
                 raise res["e"]
@@ -301,7 +318,7 @@ class Engine(object):
                     break
             if stop or len(res["r"]) < len(cur):
                 break
-            cur, look = nxt, nlook
+            cur, look, prepared = nxt, nlook, nprepared
 
     def chain_get_x(self):
         x = np.empty(self.M)
