@@ -110,6 +110,15 @@ static int configure_sweep(gh_ctx *c)
     const int wg_teams = (tw == 1) ? 4 : 1;
     // resident workgroups per CU we size the grid for (register/LDS budget of the kernel)
     int wg_per_cu = (tw == 16) ? 1 : 4;
+    if (tw == 4) {
+        // 4-wave teams (1024 < N <= 4096): as many teams as keep ~16 MB of columns in flight, not
+        // more -- every further team costs a slab row per sweep and shortens the teams' column runs
+        // (measured at 4000 x 30000, 960 MB: 5.6 TB/s with 2 workgroups per CU against 4.8 with 4;
+        // at 2000 x 20000 four are needed: 4.6 against 3.6 TB/s)
+        const int64_t col_bytes = c->panel_rows * (int64_t)sizeof(double);
+        const int64_t need = (((int64_t)env_int("GRAVHMC_INFLIGHT_MB", 16) << 20) + col_bytes - 1) / col_bytes;
+        wg_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(4, (need + c->cus - 1) / c->cus));
+    }
     wg_per_cu = env_int("GRAVHMC_WG_PER_CU", wg_per_cu);
     int64_t max_teams = (int64_t)c->cus * wg_per_cu * wg_teams;
     int64_t min_cols = env_int("GRAVHMC_MIN_COLS", tw == 1 ? 2 : 1);
