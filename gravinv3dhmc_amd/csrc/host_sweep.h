@@ -48,6 +48,7 @@ static sweep_fn sweep_for(const gh_ctx *c)
 {
     if (c->TW == 1) return pick_sweep<1>(c->EPT2, c->PF, c->NT);
     if (c->TW == 4) return pick_sweep<4>(c->EPT2, c->PF, c->NT);
+    if (c->TW == 8) return pick_sweep<8>(c->EPT2, c->PF, c->NT);
     return pick_sweep<16>(c->EPT2, c->PF, c->NT);
 }
 
@@ -55,6 +56,7 @@ static weight_fn weight_for(const gh_ctx *c)
 {
     if (c->TW == 1) return pick_weight<1>(c->EPT2);
     if (c->TW == 4) return pick_weight<4>(c->EPT2);
+    if (c->TW == 8) return pick_weight<8>(c->EPT2);
     return pick_weight<16>(c->EPT2);
 }
 
@@ -87,6 +89,9 @@ static int configure_sweep(gh_ctx *c)
     c->panel_rows = ld;
     if (ld <= 1024) tw = 1;
     else if (ld <= 4096) tw = 4;
+    // 8-wave teams, two per CU, while a thread holds <= 6 double2 (measured at N = 5000 / 6000:
+    // 6.5 / 6.2 TB/s against 5.2 / 5.8 with 16-wave teams; at 7381 and 8192 rows 16 waves win)
+    else if (ld <= 6144 && env_int("GRAVHMC_TW8", 1)) tw = 8;
     else if (ld <= 16384) tw = 16;
     else {
         // more rows than a team can hold in registers: row panels of <= 16384 rows.  The dot
@@ -109,7 +114,7 @@ static int configure_sweep(gh_ctx *c)
     c->NT = env_int("GRAVHMC_NT", c->ld * c->M * 8 > (int64_t)(512 << 20) ? 1 : 0) != 0;
     const int wg_teams = (tw == 1) ? 4 : 1;
     // resident workgroups per CU we size the grid for (register/LDS budget of the kernel)
-    int wg_per_cu = (tw == 16) ? 1 : 4;
+    int wg_per_cu = (tw == 16) ? 1 : (tw == 8) ? 2 : 4;
     if (tw == 4) {
         // 4-wave teams (1024 < N <= 4096): as many teams as keep ~16 MB of columns in flight, not
         // more -- every further team costs a slab row per sweep and shortens the teams' column runs

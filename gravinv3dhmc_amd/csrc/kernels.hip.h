@@ -91,7 +91,7 @@ struct ColRegs {
                 // and team instead of one per scalar and wave
 };
 
-// TW = waves per team (1, 4, 16).  TW == 1: four independent wave-teams per 256-thread block.
+// TW = waves per team (1, 4, 8, 16).  TW == 1: four independent wave-teams per 256-thread block.
 // EPT2 = double2 elements held per thread: capacity = TW*64*EPT2*2 rows >= ld.
 // PF = columns prefetched ahead (1 or 2).  NT = non-temporal loads of G (streamed once).
 template <int TW, int EPT2, int PF, bool NT>

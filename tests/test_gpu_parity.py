@@ -104,7 +104,8 @@ def test_tesseroid_frontend_warns_and_matches(G):
 # ----------------------------------------------------------------------- GEMV primitives
 
 @pytest.mark.parametrize("N,M", [(1, 1), (17, 5), (42, 120), (600, 257), (625, 1000), (1024, 64),
-                                 (1025, 300), (2500, 123), (4097, 77), (7381, 300), (10000, 513),
+                                 (1025, 300), (2500, 123), (4097, 77), (5000, 200), (6144, 50), (6145, 50), (7381, 300),
+                                 (10000, 513),
                                  (16384, 40), (16385, 21), (20000, 77), (40000, 33)])
 def test_forward_adjoint_vs_numpy(G, N, M):
     rng = np.random.default_rng(N * 1000 + M)
