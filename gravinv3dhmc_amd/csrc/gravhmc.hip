@@ -179,6 +179,7 @@ int gh_build_G(gh_ctx *c)
         c->have_G = true;
         c->weighted = false;
         c->chain_ready = false;
+        c->bt.ready = false;
         return GH_OK;
     }
     if (!c->dense_ok)
@@ -227,6 +228,7 @@ int gh_build_G(gh_ctx *c)
     c->have_G = true;
     c->weighted = false;
     c->chain_ready = false;
+    c->bt.ready = false;
     return GH_OK;
 }
 
@@ -269,6 +271,7 @@ int gh_upload_G(gh_ctx *c, const double *A, int64_t ld, int fortran_order)
     c->have_G = true;
     c->weighted = false;
     c->chain_ready = false;
+    c->bt.ready = false;
     return GH_OK;
 }
 
@@ -314,6 +317,7 @@ int gh_weight(gh_ctx *c, double weightfactor, double *wm_out)
     TRY(h2d(c, c->wm2, w.data(), (size_t)c->M));
     c->weighted = true;
     c->chain_ready = false;
+    c->bt.ready = false;
     return GH_OK;
 }
 
@@ -357,6 +361,7 @@ int gh_set_data(gh_ctx *c, const double *dobs, const double *grav_fix)
     if (grav_fix) TRY(h2d(c, c->gfix, grav_fix, N));
     c->have_data = true;
     c->chain_ready = false;
+    c->bt.ready = false;
     return GH_OK;
 }
 
@@ -428,6 +433,7 @@ int gh_set_reg(gh_ctx *c, int kind, double alpha, double beta, const int shape3[
     }
     c->have_reg = true;
     c->chain_ready = false;
+    c->bt.ready = false;
     return GH_OK;
 }
 
@@ -619,6 +625,7 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     w.F_valid = false;
     c->rs.state = 0;  // plan the resident chain kernel again (it would need the dense form)
     c->chain_ready = false;
+    c->bt.ready = false;
     if (nnz_out) *nnz_out = w.nnz;
     if (ncols_out) *ncols_out = Mp;
     return GH_OK;

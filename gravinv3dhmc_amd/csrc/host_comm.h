@@ -97,5 +97,6 @@ static int shard_common_init(gh_ctx *c, int rank, int world, int64_t M_global, i
     if (!c->sh.hbuf) HIPCHK(c, hipHostMalloc((void **)&c->sh.hbuf, sizeof(double) * ((size_t)c->ld + 8)));
     c->sh.buf_n = (size_t)c->ld + 8;
     c->chain_ready = false;
+    c->bt.ready = false;
     return GH_OK;
 }
