@@ -5,8 +5,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "gravhmc.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "kernels.hip.h"),
-        os.path.join(os.path.dirname(_HERE), "include", "gravhmc.h")]
+_CSRC = os.path.join(_HERE, "csrc")
+DEPS = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))) + \
+       [os.path.join(os.path.dirname(_HERE), "include", "gravhmc.h")]
 LIB = os.path.join(_HERE, "libgravhmc.so")
 
 
