@@ -710,7 +710,10 @@ def test_resident_chain_kernel_shapes(G, monkeypatch, N, M):
         e.upload_G(A)
         w = e.weight(0.5)
         e.set_data(dobs)
-        e.set_reg("MS", 0.7, 0.01, None, 0.001 * w)
+        if (N, M) == (1000, 5000):          # one-copy mode with a stencil regulariser
+            e.set_reg("TV", 0.7, 0.01, (10, 20, 25), 0.001 * w)
+        else:
+            e.set_reg("MS", 0.7, 0.01, None, 0.001 * w)
         e.chain_init(0.002 * w, 0.0 * w, 0.5 * w)
         out = []
         e.run_chain(iter(trajs), 0.01, lambda L, acc, o, x: out.append((acc, o.copy())), batch=4)
