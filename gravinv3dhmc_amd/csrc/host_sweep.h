@@ -133,6 +133,8 @@ static int configure_sweep(gh_ctx *c)
     c->n_teams = (int)((c->M + cpt - 1) / cpt);
     c->n_teams_sweep = c->n_teams;
     c->grid = (c->n_teams + wg_teams - 1) / wg_teams;
+    // (one-wave teams interleave inside their block's column range: every wave of the grid is a team)
+    if (tw == 1) c->n_teams = c->n_teams_sweep = c->grid * wg_teams;
     if (c->n_panels > 1) c->n_teams = std::max(c->n_teams, (int)((c->M + 255) / 256));  // vec_update partials
     c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : c->panel_rows + 2 * (tw + 8)) * sizeof(double);
     if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
