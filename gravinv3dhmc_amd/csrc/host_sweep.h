@@ -101,6 +101,12 @@ static int configure_sweep(gh_ctx *c)
         c->n_panels = (int)((ld + 10239) / 10240);  // <= 10240 rows: 5 double2 per thread, no spills
         c->panel_rows = ((ld + c->n_panels - 1) / c->n_panels + 15) / 16 * 16;
     }
+    {
+        // diagnostic override of the team width (must still hold a column: 8 double2 per thread)
+        const int tw_env = env_int("GRAVHMC_TW", 0);
+        if ((tw_env == 1 || tw_env == 4 || tw_env == 8 || tw_env == 16) && (int64_t)tw_env * 1024 >= c->panel_rows)
+            tw = tw_env;
+    }
     per = tw * 128;
     int e = (int)((c->panel_rows + per - 1) / per);
     if (e == 7) e = 8;
@@ -124,6 +130,23 @@ static int configure_sweep(gh_ctx *c)
         const int64_t need = (((int64_t)env_int("GRAVHMC_INFLIGHT_MB", 16) << 20) + col_bytes - 1) / col_bytes;
         wg_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(4, (need + c->cus - 1) / c->cus));
     }
+    // never more than the kernel's real residency (registers, LDS): a grid sized for four
+    // workgroups per CU of which three fit runs a quarter of its blocks in a second, thin wave
+    // (one-wave teams with 8 double2, 140 VGPRs: 5.1 TB/s; sized for the three that fit: 6.5)
+    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : c->panel_rows + 2 * (tw + 8)) * sizeof(double);
+    if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
+    sweep_fn f = sweep_for(c);
+    if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), c->lds_bytes));
+    {
+        int occ = 0;
+        const int threads = (tw == 1 ? 4 : tw) * 64;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(f), threads,
+                                                         c->lds_bytes) == hipSuccess && occ >= 1)
+            wg_per_cu = std::min(wg_per_cu, occ);
+        else
+            (void)hipGetLastError();
+    }
     wg_per_cu = env_int("GRAVHMC_WG_PER_CU", wg_per_cu);
     int64_t max_teams = (int64_t)c->cus * wg_per_cu * wg_teams;
     int64_t min_cols = env_int("GRAVHMC_MIN_COLS", tw == 1 ? 2 : 1);
@@ -136,11 +159,6 @@ static int configure_sweep(gh_ctx *c)
     // (one-wave teams interleave inside their block's column range: every wave of the grid is a team)
     if (tw == 1) c->n_teams = c->n_teams_sweep = c->grid * wg_teams;
     if (c->n_panels > 1) c->n_teams = std::max(c->n_teams, (int)((c->M + 255) / 256));  // vec_update partials
-    c->lds_bytes = (size_t)(tw == 1 ? 5 * ld : c->panel_rows + 2 * (tw + 8)) * sizeof(double);
-    if (c->lds_bytes > 160 * 1024) return fail(c, GH_ERR_UNSUPPORTED, "LDS budget exceeded");
-    sweep_fn f = sweep_for(c);
-    if (!f) return fail(c, GH_ERR_UNSUPPORTED, "no sweep instantiation for EPT2=%d", e);
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), c->lds_bytes));
     return GH_OK;
 }
 
