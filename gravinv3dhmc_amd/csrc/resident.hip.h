@@ -1,34 +1,40 @@
 // Resident chain kernel (gfx950): a whole batch of HMC trajectories in ONE launch for sensitivity
-// matrices small enough to live in the chip's LDS (256 CUs x 160 KB: N*M*8 <= ~36 MB, N <= 1024 --
-// the reference's uniformgrid example and BASELINE configs[0], 600 x 6000).
+// matrices small enough to live on the chip (256 CUs x (160 KB LDS + registers): N <= 1024 and
+// N*M*8 up to ~36 MB with a copy in LDS, ~65 MB with one copy split between LDS and registers --
+// the reference's uniformgrid and realdata examples, BASELINE configs[0] (600 x 6000) and, through
+// the dense form of the compressed forward, configs[2]).
 //
 // At that size the sweep-per-launch path is bound by launches and by re-reading G from L2/MALL
 // (3 launches, ~30 us per leapfrog step at C1), not by HBM.  Here every workgroup owns a fixed
-// block of columns (cells), loads them into LDS once per launch and keeps them there; per
-// leapfrog step only N-vectors cross the chip:
+// block of columns (cells), loads them once per launch and keeps them; per leapfrog step only
+// N-vectors cross the chip:
 //
-//   local              wave-per-column dots <G_j, r> -> gradient -> momentum/position update with
-//                      clamp-and-reflect (hmc.py:114-152); thread-per-row forward partial
-//                      sum_j G_ij x_j over the workgroup's columns
-//   hop A              the partials are published as tagged granules; `nred` reducer workgroups
-//                      sum 8 rows each over all workgroups in a fixed order -> d, published likewise
-//   hop B              every workgroup reads d, removes the mean and forms r redundantly
-//                      (potential.py:700-706: identical bits everywhere), evaluates the regulariser
-//                      gradient of its own cells
-//   trajectory end     last half momentum step, one all-gather of three scalars per workgroup
-//                      (R, p'p before/after), Metropolis test (hmc.py:158-177) decided identically
-//                      by every workgroup; the gradient at the proposal is kept for the next
-//                      trajectory, so a trajectory of L steps costs exactly L evaluations
+//   local        wave-per-column dots <G_j, r> (columns in registers where they fit) -> gradient ->
+//                one thread per column: momentum/position update with clamp-and-reflect
+//                (hmc.py:114-152); thread-per-row forward partial sum_j G_ij x_j over the own columns
+//   level 1      cluster = workgroups with equal w % 8 (one XCD, one L2).  The partials are
+//                published as tagged granules; member `crank` of every cluster sums row chunk
+//                `crank` of d over its cluster (through L2 when the placement allows it)
+//   level 2      the chunk's eight cluster sums cross the XCDs once (write-through); every cluster's
+//                owner adds them in the same order -> the same d everywhere
+//   level 3      every workgroup reads d from its cluster's copy, removes the mean and forms r
+//                redundantly (potential.py:700-706: identical bits everywhere), evaluates the
+//                regulariser gradient of its own cells
+//   trajectory   last half momentum step, one all-gather of three scalars per workgroup
+//   end          (R, p'p before/after), Metropolis test (hmc.py:158-177) decided identically by
+//                every workgroup; the gradient at the proposal is kept for the next trajectory,
+//                so a trajectory of L steps costs exactly L evaluations
 //
 // Inter-workgroup hand-offs: the data is the flag.  A double travels as two naturally aligned
-// 8-byte granules {tag = evaluation number, 32 bits of the value}, each written by ONE
-// write-through (sc1) store and read by sc1 loads that bypass the reader's L1; a reader re-reads
-// its granules until every tag is the evaluation it waits for.  No counters, no fences, no
-// barrier on the hot path; a buffer is only overwritten after every reader has published
-// something that depends on having read it.  (First version: arrival counters + agent acquire,
-// 2 x ~5 us per evaluation; this form: see DESIGN.md.)  Every spin is bounded: on a time-out the
-// abort word is raised, every workgroup leaves and the host falls back to the sweep path.  The
-// grid (one workgroup per CU by the LDS request) is checked against the occupancy query on the host.
+// 8-byte granules {tag = evaluation number, 32 bits of the value}, each written by ONE store and
+// read by sc1 loads that bypass the reader's L1; a reader re-reads the granules it still misses
+// until every tag is the evaluation it waits for.  No counters, no fences, no grid barrier; a
+// buffer is only overwritten after every reader has published something that depends on having
+// read it (the cross-XCD sums are double-buffered by evaluation parity).  Measured steps from the
+// first version (arrival counters + agent-scope acquires, 19.9 us per evaluation at C1) to this
+// one (7.1 us): DESIGN.md 4.5.  Every spin is bounded: on a time-out the abort word is raised,
+// every workgroup leaves and the host falls back to the sweep path.  The grid (one workgroup per
+// CU by the LDS request) is checked against the occupancy query on the host.
 #pragma once
 #include "kernels.hip.h"
 
