@@ -385,8 +385,8 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         const unsigned tag = a.tag0 + (unsigned)ev + 1u;
         const int par = ev & 1;
         if (stencil) {
-            // neighbours read the model after hop B: the stores are drained before any of this
-            // workgroup's partials (which hop B transitively waits for) is published
+            // neighbours read the model once they have d (level 3): the stores are drained before
+            // any of this workgroup's partials, which d transitively depends on, is published
             if (tid < nc) st_wt(a.xpub + (int64_t)par * M + j0 + tid, xs[tid]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
