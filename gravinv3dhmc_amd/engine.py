@@ -260,14 +260,18 @@ class Engine(object):
         return v
 
     def run_chain(self, draws, dt, on_result, stop_at_accepts=0, record_from=0, want_x=False,
-                  batch=None):
+                  batch=None, overlap=False):
         """Pipelined trajectories: `draws` yields (L, p0, u) in RNG-stream order.  Batches of
         trajectories run inside one library call (gh_chain_run: momentum of trajectory k+1
         announced before trajectory k, so an accepted proposal's last sweep already takes the
         next first step; small dense problems: one launch of the resident chain kernel per batch)
         while the next batch is drawn on the host.
         `on_result(L, accepted, out5, x)` is called per finished trajectory (x = chain state after
-        an accepted trajectory if want_x, else None) and may return False to stop."""
+        an accepted trajectory if want_x, else None) and may return False to stop.
+        overlap=True hands a finished batch to `on_result` while the next one already runs (the
+        device never waits for Python's bookkeeping or file output); a stop requested by
+        `on_result` -- as opposed to `stop_at_accepts`, which the library itself honours, or the
+        end of `draws` -- then takes effect one batch late."""
         import threading
         if batch is None:
             batch = self.default_batch()
@@ -282,14 +286,11 @@ class Engine(object):
                 out.append(d)
             return out
 
-        cur = take(batch)
-        look = take(1) if cur else []
-        prepared = self._prepare_batch(cur, look[0] if look else None, want_x) if cur else None
-        while cur:
+        def start(cur, look, prepared):
             res = {}
             entered = threading.Event()
 
-            def work(cur=cur, look=look, prepared=prepared, entered=entered):
+            def work():
                 try:
                     res["r"] = self._run_batch(cur, look[0] if look else None, dt, stop_at_accepts,
                                                record_from, want_x, prepared, entered)
@@ -303,22 +304,38 @@ class Engine(object):
             # the GPU has its work before this thread goes back to drawing (the legacy generator
             # holds the GIL for the ~10 ms a C2 momentum takes)
             entered.wait()
+            return th, res
+
+        def finish(job):
+            job[0].join()
+            if "e" in job[1]:
+                raise job[1]["e"]
+            return job[1]["r"]
+
+        cur = take(batch)
+        look = take(1) if cur else []
+        job = start(cur, look, self._prepare_batch(cur, look[0] if look else None, want_x)) if cur else None
+        while cur:
             # the lookahead trajectory opens the next batch; the rest is drawn and marshalled
             # while the GPU runs
             nxt = (look + take(batch - 1)) if look else []
             nlook = take(1) if nxt else []
             nprepared = self._prepare_batch(nxt, nlook[0] if nlook else None, want_x) if nxt else None
-            th.join()
-            if "e" in res:
-                raise res["e"]
+            results = finish(job)
+            short = len(results) < len(cur)           # the library stopped at stop_at_accepts
+            job = start(nxt, nlook, nprepared) if (overlap and nxt and not short) else None
             stop = False
-            for (L, _p0, _u), (acc, o, x) in zip(cur, res["r"]):
+            for (L, _p0, _u), (acc, o, x) in zip(cur, results):
                 if on_result(L, acc, o, self._full_vec(x) if x is not None else None) is False:
                     stop = True
                     break
-            if stop or len(res["r"]) < len(cur):
+            if stop or short or not nxt:
+                if job is not None:
+                    finish(job)
                 break
-            cur, look, prepared = nxt, nlook, nprepared
+            if job is None:
+                job = start(nxt, nlook, nprepared)
+            cur, look = nxt, nlook
 
     def chain_get_x(self):
         x = np.empty(self.M)

@@ -207,7 +207,7 @@ class HamitonianMC(object):
             eng.run_chain(draws(), self.dt,
                           lambda L, acc, o, xs: record(o[0], o[1], o[2], acc, lambda: xs),
                           stop_at_accepts=ndraws + nsamples, record_from=ndraws,
-                          want_x=self.sample_sink != "none")
+                          want_x=self.sample_sink != "none", overlap=True)
             self._chain_x = state["x"]
             return state["x"]
         while state["i"] < ndraws + nsamples:

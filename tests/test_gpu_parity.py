@@ -587,6 +587,41 @@ def test_speculative_chaining_is_bit_identical(G, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("resident", ["0", "1"])
+def test_run_chain_overlap_keeps_the_stop_contract(G, monkeypatch, resident):
+    """run_chain(overlap=True) starts the next batch before the finished one is handed to Python.
+    With `stop_at_accepts` the library refuses the batch that was submitted ahead once the count is
+    reached, also when it is reached on the last trajectory of a batch: same results, same final
+    state and the same posterior window as without the overlap."""
+    monkeypatch.setenv("GRAVHMC_RESIDENT", resident)
+    p = gold("potential_small.npz")
+    wm = p["wm"]
+    M = wm.size
+    rng = np.random.default_rng(31)
+    trajs = [(int(rng.integers(1, 6)), rng.normal(size=M) * 0.3, float(rng.uniform())) for _ in range(60)]
+    for stop_at in (7, 8, 11):          # batch of 4: inside a batch, at its end, inside the next
+        res = {}
+        for overlap in (False, True):
+            gm = _module_small(G, p)
+            eng = gm._engine
+            eng.set_reg("Damping", 1.0, 0.001, p["shape"], 0.001 * wm)
+            eng.chain_init(0.001 * wm, 0.0 * wm, 0.02 * wm)
+            eng.posterior_window(50)
+            out = []
+
+            def on_result(L, acc, o, x, out=out):
+                out.append((acc, o.copy()))
+                return sum(a_ for a_, _ in out) < stop_at
+
+            eng.run_chain(iter(trajs), 0.02, on_result, stop_at_accepts=stop_at, batch=4, overlap=overlap)
+            res[overlap] = (out, eng.chain_get_x(), eng.posterior_read()["total"])
+            eng.close()
+        (a, ax, an), (b, bx, bn) = res[False], res[True]
+        assert sum(x[0] for x in a) == stop_at and an == bn == stop_at
+        assert len(a) == len(b) and all(x[0] == y[0] and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+        assert np.array_equal(ax, bx)
+
+
 def test_two_contexts_share_a_kernel_instantiation(G):
     """The dynamic-LDS allowance is a property of the kernel, not of a context: a second context
     with a smaller request on the same sweep instantiation (N = 9000 and 10000: both 16-wave teams
