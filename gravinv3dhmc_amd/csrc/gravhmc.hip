@@ -1227,7 +1227,17 @@ int gh_measure_stream_read(gh_ctx *c, int nt, int reps, double *ms_per_pass)
 {
     if (!c || !ms_per_pass || reps < 1) return fail(c, GH_ERR_ARG, "gh_measure_stream_read: bad arguments");
     TRY(need(c, c->have_G && !c->mf, "gh_measure_stream_read: needs a stored kernel matrix"));
-    return gh_debug_stream_read(c, c->cus * 2, 1024, nt, reps, ms_per_pass);
+    // the best of three launch shapes (the rate of a plain read depends on how many wide loads the
+    // chip keeps in flight: 2 x CUs blocks of 256 threads reach ~6.9 TB/s where 2 x CUs of 1024 get 6.5)
+    const int shapes[3][2] = {{c->cus * 2, 256}, {c->cus, 512}, {c->cus * 16, 1024}};
+    double best = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        double ms = 0.0;
+        TRY(gh_debug_stream_read(c, shapes[k][0], shapes[k][1], nt, reps, &ms));
+        if (k == 0 || ms < best) best = ms;
+    }
+    *ms_per_pass = best;
+    return GH_OK;
 }
 
 int gh_debug_stream_read(gh_ctx *c, int blocks, int threads, int nt, int reps, double *ms_out)

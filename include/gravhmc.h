@@ -265,7 +265,7 @@ int gh_profile_read(gh_ctx *ctx, double *sweep_ms, int64_t *sweep_launches,
 /* Attainable streaming-read rate of this device on this context's stored G (the figure SURVEY
  * 8d asks to report next to the nominal 8 TB/s): `reps` timed passes of a read-only kernel over
  * the whole matrix with the sweep's load form (16-byte loads, non-temporal for nt != 0, four
- * independent loads in flight per thread); milliseconds per pass. */
+ * independent loads in flight per thread), best of three launch shapes; milliseconds per pass. */
 int gh_measure_stream_read(gh_ctx *ctx, int nt, int reps, double *ms_per_pass);
 /* Block until everything queued on the context's stream has finished. */
 int gh_synchronize(gh_ctx *ctx);
