@@ -60,6 +60,8 @@ PROTOTYPES = {
     "gh_batch_init": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp]),
     "gh_batch_trajectory": (C.c_int, [_ctx, _dp, C.c_double, C.POINTER(C.c_int), _dp,
                                       C.POINTER(C.c_int), _dp]),
+    "gh_batch_run": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), C.POINTER(_dp), _dp, C.c_double,
+                               C.POINTER(C.c_int), _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gh_batch_get_x": (C.c_int, [_ctx, C.c_int, _dp]),
     "gh_posterior_window": (C.c_int, [_ctx, C.c_int]),
     "gh_posterior_add": (C.c_int, [_ctx]),

@@ -414,6 +414,16 @@ batch_extract_kernel(const double *X, int c, int64_t M, double *out)
     if (j < M) out[j] = X[j * CB + c];
 }
 
+// rows (chain-major, C x M) of the chains in `mask` into their columns of an interleaved array
+__global__ void __launch_bounds__(256)
+batch_scatter_kernel(const double *rows, int64_t M, unsigned mask, double *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * CB) return;
+    const int c = (int)(t & 15);
+    if (mask & (1u << c)) out[t] = rows[(int64_t)c * M + (t >> 4)];
+}
+
 // copy the columns of the accepted chains from the proposal into the current state
 __global__ void __launch_bounds__(256)
 batch_commit_kernel(const double *src, double *dst, int64_t n16, unsigned mask)

@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace ghk;
@@ -1032,6 +1033,7 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     TRY(h2d(c, c->high, high, (size_t)c->M));
     gh_ctx::Resident &r = c->rs;
     r.b_on = false;
+    c->bt.run = gh_ctx::Batch::Run();  // anything gh_batch_run left in flight is discarded
     if (resident_plan(c) &&
         resident_lds_doubles(c->ld, r.cpw, C, r.lds_cols, r.split) * sizeof(double) <= (size_t)r.lds_max) {
         // small problem: the chains take turns inside the resident chain kernel (one launch per
@@ -1057,6 +1059,10 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
     if (!c || !p0s || !L || !us || !accepted || !out5s) return fail(c, GH_ERR_ARG, "gh_batch_trajectory: null pointer");
     gh_ctx::Batch &b = c->bt;
     TRY(need(c, b.ready, "gh_batch_trajectory: call gh_batch_init first"));
+    for (int k = 0; k < b.C; ++k)
+        if (b.run.live && b.run.active[k])
+            return fail(c, GH_ERR_ARG, "gh_batch_trajectory: gh_batch_run left trajectories in flight (drain them with T = 0)");
+    b.run.live = false;
     HIPCHK(c, hipSetDevice(c->device));
     const int C = b.C;
     int Lmax = 0;
@@ -1183,6 +1189,290 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return GH_OK;
+}
+
+int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const double *us, double dt,
+                 int *accepted, double *out5s, double *x_out, int *n_started, int *n_done)
+{
+    if (!c || T < 0 || (T > 0 && (!L || !p0s || !us)) || !accepted || !out5s || ((n_started == nullptr) != (n_done == nullptr)))
+        return fail(c, GH_ERR_ARG, "gh_batch_run: bad arguments");
+    if (T == 0 && !n_done) return fail(c, GH_ERR_ARG, "gh_batch_run: T = 0 (drain) needs n_started / n_done");
+    gh_ctx::Batch &b = c->bt;
+    TRY(need(c, b.ready, "gh_batch_run: call gh_batch_init first"));
+    HIPCHK(c, hipSetDevice(c->device));
+    const int C = b.C;
+    const size_t M = (size_t)c->M;
+    for (int k = 0; k < C * T; ++k)
+        if (L[k] < 1 || !p0s[k]) return fail(c, GH_ERR_ARG, "gh_batch_run: L must be >= 1 and every momentum row given");
+    if (c->rs.b_on && T == 0) {
+        for (int ch = 0; ch < C; ++ch) n_started[ch] = n_done[ch] = 0;  // nothing is ever left in flight there
+        return GH_OK;
+    }
+    if (c->rs.b_on) {
+        // small problem: the chains take turns inside the resident chain kernel, trajectory t of
+        // every chain before trajectory t + 1 of any
+        gh_ctx::Resident &r = c->rs;
+        const int K = C * T;
+        std::vector<int> chain_of((size_t)K), Lk((size_t)K), acc((size_t)K);
+        std::vector<double> pk((size_t)K * M), uk((size_t)K), o5((size_t)K * 5);
+        for (int t = 0; t < T; ++t)
+            for (int ch = 0; ch < C; ++ch) {
+                const int k = t * C + ch, src = ch * T + t;
+                chain_of[k] = ch;
+                Lk[k] = L[src];
+                uk[k] = us[src];
+                memcpy(pk.data() + (size_t)k * M, p0s[src], M * sizeof(double));
+            }
+        ResLaunch q;
+        q.C = C;
+        q.K = K;
+        q.chain_of = chain_of.data();
+        q.L = Lk.data();
+        q.p0s = pk.data();
+        q.us = uk.data();
+        q.dt = dt;
+        q.x_dev = r.bx;
+        q.gcur_dev = r.bg;
+        q.ucur_dev = r.bu;
+        q.have_state = r.b_state ? 1 : 0;
+        q.want_x = x_out != nullptr;
+        int h_run[4] = {0, 0, 0, 0};
+        const int rc = resident_launch(c, q, acc.data(), o5.data(), h_run);
+        if (rc == GH_OK) {
+            r.b_state = true;
+            const int Tout = n_done ? T + 1 : T;
+            for (int t = 0; t < T; ++t)
+                for (int ch = 0; ch < C; ++ch) {
+                    const int k = t * C + ch, dst = ch * Tout + t;
+                    accepted[dst] = acc[k];
+                    memcpy(out5s + (size_t)dst * 5, o5.data() + (size_t)k * 5, 5 * sizeof(double));
+                    if (x_out && acc[k])
+                        HIPCHK(c, hipMemcpyAsync(x_out + (size_t)dst * M, r.xacc + (size_t)k * M, M * sizeof(double),
+                                                 hipMemcpyDeviceToHost, c->stream));
+                }
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int ch = 0; ch < C && n_done; ++ch) n_started[ch] = n_done[ch] = T;
+            return GH_OK;
+        }
+        if (rc != GH_RESIDENT_ABORTED) return rc;
+        std::vector<double> xs((size_t)C * M);
+        TRY(d2h(c, xs.data(), r.bx, xs.size()));
+        r.b_on = false;
+        TRY(batch_init_mfma(c, C, xs.data()));
+    }
+    // ---- fp64-MFMA batch, chains desynchronised: per sweep every chain is in its own phase.
+    // The scheduler's state (b.run) outlives the call when the caller asks for n_started / n_done:
+    // the call then ends as soon as a chain has nothing left to start, the others keep their
+    // trajectory in flight and carry on in the next call -- no sweep is ever spent waiting for
+    // the slowest chain.  Without them every chain's T trajectories are completed.
+    const bool carry = n_done != nullptr;
+    gh_ctx::Batch::Run &run = b.run;
+    const int64_t n16 = c->M * CB, l16 = c->ld * CB;
+    const unsigned all = (C >= 32) ? 0xffffffffu : ((1u << C) - 1u);
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    double *h = b.h;
+    if (!c->copy_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+    }
+    TRY(dalloc(c, &b.stage2, (size_t)c->M * CB));
+    if (!run.live) {
+        // working state <- current state of every chain
+        run = gh_ctx::Batch::Run();
+        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xc, b.Xw[0], n16, all);
+        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, b.GREGw, n16, all);
+        batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, b.Dw, l16, all);
+        batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtc, b.Rtw, l16, all);
+        HIPCHK(c, hipGetLastError());
+        run.live = true;
+    } else if (run.dt != dt) {
+        for (int k = 0; k < C; ++k)
+            if (run.active[k]) return fail(c, GH_ERR_ARG, "gh_batch_run: dt changed while trajectories are in flight");
+    }
+    run.dt = dt;
+    std::vector<int> q_of((size_t)C, 0), done_of((size_t)C, 0);
+    // The momentum of the trajectory a chain starts next waits in one of the chain's two staging
+    // rows (b.stage / b.stage2, used alternately); it is sent on the copy stream while sweeps run.
+    std::vector<char> staged((size_t)C, 0);
+    auto stage_row = [&](int ch, int par) { return (par ? b.stage2 : b.stage) + (size_t)ch * M; };
+    auto upload = [&](int ch, hipStream_t st) -> int {  // list element q_of[ch] -> the chain's free row
+        run.par[ch] ^= 1;
+        HIPCHK(c, hipMemcpyAsync(stage_row(ch, run.par[ch]), p0s[(size_t)ch * T + q_of[ch]],
+                                 M * sizeof(double), hipMemcpyHostToDevice, st));
+        staged[ch] = 1;
+        return GH_OK;
+    };
+    std::vector<int> pending;  // chains whose next momentum is still to be sent ahead
+    for (int ch = 0; ch < C; ++ch) {
+        if (T == 0) break;
+        if (!run.active[ch])
+            TRY(upload(ch, c->stream));
+        else
+            pending.push_back(ch);
+    }
+    auto start_chains = [&](unsigned mask) -> int {
+        // (momenta sent ahead on the copy stream: wait for that stream's last copy)
+        HIPCHK(c, hipEventRecord(c->copy_ev, c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
+        unsigned even = 0, odd = 0;
+        for (int ch = 0; ch < C; ++ch)
+            if (mask & (1u << ch)) {
+                if (!staged[ch]) TRY(upload(ch, c->stream));
+                (run.par[ch] ? odd : even) |= 1u << ch;
+            }
+        if (even) batch_scatter_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.stage, c->M, even, b.Pw[run.pin]);
+        if (odd) batch_scatter_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.stage2, c->M, odd, b.Pw[run.pin]);
+        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xc, b.Xw[run.xi], n16, mask);
+        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, b.GREGw, n16, mask);
+        batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, b.Dw, l16, mask);
+        batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtc, b.Rtw, l16, mask);
+        batch_sumsq_kernel<<<dim3((unsigned)b.n_pp0), dim3(256), 0, c->stream>>>(b.Pw[run.pin], c->M, b.pp0_part);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h + CB * 4 + (size_t)b.n_waves * CB, b.pp0_part,
+                                 sizeof(double) * (size_t)b.n_pp0 * CB, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int ch = 0; ch < C; ++ch)
+            if (mask & (1u << ch)) {
+                double s = 0.0;
+                for (int w = 0; w < b.n_pp0; ++w) s += h[CB * 4 + (size_t)(b.n_waves + w) * CB + ch];
+                run.pp0[ch] = s;
+                const size_t slot = (size_t)ch * T + q_of[ch];
+                run.L_cur[ch] = L[slot];
+                run.u_cur[ch] = us[slot];
+                run.s_of[ch] = 0;
+                run.active[ch] = true;
+                q_of[ch] += 1;
+                staged[ch] = 0;
+                // the one after goes ahead once the next sweep has been queued (the staging copy
+                // blocks this thread, not the GPU)
+                if (q_of[ch] < T) pending.push_back(ch);
+            }
+        return GH_OK;
+    };
+    for (;;) {
+        unsigned starters = 0;
+        bool starved = false, any_active = false;
+        for (int k = 0; k < C; ++k) {
+            if (run.active[k]) {
+                any_active = true;
+            } else if (q_of[k] < T) {
+                starters |= 1u << k;
+                any_active = true;
+            } else {
+                starved = true;
+            }
+        }
+        if (carry ? (T == 0 ? !any_active : starved) : !any_active) break;
+        if (starters) TRY(start_chains(starters));
+        BatchAdjArgs a{};
+        a.Gb = b.Gb;
+        a.G = c->G;
+        a.ld = c->ld;
+        a.M = c->M;
+        a.np = (int)(c->ld / 16);
+        a.Rt = b.Rtw;
+        a.GREG = b.GREGw;
+        a.X_in = b.Xw[run.xi];
+        a.P_in = b.Pw[run.pin];
+        a.X_out = b.Xw[run.xi ^ 1];
+        a.P_out = b.Pw[run.pin ^ 1];
+        a.low = c->low;
+        a.high = c->high;
+        a.G_out = nullptr;
+        a.pp_part = b.pp_part;
+        a.dt = dt;
+        a.n_waves = b.n_waves;
+        bool any_upd = false;
+        unsigned fin = 0;
+        for (int k = 0; k < CB; ++k) {
+            a.phase[k] = PH_IDLE;
+            a.cu[k] = dt;
+            a.cp[k] = dt * 0.5;
+            if (k < C && run.active[k]) {
+                if (run.s_of[k] < run.L_cur[k]) {
+                    a.phase[k] = PH_UPD;
+                    a.cu[k] = (run.s_of[k] == 0) ? dt * 0.5 : dt;
+                    any_upd = true;
+                } else {
+                    a.phase[k] = PH_PFIN;
+                    fin |= 1u << k;
+                }
+            }
+        }
+        bool timed;
+        TRY(batch_time_begin(c, timed));
+        batch_adjoint_kernel<<<dim3((unsigned)(b.n_waves / 4)), dim3(256), 0, c->stream>>>(a);
+        TRY(batch_time_end(c, timed));
+        HIPCHK(c, hipGetLastError());
+        if (any_upd) TRY(batch_evaluate(c, b.Xw[run.xi ^ 1], b.Dw, b.GREGw, b.Rtw));
+        for (int ch : pending) TRY(upload(ch, c->copy_stream));
+        pending.clear();
+        run.xi ^= 1;
+        run.pin ^= 1;
+        for (int k = 0; k < C; ++k)
+            if (run.active[k]) run.s_of[k] += 1;
+        if (!fin) continue;
+        // the chains that took their final half step in this sweep: Metropolis test
+        HIPCHK(c, hipMemcpyAsync(h, b.scal, sizeof(double) * CB * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h + CB * 4, b.pp_part, sizeof(double) * (size_t)b.n_waves * CB,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        unsigned mask = 0;
+        // result slots per chain: T, plus one in carry-over mode for the trajectory that came in flight
+        const int Tout = carry ? T + 1 : T;
+        for (int k = 0; k < C; ++k) {
+            if (!(fin & (1u << k))) continue;
+            const size_t slot = (size_t)k * Tout + done_of[k];
+            double pp1 = 0.0;
+            for (int w = 0; w < b.n_waves; ++w) pp1 += h[CB * 4 + (size_t)w * CB + k];
+            const double Unew[3] = {h[4 * k + 2], h[4 * k + 0], h[4 * k + 1]};
+            const double Hcur = 0.5 * run.pp0[k] + b.U[k][0];
+            const double Hnew = 0.5 * pp1 + Unew[0];
+            const bool acc = (Hnew < Hcur) || (run.u_cur[k] < std::exp(-(Hnew - Hcur)));
+            if (acc) {
+                mask |= 1u << k;
+                b.U[k][0] = Unew[0];
+                b.U[k][1] = Unew[1];
+                b.U[k][2] = Unew[2];
+            }
+            accepted[slot] = acc ? 1 : 0;
+            out5s[5 * slot + 0] = b.U[k][0];
+            out5s[5 * slot + 1] = b.U[k][1];
+            out5s[5 * slot + 2] = b.U[k][2];
+            out5s[5 * slot + 3] = Hcur;
+            out5s[5 * slot + 4] = Hnew;
+        }
+        if (mask) {
+            batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xw[run.xi], b.Xc, n16, mask);
+            batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGw, b.GREGc, n16, mask);
+            batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dw, b.Dc, l16, mask);
+            batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtw, b.Rtc, l16, mask);
+            HIPCHK(c, hipGetLastError());
+            if (x_out)
+                for (int k = 0; k < C; ++k)
+                    if (mask & (1u << k)) {
+                        batch_extract_kernel<<<blocks(c->M), dim3(256), 0, c->stream>>>(b.Xc, k, c->M, c->tmpM);
+                        TRY(d2h(c, x_out + ((size_t)k * Tout + done_of[k]) * M, c->tmpM, M));
+                    }
+        }
+        for (int k = 0; k < C; ++k)
+            if (fin & (1u << k)) {
+                run.active[k] = false;
+                done_of[k] += 1;
+            }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    bool any_active = false;
+    for (int k = 0; k < C; ++k) {
+        if (n_done) {
+            n_started[k] = q_of[k];
+            n_done[k] = done_of[k];
+        }
+        any_active = any_active || run.active[k];
+    }
+    if (!any_active) run.live = false;  // (the working buffers are rebuilt from the current state next time)
     return GH_OK;
 }
 

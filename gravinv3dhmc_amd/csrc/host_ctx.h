@@ -125,6 +125,7 @@ struct gh_ctx {
         double *Rtw = nullptr, *GREGw = nullptr, *Dw = nullptr, *scal = nullptr;
         double *slab = nullptr, *regpart = nullptr, *pp_part = nullptr, *pp0_part = nullptr;
         double *stage = nullptr;  // C x M rows as the host passes them
+        double *stage2 = nullptr; // second set of rows (gh_batch_run: next trajectories' momenta sent ahead)
         double *Gb = nullptr;     // second copy of G in MFMA operand order (adjoint), if HBM allows
         double *h = nullptr;      // pinned
         int n_colblocks = 0, n_regblocks = 0, n_waves = 0, n_pp0 = 0;
@@ -132,6 +133,15 @@ struct gh_ctx {
         double U[CB][3];
         bool ready = false;
         int64_t sweeps = 0;
+        // scheduler of gh_batch_run: trajectories in flight survive the call (carry-over mode)
+        struct Run {
+            bool live = false;
+            bool active[CB] = {};
+            int s_of[CB] = {}, L_cur[CB] = {}, par[CB] = {};
+            double u_cur[CB] = {}, pp0[CB] = {};
+            int xi = 0, pin = 0;
+            double dt = 0.0;
+        } run;
     } bt;
 
     // resident chain kernel (resident.hip.h): G held in LDS across a whole batch of trajectories

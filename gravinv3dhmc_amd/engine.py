@@ -367,6 +367,36 @@ class Engine(object):
                                                 ptr(out5)))
         return [bool(a) for a in acc], out5
 
+    def batch_run(self, p0s, dt, Ls, us, want_x=False, carry=False):
+        """Up to T further trajectories of every chain, the chains desynchronised (gh_batch_run).
+        p0s: (C, T, M) array, or C lists of T momentum vectors (not copied); Ls (C, T), us (C, T):
+        the trajectories each chain has not started yet.  Returns accepted (C, S) bool, out5
+        (C, S, 5), xs (C, S, M) or None -- per chain in order of completion, S = T slots, T + 1
+        with carry -- and, with carry=True, (n_started, n_done): the call then ends as soon as a chain has nothing left to
+        start, the others keep their trajectory in flight for the next call (T = 0, i.e. C empty
+        lists, drains them)."""
+        rows = [[f64(p) for p in chain] for chain in p0s]
+        Cn = len(rows)
+        T = len(rows[0]) if Cn else 0
+        if any(len(r) != T for r in rows) or any(p.shape != (self.M,) for r in rows for p in r):
+            raise ValueError("p0s must hold the same number of M-vectors for every chain")
+        To = T + 1 if carry else T            # result slots per chain
+        Ls = np.ascontiguousarray(Ls, dtype=np.int32).reshape(Cn, T)
+        us = np.ascontiguousarray(us, dtype=np.float64).reshape(Cn, T)
+        ptrs = (_lib._dp * max(1, Cn * T))(*[ptr(p) for r in rows for p in r])
+        acc = np.zeros((Cn, To), dtype=np.int32)
+        out5 = np.zeros((Cn, To, 5))
+        xs = np.empty((Cn, To, self.M)) if want_x else None
+        ns = np.zeros(Cn, dtype=np.int32)
+        nd = np.zeros(Cn, dtype=np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        self._chk(self._lib.gh_batch_run(self._h, int(T), ip(Ls) if T else None, ptrs if T else None,
+                                         ptr(us) if T else None, float(dt), ip(acc), ptr(out5), ptr(xs),
+                                         ip(ns) if carry else None, ip(nd) if carry else None))
+        if carry:
+            return acc.astype(bool), out5, xs, ns, nd
+        return acc.astype(bool), out5, xs
+
     def batch_get_x(self, chain):
         x = np.empty(self.M)
         self._chk(self._lib.gh_batch_get_x(self._h, int(chain), ptr(x)))

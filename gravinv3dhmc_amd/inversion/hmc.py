@@ -286,9 +286,11 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     hmc.py:367-369).  Here chain c is the chain the reference's rank first_rank + c would run --
     its own legacy RandomState(seed + rank) drawn in the reference's order (L, momentum,
     Metropolis variate), its own folder save_folder + str(rank), the same console lines -- but
-    every leapfrog step of all chains shares two sweeps of G on the fp64 MFMA path
-    (gh_batch_trajectory).  Chains that reach ndraws + nsamples accepted samples keep running
-    (unrecorded) until the slowest one is done.  'mandatory' constraint only."""
+    every leapfrog step of all chains shares two sweeps of G on the fp64 MFMA path, the chains
+    running desynchronised (gh_batch_run: none waits for the longest trajectory of a round); on
+    problems small enough they take turns inside the resident chain kernel instead.  Chains that
+    reach ndraws + nsamples accepted samples keep running (unrecorded) until the slowest one is
+    done.  'mandatory' constraint only."""
     if constraint != 'mandatory':
         raise ValueError("HMCSampleBatch supports the 'mandatory' boundary constraint only")
     eng = model._engine
@@ -316,46 +318,69 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=n_chains + 1)
 
-    def draw_round():
-        """(L, momentum, Metropolis variate) of every chain, each from its own stream in the
-        reference's order; the streams are independent, so they are drawn concurrently."""
-        def one(r):
-            L = r.randint(Lrange[0], Lrange[1] + 1)
-            return L, r.randn(M) * Sigma, r.rand()
-        res = list(pool.map(one, rs))
-        return [a for a, _, _ in res], [b for _, b, _ in res], [c for _, _, c in res]
+    # Trajectories offered per chain and library call.  The chains run desynchronised
+    # (gh_batch_run, carry-over mode): a call ends when the first chain has used up its offer, the
+    # others keep their trajectory in flight; what a chain has not started is offered again next
+    # time together with fresh draws.  Bounded by the momenta held on the host.
+    import collections
+    T = int(max(2, min(8, (256 << 20) // (8 * M * n_chains))))
+    pending = [collections.deque() for _ in range(n_chains)]    # drawn, not started yet
+    inflight = [collections.deque() for _ in range(n_chains)]   # started, result not reported yet
 
-    nxt = draw_round()
+    def top_up():
+        """Fill every chain's queue up to 2 T draws (L, momentum, Metropolis variate), each chain
+        from its own stream in the reference's order; the streams are independent, so they are
+        drawn concurrently."""
+        def one(c):
+            r = rs[c]
+            while len(pending[c]) < 2 * T:
+                L = r.randint(Lrange[0], Lrange[1] + 1)
+                pending[c].append((L, r.randn(M) * Sigma, r.rand()))
+        list(pool.map(one, range(n_chains)))
+
+    def offer():
+        cur = [[pending[c][t] for t in range(T)] for c in range(n_chains)]
+        return ([[tr[1] for tr in ch] for ch in cur], [[tr[0] for tr in ch] for ch in cur],
+                [[tr[2] for tr in ch] for ch in cur])
+
+    want_x = sample_sink != "none"
+    top_up()
     while min(acc_n) < target:
-        Ls, p0s, us = nxt
-        # the next round is drawn on the host while the GPU runs this one
-        fut = pool.submit(eng.batch_trajectory, np.stack(p0s), delta, Ls, us)
-        nxt = draw_round()
-        accepted, out5 = fut.result()
+        p0s, Ls, us = offer()
+        # more is drawn on the host while the GPU runs (appended behind what has been offered)
+        fut = pool.submit(eng.batch_run, p0s, delta, Ls, us, want_x, True)
+        top_up()
+        accepted, out5, xs, n_started, n_done = fut.result()
         for c in range(n_chains):
-            if acc_n[c] >= target:
-                continue
-            U, U_data, U_model = out5[c][0], out5[c][1], out5[c][2]
-            Udn, Umn = U_data / N, U_model / M
-            Un = Udn + alpha * Umn
-            if accepted[c]:
-                if acc_n[c] >= ndraws:
-                    with open(folders[c] + "/misfit.dat", "a") as f:
-                        np.savetxt(f, np.array([[U, U_data, U_model, Un, Udn, Umn, alpha]]), fmt='%.8f',
-                                   delimiter=' ')
-                    if sample_sink != "none":
-                        m = WmInv @ eng.batch_get_x(c)
-                        if sample_sink == "text":
-                            with open(folders[c] + "/model.dat", "a") as f:
-                                np.savetxt(f, m[None, :], fmt='%.8f', delimiter=' ')
-                        else:
-                            with open(folders[c] + "/model.bin", "ab") as f:
-                                np.ascontiguousarray(m).tofile(f)
-                acc_n[c] += 1
-            tot_n[c] += 1
-            print("chain {}: {:.2%}, misfit(total, data, alpha, model)=({:.7f},{:.7f},{:.2f},{:.7f}) "
-                  "-- accept ratio {:.2%}\n".format(ranks[c], acc_n[c] / target, Un, Udn, alpha, Umn,
-                                                    acc_n[c] / tot_n[c]))
+            for _ in range(int(n_started[c])):
+                inflight[c].append(pending[c].popleft())
+        for i in range(int(max(n_done))):
+            for c in range(n_chains):
+                if i >= n_done[c]:
+                    continue
+                inflight[c].popleft()
+                if acc_n[c] >= target:
+                    continue
+                U, U_data, U_model = out5[c, i, 0], out5[c, i, 1], out5[c, i, 2]
+                Udn, Umn = U_data / N, U_model / M
+                Un = Udn + alpha * Umn
+                if accepted[c, i]:
+                    if acc_n[c] >= ndraws:
+                        with open(folders[c] + "/misfit.dat", "ab") as f:
+                            write_rows_fixed8(f, np.array([[U, U_data, U_model, Un, Udn, Umn, alpha]]))
+                        if want_x:
+                            m = WmInv @ xs[c, i]
+                            if sample_sink == "text":
+                                with open(folders[c] + "/model.dat", "ab") as f:
+                                    write_rows_fixed8(f, m[None, :])
+                            else:
+                                with open(folders[c] + "/model.bin", "ab") as f:
+                                    np.ascontiguousarray(m).tofile(f)
+                    acc_n[c] += 1
+                tot_n[c] += 1
+                print("chain {}: {:.2%}, misfit(total, data, alpha, model)=({:.7f},{:.7f},{:.2f},{:.7f}) "
+                      "-- accept ratio {:.2%}\n".format(ranks[c], acc_n[c] / target, Un, Udn, alpha, Umn,
+                                                        acc_n[c] / tot_n[c]))
         sys.stdout.flush()
     pool.shutdown(wait=False)
     return acc_n, tot_n

@@ -200,6 +200,28 @@ int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state 
 int gh_batch_init(gh_ctx *ctx, int C, const double *x0s, const double *low, const double *high);
 int gh_batch_trajectory(gh_ctx *ctx, const double *p0s, double dt, const int *L, const double *us,
                         int *accepted /* C */, double *out5s /* C x 5, as gh_chain_trajectory */);
+/* Up to T further trajectories of every chain in one call; arrays are chain-major: L[c*T + t],
+ * us[c*T + t] and the momentum p0_rows[c*T + t] (pointer to M doubles: the rows need not be
+ * contiguous) are the trajectories chain c has not started yet, in order.
+ * The chains do not wait for each other: a chain that has finished a trajectory (its L steps and
+ * the final half momentum step) is decided and starts its next one in the very next sweep while
+ * the others are in the middle of theirs, so every sweep of G carries a step of every chain that
+ * has work.  (Rounds of gh_batch_trajectory leave a chain idle from its own L to the longest L of
+ * the round: with the reference's Lrange [5,20] and 16 chains 38 % of the sweeps' capacity.)  Each
+ * chain computes exactly what it computes through gh_batch_trajectory.
+ * Results are reported per chain in order of completion: accepted[c*S + i], out5s[(c*S + i)*5 ..]
+ * and, if x_out != NULL, the state after an ACCEPTED trajectory at x_out[(c*S + i)*M ..], for the
+ * i-th trajectory chain c COMPLETED in this call; S = T result slots per chain, S = T + 1 in
+ * carry-over mode (the trajectory that came in flight plus up to T new ones).
+ * n_started == n_done == NULL: all T trajectories of every chain are run to completion.
+ * Otherwise (carry-over mode) the call ends as soon as some chain has nothing left to start; the
+ * other chains keep their trajectory in flight and continue it in the next call (same dt), where
+ * its result is the first that chain reports.  n_started[c] = how many of this call's T chain c
+ * has started (pass the rest again, followed by new ones), n_done[c] = completions reported.
+ * T = 0 in that mode drains: the trajectories in flight are completed (at most one result per
+ * chain).  gh_batch_init discards anything in flight. */
+int gh_batch_run(gh_ctx *ctx, int T, const int *L, const double *const *p0_rows, const double *us,
+                 double dt, int *accepted, double *out5s, double *x_out, int *n_started, int *n_done);
 int gh_batch_get_x(gh_ctx *ctx, int chain, double *x /* M */);
 
 /* Posterior statistics without text I/O.  The reference appends every accepted

@@ -1069,6 +1069,120 @@ def test_batched_chains_match_single_chain_engines(G, monkeypatch, case, residen
         e.close()
 
 
+@pytest.mark.parametrize("case,resident", [("small_tv", "0"), ("small_tv", "1"), ("random_damping_big", "1")])
+def test_batch_run_desynchronised_chains_match_lockstep_rounds(G, monkeypatch, case, resident):
+    """gh_batch_run: T trajectories per chain in one call, every chain starting its next trajectory
+    in the sweep after it finished the previous one (the others are in the middle of theirs).  Each
+    chain must compute what it computes in lock-step rounds of gh_batch_trajectory, including the
+    states reported after accepted trajectories."""
+    monkeypatch.setenv("GRAVHMC_RESIDENT", resident)
+    rng = np.random.default_rng(17)
+    if case == "small_tv":
+        p = gold("potential_small.npz")
+        A, dobs, shape, reg, beta = np.asarray(p["Aw"]) * p["wm"][None, :], p["dobs"], p["shape"], "TV", 0.001
+        C, T, dt, sig, hi = 5, 4, 0.02, 0.3, 0.02
+    else:
+        N, M = 5003, 1234
+        A = np.asfortranarray(rng.normal(size=(N, M)))
+        dobs, shape, reg, beta = rng.normal(size=N) * 20, (1, 1, M), "Damping", 0.01
+        C, T, dt, sig, hi = 3, 3, 0.004, 0.02, 0.5
+    N, M = A.shape
+
+    def make():
+        e = G.Engine(N, M)
+        e.upload_G(A)
+        w = e.weight(0.5)
+        e.set_data(dobs)
+        e.set_reg(reg, 1.0, beta, shape, 0.001 * w)
+        return e, w
+
+    Ls = rng.integers(1, 9, size=(C, T))
+    ea, wm = make()
+    p0s = rng.normal(size=(C, T, M)) * sig
+    us = rng.uniform(size=(C, T))
+    low, high = 0.0 * wm, hi * wm
+    x0s = np.stack([(0.001 + 0.002 * c) * wm for c in range(C)])
+    ea.batch_init(x0s, low, high)
+    acc_a, out_a, xs_a = ea.batch_run(p0s, dt, Ls, us, want_x=True)
+    eb, _ = make()
+    eb.batch_init(x0s, low, high)
+    n_acc = 0
+    for t in range(T):
+        acc, out5 = eb.batch_trajectory(p0s[:, t], dt, Ls[:, t], us[:, t])
+        for c in range(C):
+            assert bool(acc[c]) == bool(acc_a[c, t]), (case, c, t)
+            assert relmax(out_a[c, t], out5[c]) < 1e-10
+            if acc[c]:
+                assert relmax(xs_a[c, t], eb.batch_get_x(c)) < 1e-10
+                n_acc += 1
+    assert 0 < n_acc
+    for c in range(C):
+        assert relmax(ea.batch_get_x(c), eb.batch_get_x(c)) < 1e-10
+    ea.close()
+    eb.close()
+
+
+def test_batch_run_carry_over_continues_trajectories_across_calls(G, monkeypatch):
+    """gh_batch_run in carry-over mode: a call ends when the first chain has used up its offer, the
+    others keep their trajectory in flight and finish it in a later call.  Feeding the chains call
+    by call (re-offering what was not started) must give every chain exactly the results of lock-step
+    rounds, in order; T = 0 drains; the lock-step call refuses while something is in flight."""
+    monkeypatch.setenv("GRAVHMC_RESIDENT", "0")
+    rng = np.random.default_rng(23)
+    p = gold("potential_small.npz")
+    A, dobs, shape = np.asarray(p["Aw"]) * p["wm"][None, :], p["dobs"], p["shape"]
+    N, M = A.shape
+    C, n_traj, T, dt = 5, 14, 3, 0.02
+
+    def make():
+        e = G.Engine(N, M)
+        e.upload_G(A)
+        w = e.weight(0.5)
+        e.set_data(dobs)
+        e.set_reg("TV", 1.0, 0.001, shape, 0.001 * w)
+        return e, w
+
+    ea, wm = make()
+    Ls = rng.integers(1, 9, size=(C, n_traj))
+    p0s = rng.normal(size=(C, n_traj, M)) * 0.3
+    us = rng.uniform(size=(C, n_traj))
+    x0s = np.stack([(0.001 + 0.002 * c) * wm for c in range(C)])
+    ea.batch_init(x0s, 0.0 * wm, 0.02 * wm)
+    eb, _ = make()
+    eb.batch_init(x0s, 0.0 * wm, 0.02 * wm)
+    ref = [eb.batch_trajectory(p0s[:, t], dt, Ls[:, t], us[:, t]) for t in range(n_traj)]
+    started = [0] * C
+    got = [[] for _ in range(C)]
+    calls = 0
+    in_flight_seen = False
+    while max(started) + T <= n_traj:            # while every chain can still be offered T trajectories
+        off = [list(range(started[c], started[c] + T)) for c in range(C)]
+        acc, out5, xs, ns, nd = ea.batch_run([[p0s[c, t] for t in off[c]] for c in range(C)], dt,
+                                             [[Ls[c, t] for t in off[c]] for c in range(C)],
+                                             [[us[c, t] for t in off[c]] for c in range(C)], want_x=True, carry=True)
+        calls += 1
+        for c in range(C):
+            started[c] += int(ns[c])
+            for i in range(int(nd[c])):
+                got[c].append((bool(acc[c, i]), out5[c, i].copy(), xs[c, i].copy()))
+        in_flight_seen = in_flight_seen or any(started[c] > len(got[c]) for c in range(C))
+    assert calls >= 2 and in_flight_seen
+    if any(started[c] > len(got[c]) for c in range(C)):
+        with pytest.raises(ValueError):
+            ea.batch_trajectory(p0s[:, 0], dt, Ls[:, 0], us[:, 0])
+    acc, out5, xs, ns, nd = ea.batch_run([[] for _ in range(C)], dt, np.zeros((C, 0)), np.zeros((C, 0)),
+                                         want_x=True, carry=True)
+    for c in range(C):
+        assert ns[c] == 0 and nd[c] <= 1
+        if nd[c]:
+            got[c].append((bool(acc[c, 0]), out5[c, 0].copy(), xs[c, 0].copy()))
+        assert len(got[c]) == started[c] >= T
+        for t, (a_, o_, x_) in enumerate(got[c]):
+            assert a_ == bool(ref[t][0][c]) and relmax(o_, ref[t][1][c]) < 1e-10, (c, t)
+    ea.close()
+    eb.close()
+
+
 def test_hmcsample_batch_reproduces_reference_chains(G, tmp_path, capsys):
     """HMCSampleBatch: chains 0..2 of one MFMA batch; chain 0 must print the reference's own
     chain-0 lines (chain_small fixtures), every chain must equal a separate HMCSample(myrank=r)."""
