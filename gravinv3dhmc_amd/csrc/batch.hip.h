@@ -25,7 +25,11 @@ namespace ghk {
 using d4 = double __attribute__((ext_vector_type(4)));
 constexpr int CB = 16;  // chain slots of a batch (MFMA N dimension)
 
-enum : int { PH_IDLE = 0, PH_UPD = 1, PH_PFIN = 2, PH_GOUT = 3 };
+// PH_PFIN_SPEC: the final half momentum step of a trajectory AND, from the same gradient at the
+// proposal, the first leapfrog step of the chain's next trajectory with its momentum Pn (valid if
+// the proposal is accepted; a rejected one simply discards it): a trajectory then costs L sweep
+// pairs instead of L + 1.
+enum : int { PH_IDLE = 0, PH_UPD = 1, PH_PFIN = 2, PH_GOUT = 3, PH_PFIN_SPEC = 4 };
 
 struct BatchAdjArgs {
     const double *Gb;       // MFMA-operand-ordered copy of G (see batch_relayout_kernel) or nullptr
@@ -35,6 +39,7 @@ struct BatchAdjArgs {
     const double *Rt;       // np x 2 x 4 x 16 x 2
     const double *GREG;     // M x 16 (alpha * grad R per chain)
     const double *X_in, *P_in;
+    const double *Pn;       // M x 16 momenta of the next trajectories (PH_PFIN_SPEC) or nullptr
     double *X_out, *P_out;  // M x 16
     const double *low, *high;  // M
     double *G_out;          // M x 16 gradient (PH_GOUT) or nullptr
@@ -145,6 +150,21 @@ __global__ void __launch_bounds__(256) batch_adjoint_kernel(BatchAdjArgs a)
                     pp += pf * pf;
                     a.P_out[idx] = pf;
                     a.X_out[idx] = a.X_in[idx];
+                } else if (ph == PH_PFIN_SPEC) {
+                    const double pf = a.P_in[idx] - a.cp[c] * g;
+                    pp += pf * pf;
+                    double pj = a.Pn[idx] - a.cu[c] * g;
+                    double xj = a.X_in[idx] + a.dt * pj;
+                    const double hi = a.high[j], lw = a.low[j];
+                    if (xj > hi) {
+                        xj = hi;
+                        pj = -pj;
+                    } else if (xj < lw) {
+                        xj = lw;
+                        pj = -pj;
+                    }
+                    a.P_out[idx] = pj;
+                    a.X_out[idx] = xj;
                 } else {
                     a.P_out[idx] = a.P_in[idx];
                     a.X_out[idx] = a.X_in[idx];
@@ -156,7 +176,7 @@ __global__ void __launch_bounds__(256) batch_adjoint_kernel(BatchAdjArgs a)
     pp += __shfl_xor(pp, 16, WAVE);
     pp += __shfl_xor(pp, 32, WAVE);
     // only chains that took their final half step in THIS sweep write: the slot keeps that value
-    if (a.pp_part && lane < 16 && wave < a.n_waves && a.phase[lane] == PH_PFIN)
+    if (a.pp_part && lane < 16 && wave < a.n_waves && (a.phase[lane] == PH_PFIN || a.phase[lane] == PH_PFIN_SPEC))
         a.pp_part[(int64_t)wave * CB + lane] = pp;
 }
 

@@ -1267,6 +1267,7 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
     // trajectory in flight and carry on in the next call -- no sweep is ever spent waiting for
     // the slowest chain.  Without them every chain's T trajectories are completed.
     const bool carry = n_done != nullptr;
+    const bool use_spec = env_int("GRAVHMC_BATCH_SPEC", 1) != 0;
     gh_ctx::Batch::Run &run = b.run;
     const int64_t n16 = c->M * CB, l16 = c->ld * CB;
     const unsigned all = (C >= 32) ? 0xffffffffu : ((1u << C) - 1u);
@@ -1276,14 +1277,23 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
     }
-    TRY(dalloc(c, &b.stage2, (size_t)c->M * CB));
+    TRY(dalloc(c, &b.stage2, (size_t)n16));
+    TRY(dalloc(c, &b.GREGw2, (size_t)n16));
+    TRY(dalloc(c, &b.Dw2, (size_t)l16));
+    TRY(dalloc(c, &b.Rtw2, (size_t)l16));
+    TRY(dalloc(c, &b.scal2, CB * 4));
+    TRY(dalloc(c, &b.Pn, (size_t)n16));
+    TRY(dalloc(c, &b.pn0_part, (size_t)b.n_pp0 * CB));
+    // two working sets: a sweep reads set run.ws, the evaluation behind it writes the other one
+    double *GREGs[2] = {b.GREGw, b.GREGw2}, *Ds[2] = {b.Dw, b.Dw2}, *Rts[2] = {b.Rtw, b.Rtw2},
+           *scals[2] = {b.scal, b.scal2};
     if (!run.live) {
         // working state <- current state of every chain
         run = gh_ctx::Batch::Run();
         batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xc, b.Xw[0], n16, all);
-        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, b.GREGw, n16, all);
-        batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, b.Dw, l16, all);
-        batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtc, b.Rtw, l16, all);
+        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, GREGs[0], n16, all);
+        batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, Ds[0], l16, all);
+        batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtc, Rts[0], l16, all);
         HIPCHK(c, hipGetLastError());
         run.live = true;
     } else if (run.dt != dt) {
@@ -1303,6 +1313,19 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         staged[ch] = 1;
         return GH_OK;
     };
+    // staged rows of the chains in `mask` -> their columns of the interleaved array dst
+    auto scatter_staged = [&](unsigned mask, double *dst) {
+        unsigned even = 0, odd = 0;
+        for (int ch = 0; ch < C; ++ch)
+            if (mask & (1u << ch)) (run.par[ch] ? odd : even) |= 1u << ch;
+        if (even) batch_scatter_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.stage, c->M, even, dst);
+        if (odd) batch_scatter_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.stage2, c->M, odd, dst);
+    };
+    auto wait_copies = [&]() -> int {  // (momenta sent ahead on the copy stream: wait for its last copy)
+        HIPCHK(c, hipEventRecord(c->copy_ev, c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
+        return GH_OK;
+    };
     std::vector<int> pending;  // chains whose next momentum is still to be sent ahead
     for (int ch = 0; ch < C; ++ch) {
         if (T == 0) break;
@@ -1311,22 +1334,30 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         else
             pending.push_back(ch);
     }
+    // a chain takes the trajectory at the head of its list: bookkeeping shared by both kinds of start
+    auto take_next = [&](int ch, double pp0_val, int s_first) {
+        const size_t slot = (size_t)ch * T + q_of[ch];
+        run.pp0[ch] = pp0_val;
+        run.L_cur[ch] = L[slot];
+        run.u_cur[ch] = us[slot];
+        run.s_of[ch] = s_first;
+        run.active[ch] = true;
+        q_of[ch] += 1;
+        staged[ch] = 0;
+        // the one after goes ahead once the next sweep has been queued (the staging copy blocks
+        // this thread, not the GPU)
+        if (q_of[ch] < T) pending.push_back(ch);
+    };
+    // working state <- current state, momenta of the chains in `mask` <- their next trajectory
     auto start_chains = [&](unsigned mask) -> int {
-        // (momenta sent ahead on the copy stream: wait for that stream's last copy)
-        HIPCHK(c, hipEventRecord(c->copy_ev, c->copy_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
-        unsigned even = 0, odd = 0;
+        TRY(wait_copies());
         for (int ch = 0; ch < C; ++ch)
-            if (mask & (1u << ch)) {
-                if (!staged[ch]) TRY(upload(ch, c->stream));
-                (run.par[ch] ? odd : even) |= 1u << ch;
-            }
-        if (even) batch_scatter_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.stage, c->M, even, b.Pw[run.pin]);
-        if (odd) batch_scatter_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.stage2, c->M, odd, b.Pw[run.pin]);
+            if ((mask & (1u << ch)) && !staged[ch]) TRY(upload(ch, c->stream));
+        scatter_staged(mask, b.Pw[run.pin]);
         batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xc, b.Xw[run.xi], n16, mask);
-        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, b.GREGw, n16, mask);
-        batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, b.Dw, l16, mask);
-        batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtc, b.Rtw, l16, mask);
+        batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, GREGs[run.ws], n16, mask);
+        batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, Ds[run.ws], l16, mask);
+        batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtc, Rts[run.ws], l16, mask);
         batch_sumsq_kernel<<<dim3((unsigned)b.n_pp0), dim3(256), 0, c->stream>>>(b.Pw[run.pin], c->M, b.pp0_part);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(h + CB * 4 + (size_t)b.n_waves * CB, b.pp0_part,
@@ -1336,20 +1367,11 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
             if (mask & (1u << ch)) {
                 double s = 0.0;
                 for (int w = 0; w < b.n_pp0; ++w) s += h[CB * 4 + (size_t)(b.n_waves + w) * CB + ch];
-                run.pp0[ch] = s;
-                const size_t slot = (size_t)ch * T + q_of[ch];
-                run.L_cur[ch] = L[slot];
-                run.u_cur[ch] = us[slot];
-                run.s_of[ch] = 0;
-                run.active[ch] = true;
-                q_of[ch] += 1;
-                staged[ch] = 0;
-                // the one after goes ahead once the next sweep has been queued (the staging copy
-                // blocks this thread, not the GPU)
-                if (q_of[ch] < T) pending.push_back(ch);
+                take_next(ch, s, 0);
             }
         return GH_OK;
     };
+    const size_t h_pn0 = CB * 4 + (size_t)(b.n_waves + b.n_pp0) * CB;  // (b.h is sized for it below)
     for (;;) {
         unsigned starters = 0;
         bool starved = false, any_active = false;
@@ -1365,16 +1387,18 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         }
         if (carry ? (T == 0 ? !any_active : starved) : !any_active) break;
         if (starters) TRY(start_chains(starters));
+        const int rs = run.ws, wset = rs ^ 1;
         BatchAdjArgs a{};
         a.Gb = b.Gb;
         a.G = c->G;
         a.ld = c->ld;
         a.M = c->M;
         a.np = (int)(c->ld / 16);
-        a.Rt = b.Rtw;
-        a.GREG = b.GREGw;
+        a.Rt = Rts[rs];
+        a.GREG = GREGs[rs];
         a.X_in = b.Xw[run.xi];
         a.P_in = b.Pw[run.pin];
+        a.Pn = b.Pn;
         a.X_out = b.Xw[run.xi ^ 1];
         a.P_out = b.Pw[run.pin ^ 1];
         a.low = c->low;
@@ -1384,7 +1408,7 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         a.dt = dt;
         a.n_waves = b.n_waves;
         bool any_upd = false;
-        unsigned fin = 0;
+        unsigned fin = 0, spec = 0;
         for (int k = 0; k < CB; ++k) {
             a.phase[k] = PH_IDLE;
             a.cu[k] = dt;
@@ -1395,28 +1419,51 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
                     a.cu[k] = (run.s_of[k] == 0) ? dt * 0.5 : dt;
                     any_upd = true;
                 } else {
-                    a.phase[k] = PH_PFIN;
                     fin |= 1u << k;
+                    // the chain's next trajectory is known: its first step rides on this sweep
+                    if (use_spec && q_of[k] < T) {
+                        a.phase[k] = PH_PFIN_SPEC;
+                        a.cu[k] = dt * 0.5;
+                        spec |= 1u << k;
+                        any_upd = true;
+                    } else {
+                        a.phase[k] = PH_PFIN;
+                    }
                 }
             }
+        }
+        if (spec) {
+            TRY(wait_copies());
+            for (int ch = 0; ch < C; ++ch)
+                if ((spec & (1u << ch)) && !staged[ch]) TRY(upload(ch, c->stream));
+            scatter_staged(spec, b.Pn);
+            batch_sumsq_kernel<<<dim3((unsigned)b.n_pp0), dim3(256), 0, c->stream>>>(b.Pn, c->M, b.pn0_part);
         }
         bool timed;
         TRY(batch_time_begin(c, timed));
         batch_adjoint_kernel<<<dim3((unsigned)(b.n_waves / 4)), dim3(256), 0, c->stream>>>(a);
         TRY(batch_time_end(c, timed));
         HIPCHK(c, hipGetLastError());
-        if (any_upd) TRY(batch_evaluate(c, b.Xw[run.xi ^ 1], b.Dw, b.GREGw, b.Rtw));
+        if (any_upd) {
+            TRY(batch_evaluate(c, b.Xw[run.xi ^ 1], Ds[wset], GREGs[wset], Rts[wset], scals[wset]));
+            run.ws = wset;
+        }
         for (int ch : pending) TRY(upload(ch, c->copy_stream));
         pending.clear();
+        const int x_prop = run.xi;  // the sweep's input: the proposals of the chains that finished
         run.xi ^= 1;
         run.pin ^= 1;
         for (int k = 0; k < C; ++k)
             if (run.active[k]) run.s_of[k] += 1;
         if (!fin) continue;
-        // the chains that took their final half step in this sweep: Metropolis test
-        HIPCHK(c, hipMemcpyAsync(h, b.scal, sizeof(double) * CB * 4, hipMemcpyDeviceToHost, c->stream));
+        // the chains that took their final half step in this sweep: Metropolis test.  Their
+        // proposals' potentials, gradients and residuals are in the set the sweep READ.
+        HIPCHK(c, hipMemcpyAsync(h, scals[rs], sizeof(double) * CB * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(h + CB * 4, b.pp_part, sizeof(double) * (size_t)b.n_waves * CB,
                                  hipMemcpyDeviceToHost, c->stream));
+        if (spec)
+            HIPCHK(c, hipMemcpyAsync(h + h_pn0, b.pn0_part, sizeof(double) * (size_t)b.n_pp0 * CB,
+                                     hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         unsigned mask = 0;
         // result slots per chain: T, plus one in carry-over mode for the trajectory that came in flight
@@ -1444,10 +1491,10 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
             out5s[5 * slot + 4] = Hnew;
         }
         if (mask) {
-            batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xw[run.xi], b.Xc, n16, mask);
-            batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGw, b.GREGc, n16, mask);
-            batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dw, b.Dc, l16, mask);
-            batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtw, b.Rtc, l16, mask);
+            batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xw[x_prop], b.Xc, n16, mask);
+            batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(GREGs[rs], b.GREGc, n16, mask);
+            batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(Ds[rs], b.Dc, l16, mask);
+            batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(Rts[rs], b.Rtc, l16, mask);
             HIPCHK(c, hipGetLastError());
             if (x_out)
                 for (int k = 0; k < C; ++k)
@@ -1460,6 +1507,12 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
             if (fin & (1u << k)) {
                 run.active[k] = false;
                 done_of[k] += 1;
+                if ((spec & mask) & (1u << k)) {
+                    // accepted, and the first step of the next trajectory has been taken: carry on
+                    double s = 0.0;
+                    for (int w = 0; w < b.n_pp0; ++w) s += h[h_pn0 + (size_t)w * CB + k];
+                    take_next(k, s, 1);
+                }
             }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -39,7 +39,7 @@ static int batch_alloc(gh_ctx *c)
     TRY(dalloc(c, &b.pp_part, (size_t)b.n_waves * CB));
     b.n_pp0 = (int)std::min<int64_t>(512, (c->M + 15) / 16);
     TRY(dalloc(c, &b.pp0_part, (size_t)b.n_pp0 * CB));
-    HIPCHK(c, hipHostMalloc((void **)&b.h, sizeof(double) * (size_t)(CB * 4 + (b.n_waves + b.n_pp0) * CB)));
+    HIPCHK(c, hipHostMalloc((void **)&b.h, sizeof(double) * (size_t)(CB * 4 + (b.n_waves + 2 * b.n_pp0) * CB)));
     // the adjoint GEMM wants G in MFMA operand order; 288 GB of HBM usually has room for the
     // second copy (C2: 40 GB + 40 GB).  Without it the kernel reads the column-major matrix.
     if (env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
@@ -84,7 +84,7 @@ static int batch_time_end(gh_ctx *c, bool timed)
 }
 
 // forward of all chains at X, then regulariser and residuals into (D, GREG, Rt, scal)
-static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, double *Rt)
+static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, double *Rt, double *scal = nullptr)
 {
     gh_ctx::Batch &b = c->bt;
     BatchFwdArgs f;
@@ -127,7 +127,7 @@ static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, d
     fa.regpart = b.regpart;
     fa.alpha = c->alpha;
     fa.Rt = Rt;
-    fa.scal = b.scal;
+    fa.scal = scal ? scal : b.scal;
     batch_finish_kernel<<<dim3(CB), dim3(1024), 0, c->stream>>>(fa);
     HIPCHK(c, hipGetLastError());
     return GH_OK;

@@ -126,6 +126,9 @@ struct gh_ctx {
         double *slab = nullptr, *regpart = nullptr, *pp_part = nullptr, *pp0_part = nullptr;
         double *stage = nullptr;  // C x M rows as the host passes them
         double *stage2 = nullptr; // second set of rows (gh_batch_run: next trajectories' momenta sent ahead)
+        // gh_batch_run: second working set (the sweep reads one, the evaluation writes the other, so the
+        // proposal's values survive a speculative first step) and the next trajectories' momenta
+        double *GREGw2 = nullptr, *Dw2 = nullptr, *Rtw2 = nullptr, *scal2 = nullptr, *Pn = nullptr, *pn0_part = nullptr;
         double *Gb = nullptr;     // second copy of G in MFMA operand order (adjoint), if HBM allows
         double *h = nullptr;      // pinned
         int n_colblocks = 0, n_regblocks = 0, n_waves = 0, n_pp0 = 0;
@@ -139,7 +142,7 @@ struct gh_ctx {
             bool active[CB] = {};
             int s_of[CB] = {}, L_cur[CB] = {}, par[CB] = {};
             double u_cur[CB] = {}, pp0[CB] = {};
-            int xi = 0, pin = 0;
+            int xi = 0, pin = 0, ws = 0;  // ws: working set the next sweep reads
             double dt = 0.0;
         } run;
     } bt;
