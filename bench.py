@@ -256,22 +256,51 @@ def main():
             def one(r):
                 return r.randn(M) * Sigma, r.rand()
             res = list(pool.map(one, rs))
-            return np.stack([p for p, _ in res]), np.array([u for _, u in res]), n
+            return [p for p, _ in res], [u for _, u in res], n
 
         def run_rounds(total_steps, first):
+            """Every chain runs total_steps leapfrog steps in trajectories of L (the last one
+            shorter), through the sampler's path (HMCSampleBatch): gh_batch_run in carry-over mode,
+            four trajectories per chain offered per call -- a finishing chain's last sweep takes the
+            first step of the next one it has been offered -- further rounds drawn meanwhile."""
             plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
-            nacc, nxt = 0, first
-            for i, n in enumerate(plan):
-                p0s, us, _ = nxt
-                fut = pool.submit(eng.batch_trajectory, p0s, dt, [n] * CPG, us)
-                nxt = draw_round(plan[i + 1]) if i + 1 < len(plan) else None
-                acc, _ = fut.result()
-                nacc += sum(acc)
+            queue = [[] for _ in range(CPG)]           # per chain: (n, p0, u) not started yet
+            drawn = 0
+
+            def draw_into_queue():
+                nonlocal drawn
+                if drawn < len(plan):
+                    p0s, us, n = first[drawn] if drawn < len(first) else draw_round(plan[drawn])
+                    for k in range(CPG):
+                        queue[k].append((plan[drawn], p0s[k], us[k]))
+                    drawn += 1
+
+            for _ in range(4):
+                draw_into_queue()
+            nacc, done = 0, [0] * CPG
+            while min(done) < len(plan):
+                T = min(4, min(len(q) for q in queue))
+                if T == 0:                             # nothing left to offer: finish what is in flight
+                    acc, _, _, ns, nd = eng.batch_run([[] for _ in range(CPG)], dt, np.zeros((CPG, 0)),
+                                                      np.zeros((CPG, 0)), carry=True)
+                else:
+                    fut = pool.submit(eng.batch_run, [[tr[1] for tr in q[:T]] for q in queue], dt,
+                                      [[tr[0] for tr in q[:T]] for q in queue],
+                                      [[tr[2] for tr in q[:T]] for q in queue], False, True)
+                    while min(len(q) for q in queue) < 8 and drawn < len(plan):
+                        draw_into_queue()
+                    acc, _, _, ns, nd = fut.result()
+                for k in range(CPG):
+                    del queue[k][:int(ns[k])]
+                    done[k] += int(nd[k])
+                    nacc += int(acc[k, :int(nd[k])].sum())
             return nacc, len(plan)
 
+        # a sampler in steady state has its next rounds drawn while the GPU was busy: the first four
+        # are drawn before the clock starts, the rest overlaps as usual
         if args.warmup > 0:
-            run_rounds(args.warmup, draw_round(L))
-        first = draw_round(L)
+            run_rounds(args.warmup, [draw_round(L)])
+        first = [draw_round(L) for _ in range(4)]
         eng.synchronize()
         barrier()
         eng.profile_enable(True)
