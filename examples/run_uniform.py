@@ -31,7 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("attempt", nargs="?", type=int, default=0)
     ap.add_argument("--config", default="SetPMTS.txt")
-    ap.add_argument("--chains", type=int, default=1, help="chains batched on this GPU (MFMA path)")
+    ap.add_argument("--chains", type=int, default=1, help="chains sharing this GPU (fp64-MFMA batch, or the resident kernel for small problems)")
     ap.add_argument("--wavelet", default=None, choices=[None, "1D", "3D"])
     ap.add_argument("--sink", default="text", choices=["text", "binary", "none"])
     args = ap.parse_args()

@@ -1025,9 +1025,15 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     if (C < 1 || C > CB) return fail(c, GH_ERR_ARG, "gh_batch_init: 1..16 chains per batch");
     TRY(need(c, c->have_G && c->have_data && c->have_reg && !c->mf,
              "gh_batch_init: needs the stored (dense) kernel matrix, gh_set_data and gh_set_reg"));
-    if (c->wv.on || c->sh.kind != 0)
-        return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the dense, unsharded kernel only");
+    if (c->sh.kind != 0)
+        return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the unsharded kernel only");
     HIPCHK(c, hipSetDevice(c->device));
+    // (the wavelet-compressed forward only where the resident chain kernel takes the batch: the MFMA
+    // batch has no compressed forward)
+    if (c->wv.on && !(resident_plan(c) && resident_lds_doubles(c->ld, c->rs.cpw, C, c->rs.lds_cols, c->rs.split) *
+                                                  sizeof(double) <= (size_t)c->rs.lds_max))
+        return fail(c, GH_ERR_UNSUPPORTED, "batched chains with the wavelet-compressed forward need a problem "
+                                           "small enough for the resident chain kernel");
     TRY(ensure_work(c));
     TRY(h2d(c, c->low, low, (size_t)c->M));
     TRY(h2d(c, c->high, high, (size_t)c->M));

@@ -193,7 +193,9 @@ int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state 
  * chains cost two sweeps of G per step instead of 16.  Each chain keeps its own trajectory
  * length L[c] (chains that finish early idle until the longest is done) and its own Metropolis
  * variate; every chain reproduces what a single-chain context computes from the same inputs.
- * Host arrays are chain-major: x0s, p0s = C rows of M doubles.  Dense, unsharded kernel only.
+ * Host arrays are chain-major: x0s, p0s = C rows of M doubles.  Unsharded kernel only; with the
+ * wavelet-compressed forward only where the resident chain kernel takes the batch (GH_ERR_UNSUPPORTED
+ * otherwise: the MFMA form has no compressed forward).
  * Problems small enough for the resident chain kernel (see gh_chain_resident_stats) do not use
  * the MFMA form, which would be bound by its launches there: the chains take turns inside one
  * launch of that kernel per gh_batch_trajectory call (same contract, same results to rounding). */

@@ -1004,7 +1004,8 @@ def test_posterior_window_and_sample_sinks(G, orc, tmp_path, capsys):
 # --------------------------------------------------------- several chains per GPU (fp64 MFMA)
 
 @pytest.mark.parametrize("case,resident", [("small_tv", "0"), ("small_tv", "1"), ("random_ms", "0"),
-                                           ("random_ms", "1"), ("random_damping_big", "1")])
+                                           ("random_ms", "1"), ("random_damping_big", "1"),
+                                           ("small_tv_wavelet", "1")])
 def test_batched_chains_match_single_chain_engines(G, monkeypatch, case, resident):
     """gh_batch_*: up to 16 chains share every sweep of G through v_mfma_f64_16x16x4 -- or, on
     problems small enough for the resident chain kernel (resident = "1": the first two cases),
@@ -1013,7 +1014,7 @@ def test_batched_chains_match_single_chain_engines(G, monkeypatch, case, residen
     MFMA contracts rows in another order than the wave reduction)."""
     monkeypatch.setenv("GRAVHMC_RESIDENT", resident)
     rng = np.random.default_rng(11)
-    if case == "small_tv":
+    if case in ("small_tv", "small_tv_wavelet"):
         p = gold("potential_small.npz")
         A, dobs, shape, reg, beta = np.asarray(p["Aw"]) * p["wm"][None, :], p["dobs"], p["shape"], "TV", 0.001
         C, dt, sig, hi, ntraj = 5, 0.02, 0.3, 0.02, 6
@@ -1035,6 +1036,8 @@ def test_batched_chains_match_single_chain_engines(G, monkeypatch, case, residen
         w = e.weight(0.5)
         e.set_data(dobs)
         e.set_reg(reg, 1.0, beta, shape, 0.001 * w)
+        if case == "small_tv_wavelet":      # compressed forward: only the resident kernel batches it
+            e.compress_wavelet(3, shape, 1e-3, 2)
         return e, w
 
     eb, wm = make()
@@ -1042,6 +1045,11 @@ def test_batched_chains_match_single_chain_engines(G, monkeypatch, case, residen
     x0s = np.stack([(0.001 + 0.002 * c) * wm for c in range(C)])
     eb.batch_init(x0s, low, high)
     monkeypatch.setenv("GRAVHMC_RESIDENT", "0")     # the single-chain contexts: sweep path
+    if case == "small_tv_wavelet":
+        en, _ = make()
+        with pytest.raises(NotImplementedError):    # (no compressed forward in the MFMA batch)
+            en.batch_init(x0s, low, high)
+        en.close()
     singles = []
     for c in range(C):
         e, _ = make()
@@ -1061,7 +1069,7 @@ def test_batched_chains_match_single_chain_engines(G, monkeypatch, case, residen
             n_acc += a1
             n_rej += not a1
     assert n_acc > 0
-    if case == "small_tv":
+    if case in ("small_tv", "small_tv_wavelet"):
         assert n_rej > 0
     took_resident = eb.chain_stats()["resident_launches"] > 0
     assert took_resident == (resident == "1" and case != "random_damping_big")
