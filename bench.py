@@ -395,7 +395,7 @@ def main():
                          "stream_read_microbench_GBps": stream_gbps,
                          "vs_stream_read_microbench": achieved / stream_gbps if stream_gbps else None},
         }
-        cstat = eng.chain_stats() if CPG == 1 else {}
+        cstat = eng.chain_stats()
         if cstat.get("resident_evaluations", 0) > 0:
             # G never left the chip: the figure below is what the reference formulation would have
             # had to read per second, not HBM traffic
@@ -407,7 +407,13 @@ def main():
                 "launches": cstat["resident_launches"], "avg_ms": None,
                 "evaluations": prof["sweeps"], "us_per_evaluation": sweep_ms * 1e3,
                 "lds_equiv_GBps": achieved})
-        if CPG > 1:
+        if CPG > 1 and cstat.get("resident_evaluations", 0) > 0:
+            # small problem: the chains took turns inside the resident chain kernel
+            line["roofline"]["kernel"] = ("resident_chain_kernel (%d chains x %d trajectories in %d launches)"
+                                          % (CPG, ntraj, cstat["resident_launches"]))
+            line["roofline"]["reference_formulation_equiv_GBps"] = \
+                2 * bytes_sweep * CPG * args.steps / elapsed / 1e9
+        elif CPG > 1:
             line["roofline"].update({
                 "kernel": "batch_adjoint_kernel + batch_forward_kernel (v_mfma_f64_16x16x4, %d chains "
                           "share each read of G; two sweeps per leapfrog step of the batch)" % CPG,
