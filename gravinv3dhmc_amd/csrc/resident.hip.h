@@ -205,9 +205,19 @@ __device__ __forceinline__ double res_block_sum(double v, double *red)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
+    // (the eight partials in four 16-byte reads issued together; summed in wave order)
+    const d2 *red2 = reinterpret_cast<const d2 *>(red);
+    const d2 a0 = red2[0], a1 = red2[1], a2 = red2[2], a3 = red2[3];
+    __builtin_amdgcn_sched_barrier(0);
     double t = 0.0;
-#pragma unroll
-    for (int q = 0; q < RES_WAVES; ++q) t += red[q];
+    t += a0.x;
+    t += a0.y;
+    t += a1.x;
+    t += a1.y;
+    t += a2.x;
+    t += a2.y;
+    t += a3.x;
+    t += a3.y;
     return t;
 }
 
@@ -419,16 +429,40 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         }
         if (tid < ld2) {
             d2 acc = d2{0.0, 0.0};
+            // (LDS reads in batches of eight with the arithmetic fenced off behind them: at this
+            // kernel's register pressure the scheduler otherwise issues read, wait, FMA one by one
+            // and the pass runs at LDS latency -- measured 1.4 us for 24 columns -- instead of
+            // LDS bandwidth; the order of the sums is unchanged)
             if (split) {
                 const d2 *f2 = reinterpret_cast<const d2 *>(fsc);
+                d2 t[RES_WAVES];
+#pragma unroll
+                for (int v = 0; v < RES_WAVES; ++v) t[v] = f2[v * ld2 + tid];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int v = 0; v < RES_WAVES; ++v) {
-                    const d2 t = f2[v * ld2 + tid];
-                    acc.x += t.x;
-                    acc.y += t.y;
+                    acc.x += t[v].x;
+                    acc.y += t[v].y;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            for (int c = 0; c < nl; ++c) {
+            int c = 0;
+            for (; c + 8 <= nl; c += 8) {
+                d2 g[8];
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g[u] = Gs2[(c + u) * ld2 + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = xs[lds_c0 + c + u];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc.x += g[u].x * x[u];
+                    acc.y += g[u].y * x[u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; c < nl; ++c) {
                 const d2 g = Gs2[c * ld2 + tid];
                 const double x = xs[lds_c0 + c];
                 acc.x += g.x * x;
@@ -570,12 +604,16 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     // cu; 2: last half momentum step (returns this workgroup's sum of p^2, gradient in gs).
     auto dots = [&](int what, double cu) -> double {
         __syncthreads();  // r_s, gr complete
+        tick(11);
+        // (unconditional reads -- the few doubles past r_s belong to redbuf -- then zeroed: selects
+        // instead of branches, all reads in flight together)
         d2 rr[RC];
 #pragma unroll
-        for (int k = 0; k < RC; ++k) {
-            const int e = lane + 64 * k;
-            rr[k] = (e < ld2) ? r_s2[e] : d2{0.0, 0.0};
-        }
+        for (int k = 0; k < RC; ++k) rr[k] = r_s2[lane + 64 * k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+            if (lane + 64 * k >= ld2) rr[k] = d2{0.0, 0.0};
         if (CW > 0) {
             double s[CW > 0 ? CW : 1];
 #pragma unroll
@@ -604,15 +642,20 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                     const int c = cb + q * RES_WAVES;
                     s[q] = 0.0;
                     if (c < nc) {
+                        // (rows past the column read its last chunk again and meet rr = 0)
+                        d2 g[RC];
 #pragma unroll
                         for (int k = 0; k < RC; ++k) {
                             const int e = lane + 64 * k;
-                            if (e < ld2) {
-                                const d2 g = Gs2[(c - lds_c0) * ld2 + e];
-                                s[q] += g.x * rr[k].x;
-                                s[q] += g.y * rr[k].y;
-                            }
+                            g[k] = Gs2[(c - lds_c0) * ld2 + (e < ld2 ? e : ld2 - 1)];
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < RC; ++k) {
+                            s[q] += g[k].x * rr[k].x;
+                            s[q] += g[k].y * rr[k].y;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
@@ -624,14 +667,18 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 }
             }
         }
+        tick(12);
         __syncthreads();
+        tick(13);
         double pp = 0.0;
         if (tid < nc) {
-            const double g = 2.0 * gs[tid] + gr[tid];
+            const double gs_j = gs[tid], gr_j = gr[tid], ps_j = ps[tid], xs_j = xs[tid];
+            const double chi = hi[tid], clo = lo[tid];
+            __builtin_amdgcn_sched_barrier(0);
+            const double g = 2.0 * gs_j + gr_j;
             if (what == 1) {
-                double pj = ps[tid] - cu * g;
-                double xj = xs[tid] + a.dt * pj;
-                const double chi = hi[tid], clo = lo[tid];
+                double pj = ps_j - cu * g;
+                double xj = xs_j + a.dt * pj;
                 if (xj > chi) {
                     xj = chi;
                     pj = -pj;
@@ -643,12 +690,13 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 xs[tid] = xj;
             } else {
                 if (what == 2) {
-                    const double pf = ps[tid] - cu * g;
+                    const double pf = ps_j - cu * g;
                     pp = pf * pf;
                 }
                 gs[tid] = g;
             }
         }
+        tick(14);
         if (what != 2) return 0.0;
         return res_block_sum(pp, red);
     };
@@ -676,6 +724,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             return ok;
         });
         if (!got) *flag_s = 0;
+        tick(15);
         Rtot = res_block_sum(t0, red);
         pp1 = res_block_sum(t1, red);
         pp0 = res_block_sum(t2, red);
