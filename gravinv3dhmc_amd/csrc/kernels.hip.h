@@ -373,12 +373,84 @@ struct RegArgs {
     const double *xlo, *xhi, *alo, *ahi;
 };
 
-// Regulariser term of cell j at the model a.x (own value xj = a.x[j] passed in; neighbours of the
-// stencil kinds are read from a.x): returns dR/dx_j, adds the cell's share of R to `val`
-// (potential.py:719-736, 775-810).  The finite-difference operator of potential.py:266-361 is never
-// materialised.
+// Stencil regularisers (Smoothness, TV), first half: model and prior model of the six neighbours of
+// cell j, [2 ax] forward, [2 ax + 1] backward (the cell itself where the mesh ends: not used).  All
+// twelve loads are issued before any arithmetic -- one memory latency instead of six in a row --
+// and a caller with other work to do can put it between this and reg_stencil_eval.
 // SC1: the neighbours' model values are read with agent-scope (sc1) loads that bypass this CU's L1
 // (resident chain kernel: other workgroups wrote them, write-through, earlier in the same launch).
+template <bool HALO, bool SC1>
+__device__ __forceinline__ void reg_stencil_load(const RegArgs &a, int64_t j, double (&xn)[6], double (&an)[6])
+{
+    const int64_t nx = a.nx, ny = a.ny, nz = a.nz, P = nx * ny;
+    const int64_t i = j % nx, jj = (j / nx) % ny, k = j / P + a.k0;
+    const int64_t stride[3] = {1, nx, P};
+    const bool fwd[3] = {i < nx - 1, jj < ny - 1, k < nz - 1};
+    const bool bwd[3] = {i > 0, jj > 0, k > 0};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const int64_t qf = fwd[ax] ? j + stride[ax] : j, qb = bwd[ax] ? j - stride[ax] : j;
+        if (HALO) {
+            // beyond the local planes: the neighbouring rank's boundary plane
+            xn[2 * ax] = qf >= a.M ? a.xhi[qf - a.M] : a.x[qf];
+            an[2 * ax] = qf >= a.M ? a.ahi[qf - a.M] : a.mwapr[qf];
+            xn[2 * ax + 1] = qb < 0 ? a.xlo[qb + P] : a.x[qb];
+            an[2 * ax + 1] = qb < 0 ? a.alo[qb + P] : a.mwapr[qb];
+        } else {
+            if (SC1) {
+                xn[2 * ax] = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(a.x + qf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                xn[2 * ax + 1] = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(a.x + qb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            } else {
+                xn[2 * ax] = a.x[qf];
+                xn[2 * ax + 1] = a.x[qb];
+            }
+            an[2 * ax] = a.mwapr[qf];
+            an[2 * ax + 1] = a.mwapr[qb];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Second half: dR/dx_j from v = x_j - prior_j and the neighbours; adds the cell's share of R to
+// `val` (potential.py:786-810; the finite-difference operator of potential.py:266-361 is never
+// materialised)
+__device__ __forceinline__ double reg_stencil_eval(const RegArgs &a, int64_t j, double v, const double (&xn)[6],
+                                                   const double (&an)[6], double &val)
+{
+    const int64_t nx = a.nx, ny = a.ny, nz = a.nz, P = nx * ny;
+    const int64_t i = j % nx, jj = (j / nx) % ny, k = j / P + a.k0;
+    const bool fwd[3] = {i < nx - 1, jj < ny - 1, k < nz - 1};
+    const bool bwd[3] = {i > 0, jj > 0, k > 0};
+    double g = 0.0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (fwd[ax]) {
+            const double t = v - (xn[2 * ax] - an[2 * ax]);
+            if (a.kind == 1) {
+                val += t * t;
+                g += 2.0 * t;
+            } else {
+                const double s = sqrt(t * t + a.beta);
+                val += s;
+                g += t / s;
+            }
+        }
+        if (bwd[ax]) {
+            const double t = (xn[2 * ax + 1] - an[2 * ax + 1]) - v;
+            if (a.kind == 1)
+                g -= 2.0 * t;
+            else
+                g -= t / sqrt(t * t + a.beta);
+        }
+    }
+    return g;
+}
+
+// Regulariser term of cell j at the model a.x (own value xj = a.x[j] passed in; neighbours of the
+// stencil kinds are read from a.x): returns dR/dx_j, adds the cell's share of R to `val`
+// (potential.py:719-736, 775-810).
 template <bool HALO = false, bool SC1 = false>
 __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double xj, double &val)
 {
@@ -393,45 +465,9 @@ __device__ __forceinline__ double reg_cell(const RegArgs &a, int64_t j, double x
         const double deng = a.ms_grad_den_mw ? xj * xj + a.beta : den;
         g = (2.0 * a.beta * w2 * v) / (deng * deng);
     } else {  // Smoothness (1) / TV (3)
-        const int64_t nx = a.nx, ny = a.ny, nz = a.nz, P = nx * ny;
-        const int64_t i = j % nx, jj = (j / nx) % ny, k = j / P + a.k0;
-        const int64_t stride[3] = {1, nx, P};
-        const bool fwd[3] = {i < nx - 1, jj < ny - 1, k < nz - 1};
-        const bool bwd[3] = {i > 0, jj > 0, k > 0};
-        // model minus prior model of neighbour q (beyond the local planes: the neighbouring rank's)
-        auto nb = [&](int64_t q) -> double {
-            if (HALO) {
-                if (q >= a.M) return a.xhi[q - a.M] - a.ahi[q - a.M];
-                if (q < 0) return a.xlo[q + P] - a.alo[q + P];
-            }
-            if (SC1) {
-                const unsigned long long b = __hip_atomic_load(
-                    reinterpret_cast<const unsigned long long *>(a.x + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return __longlong_as_double((long long)b) - a.mwapr[q];
-            }
-            return a.x[q] - a.mwapr[q];
-        };
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            if (fwd[ax]) {
-                const double t = v - nb(j + stride[ax]);
-                if (a.kind == 1) {
-                    val += t * t;
-                    g += 2.0 * t;
-                } else {
-                    const double s = sqrt(t * t + a.beta);
-                    val += s;
-                    g += t / s;
-                }
-            }
-            if (bwd[ax]) {
-                const double t = nb(j - stride[ax]) - v;
-                if (a.kind == 1)
-                    g -= 2.0 * t;
-                else
-                    g -= t / sqrt(t * t + a.beta);
-            }
-        }
+        double xn[6], an[6];
+        reg_stencil_load<HALO, SC1>(a, j, xn, an);
+        g = reg_stencil_eval(a, j, v, xn, an, val);
     }
     return g;
 }

@@ -240,6 +240,8 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     const int nc = (int)((M - j0 < cpw) ? (M - j0) : cpw);
     const int nwg = a.nwg;
     const bool stencil = (a.kind == 1 || a.kind == 3);
+    // (stencil regularisers) one thread per (cell, neighbour) where that fits
+    const bool spread = 6 * cpw <= RES_THREADS && 12 * cpw <= RES_REDBUF;
 
     // split mode: columns [0, 8 CW) of the workgroup live in the waves' registers only
     const bool split = CW > 0 && a.split != 0;
@@ -394,13 +396,10 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         tick(0);
         const unsigned tag = a.tag0 + (unsigned)ev + 1u;
         const int par = ev & 1;
-        if (stencil) {
-            // neighbours read the model once they have d (level 3): the stores are drained before
-            // any of this workgroup's partials, which d transitively depends on, is published
-            if (tid < nc) st_wt(a.xpub + (int64_t)par * M + j0 + tid, xs[tid]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        // neighbours read the model once they have d (level 3): these stores are drained (below,
+        // behind the forward pass that hides their latency) before any of this workgroup's
+        // partials, which d transitively depends on, is published
+        if (stencil && tid < nc) st_wt(a.xpub + (int64_t)par * M + j0 + tid, xs[tid]);
         if (split) {
             // forward share of the register-held columns: per wave over its columns, then summed
             // over the waves through LDS in a fixed order
@@ -427,8 +426,8 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             }
             __syncthreads();
         }
+        d2 facc = d2{0.0, 0.0};
         if (tid < ld2) {
-            d2 acc = d2{0.0, 0.0};
             // (LDS reads in batches of eight with the arithmetic fenced off behind them: at this
             // kernel's register pressure the scheduler otherwise issues read, wait, FMA one by one
             // and the pass runs at LDS latency -- measured 1.4 us for 24 columns -- instead of
@@ -441,8 +440,8 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int v = 0; v < RES_WAVES; ++v) {
-                    acc.x += t[v].x;
-                    acc.y += t[v].y;
+                    facc.x += t[v].x;
+                    facc.y += t[v].y;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -457,24 +456,30 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    acc.x += g[u].x * x[u];
-                    acc.y += g[u].y * x[u];
+                    facc.x += g[u].x * x[u];
+                    facc.y += g[u].y * x[u];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             for (; c < nl; ++c) {
                 const d2 g = Gs2[c * ld2 + tid];
                 const double x = xs[lds_c0 + c];
-                acc.x += g.x * x;
-                acc.y += g.y * x;
+                facc.x += g.x * x;
+                facc.y += g.y * x;
             }
+        }
+        if (stencil) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (tid < ld2) {
             u64 *out = a.slabg + ((int64_t)w * ld + i0) * 2;
             if (local) {
-                st_gran_l2(out, tag, acc.x);
-                st_gran_l2(out + 2, tag, acc.y);
+                st_gran_l2(out, tag, facc.x);
+                st_gran_l2(out + 2, tag, facc.y);
             } else {
-                st_gran(out, tag, acc.x);
-                st_gran(out + 2, tag, acc.y);
+                st_gran(out, tag, facc.x);
+                st_gran(out + 2, tag, facc.y);
             }
         }
         // the cell-local regularisers (Damping, MS) do not wait for anybody
@@ -558,6 +563,37 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             dinv = d2{dx, dy};
         }
         tick(6);
+        // Stencil regularisers: the neighbours' models are requested now and used behind the
+        // residual below, which hides the memory latency.  Any row of d depends on a partial of
+        // every workgroup, and those were published after the workgroup's model stores had drained
+        // (write-through); the loads bypass L1: no fence needed.
+        // Where the workgroup's cells times six fit its threads, thread 6 c + q takes term q (axis
+        // q / 2, forward / backward) of cell c -- one square root and one division per lane
+        // instead of six of each on a few lanes of wave 0 -- and the terms meet again in LDS, added
+        // in the order reg_stencil_eval adds them.
+        double xn[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, an[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double xn1 = 0.0, an1 = 0.0, ap1 = 0.0;
+        bool ex1 = false;
+        const int c6 = tid / 6, q6 = tid - 6 * c6;
+        if (stencil) ra.x = a.xpub + (int64_t)par * M;
+        if (stencil && spread) {
+            if (c6 < nc) {
+                const int64_t j = j0 + c6, P = (int64_t)a.nx * a.ny;
+                const int64_t ci = j % a.nx, cj = (j / a.nx) % a.ny, ck = j / P;
+                const int ax = q6 >> 1;
+                const int64_t pos = ax == 0 ? ci : ax == 1 ? cj : ck, len = ax == 0 ? a.nx : ax == 1 ? a.ny : a.nz;
+                const int64_t str = ax == 0 ? 1 : ax == 1 ? a.nx : P;
+                ex1 = (q6 & 1) ? pos > 0 : pos < len - 1;
+                const int64_t qn = ex1 ? ((q6 & 1) ? j - str : j + str) : j;
+                xn1 = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(ra.x + qn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                an1 = a.mwapr[qn];
+                ap1 = a.mwapr[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (stencil && tid < nc) {
+            reg_stencil_load<false, true>(ra, j0 + tid, xn, an);
+        }
         // mean removal, residual, data misfit (potential.py:700-706)
         double s = 0.0;
         if (tid < ld2) {
@@ -581,14 +617,33 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             }
             r_s2[tid] = rv;
         }
-        if (stencil) {
-            // regulariser of the own cells at xs, neighbours from the published model: those
-            // stores were write-through and drained before the partials that d -- which has just
-            // been read -- depends on, and the loads bypass L1: no fence needed
-            if (tid < nc) {
-                ra.x = a.xpub + (int64_t)par * M;
-                gr[tid] = a.alpha * reg_cell<false, true>(ra, j0 + tid, xs[tid], val);
+        // regulariser of the own cells at xs, neighbours from the published model (requested above)
+        if (stencil && spread) {
+            if (c6 < nc) {
+                const double v = xs[c6] - ap1;
+                const double t = (q6 & 1) ? (xn1 - an1) - v : v - (xn1 - an1);
+                double gt, vt;
+                if (a.kind == 1) {  // Smoothness (potential.py:786-796)
+                    gt = 2.0 * t;
+                    vt = t * t;
+                } else {  // TV (potential.py:798-810)
+                    vt = sqrt(t * t + a.beta);
+                    gt = t / vt;
+                }
+                redbuf[tid] = ex1 ? ((q6 & 1) ? -gt : gt) : 0.0;
+                redbuf[6 * cpw + tid] = (ex1 && !(q6 & 1)) ? vt : 0.0;
             }
+            __syncthreads();
+            if (tid < nc) {
+                double g = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) g += redbuf[6 * tid + q];
+#pragma unroll
+                for (int q = 0; q < 6; q += 2) val += redbuf[6 * cpw + 6 * tid + q];
+                gr[tid] = a.alpha * g;
+            }
+        } else if (stencil && tid < nc) {
+            gr[tid] = a.alpha * reg_stencil_eval(ra, j0 + tid, xs[tid] - apr_j, xn, an, val);
         }
         if (last) {
             ud = res_block_sum(acc, red);
