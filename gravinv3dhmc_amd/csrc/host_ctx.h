@@ -154,7 +154,7 @@ struct gh_ctx {
         int lds_cols = 0;     // columns of a workgroup held in LDS
         bool split = false;   // one copy: the first 8 ct columns in registers only, the rest in LDS
         size_t lds = 0;
-        ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xccg = nullptr;
+        ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xscalg = nullptr, *xccg = nullptr;
         double *xpub = nullptr;
         unsigned *abort_w = nullptr;
         unsigned tag = 0, tagE = 0;  // granule tags used so far (the buffers keep them across launches)

@@ -123,7 +123,8 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
         TRY(dalloc(c, &r.slabg, (size_t)(r.nwg + 8) * (size_t)c->ld * 2));
         TRY(dalloc(c, &r.xslabg, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
         TRY(dalloc(c, &r.dclg, (size_t)RES_CLUSTERS * (size_t)c->ld * 2));
-        TRY(dalloc(c, &r.scalg, (size_t)r.nwg * 8));
+        TRY(dalloc(c, &r.scalg, (size_t)(r.nwg + 8) * 8));
+        TRY(dalloc(c, &r.xscalg, (size_t)RES_CLUSTERS * 8));
         TRY(dalloc(c, &r.xccg, (size_t)r.nwg + 8));
         TRY(dalloc(c, &r.xpub, 2 * M));
         TRY(dalloc(c, &r.abort_w, 4));
@@ -156,6 +157,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
         HIPCHK(c, hipMemsetAsync(r.xslabg, 0, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.dclg, 0, (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.scalg, 0, (size_t)r.nwg * 8 * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.xscalg, 0, (size_t)RES_CLUSTERS * 8 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.xccg, 0, (size_t)r.nwg * sizeof(ghk::u64), c->stream));
         r.tag = r.tagE = 0;
     }
@@ -210,6 +212,7 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     a.xslabg = r.xslabg;
     a.dclg = r.dclg;
     a.scalg = r.scalg;
+    a.xscalg = r.xscalg;
     a.xccg = r.xccg;
     a.xpub = r.xpub;
     a.tag0 = r.tag;

@@ -89,7 +89,8 @@ struct ResArgs {
     u64 *xslabg;     // 2 x 8 x ld x 2 cluster sums, double-buffered by evaluation parity
     u64 *dclg;       // 8 x ld x 2 finished d, one copy per cluster
     u64 *xccg;       // nwg: {launch tag, XCC id} of every workgroup
-    u64 *scalg;      // nwg x 8 trajectory-end scalars
+    u64 *scalg;      // nwg x 8 trajectory-end scalars of the workgroups
+    u64 *xscalg;     // 8 x 8 the same summed over each cluster
     double *xpub;    // 2 x M models as the stencil regularisers see them (Smoothness / TV)
     unsigned tag0, tagE0;
     unsigned *abort_w;
@@ -759,30 +760,72 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     // all-gather of {R share, p'p after, p'p before} over the workgroups, summed in a fixed order
     double Rtot = 0.0, pp1 = 0.0, pp0 = 0.0;
     auto gather_scalars = [&](double v_r, double v_pp1, double v_pp0) -> bool {
+        // Two hops along the hardware like the N-vectors: the cluster's member 0 collects the
+        // triples of its members (through L2 where the cluster shares one) and publishes the
+        // cluster's sums; every workgroup then reads the eight cluster sums.  (One hop, every
+        // workgroup reading all 250 triples from memory, measured 7 us per trajectory.)
         tick(8);
         const unsigned tag = a.tagE0 + (unsigned)ng + 1u;
         if (tid == 0) {
             u64 *out = a.scalg + 8 * w;
-            st_gran(out, tag, v_r);
-            st_gran(out + 2, tag, v_pp1);
-            st_gran(out + 4, tag, v_pp0);
-        }
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-        const bool got = res_poll(a.abort_w, [&]() -> bool {
-            bool ok = true;
-            if (tid < nwg) {
-                u64 *in = a.scalg + 8 * tid;
-                ok = ld_gran(in, tag, t0);
-                ok &= ld_gran(in + 2, tag, t1);
-                ok &= ld_gran(in + 4, tag, t2);
+            if (local) {
+                st_gran_l2(out, tag, v_r);
+                st_gran_l2(out + 2, tag, v_pp1);
+                st_gran_l2(out + 4, tag, v_pp0);
+            } else {
+                st_gran(out, tag, v_r);
+                st_gran(out + 2, tag, v_pp1);
+                st_gran(out + 4, tag, v_pp0);
             }
-            return ok;
-        });
-        if (!got) *flag_s = 0;
+        }
+        if (wave == 0) {
+            if (crank == 0) {
+                double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+                bool h0 = !(lane < cn), h1 = h0, h2 = h0;
+                u64 *in = a.scalg + 8 * (cg + RES_CLUSTERS * (lane < cn ? lane : 0));
+                const bool got = res_poll(a.abort_w, [&]() -> bool {
+                    if (!h0) h0 = ld_gran(in, tag, t0);
+                    if (!h1) h1 = ld_gran(in + 2, tag, t1);
+                    if (!h2) h2 = ld_gran(in + 4, tag, t2);
+                    return h0 && h1 && h2;
+                });
+                if (!got) *flag_s = 0;
+                // (members in lane order, fixed tree)
+                t0 = wave_sum_dpp(t0);
+                t1 = wave_sum_dpp(t1);
+                t2 = wave_sum_dpp(t2);
+                if (lane == 0) {
+                    u64 *out = a.xscalg + 8 * cg;
+                    st_gran(out, tag, t0);
+                    st_gran(out + 2, tag, t1);
+                    st_gran(out + 4, tag, t2);
+                }
+            }
+            double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+            bool h0 = !(lane < ncl), h1 = h0, h2 = h0;
+            u64 *in = a.xscalg + 8 * (lane < ncl ? lane : 0);
+            const bool got = res_poll(a.abort_w, [&]() -> bool {
+                if (!h0) h0 = ld_gran(in, tag, u0);
+                if (!h1) h1 = ld_gran(in + 2, tag, u1);
+                if (!h2) h2 = ld_gran(in + 4, tag, u2);
+                return h0 && h1 && h2;
+            });
+            if (!got) *flag_s = 0;
+            u0 = wave_sum_dpp(u0);
+            u1 = wave_sum_dpp(u1);
+            u2 = wave_sum_dpp(u2);
+            // (red[8..10]: the block sums use red[0..7], and slow waves may still be reading those)
+            if (lane == 0) {
+                red[8] = u0;
+                red[9] = u1;
+                red[10] = u2;
+            }
+        }
         tick(15);
-        Rtot = res_block_sum(t0, red);
-        pp1 = res_block_sum(t1, red);
-        pp0 = res_block_sum(t2, red);
+        __syncthreads();
+        Rtot = red[8];
+        pp1 = red[9];
+        pp0 = red[10];
         ++ng;
         tick(9);
         return *flag_s != 0;
