@@ -911,7 +911,7 @@ int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double
     *n_run = 0;
     // already there (a caller that submits batches ahead of looking at the results)
     if (stop_at_accepts > 0 && c->accept_count >= stop_at_accepts) return GH_OK;
-    if (resident_plan(c)) {
+    if (resident_usable(c)) {
         int64_t steps = 0;
         bool ok = true;
         for (int k = 0; k < K; ++k) {
@@ -1030,7 +1030,7 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     HIPCHK(c, hipSetDevice(c->device));
     // (the wavelet-compressed forward only where the resident chain kernel takes the batch: the MFMA
     // batch has no compressed forward)
-    if (c->wv.on && !(resident_plan(c) && resident_lds_doubles(c->ld, c->rs.cpw, C, c->rs.lds_cols, c->rs.split) *
+    if (c->wv.on && !(resident_usable(c) && resident_lds_doubles(c->ld, c->rs.cpw, C, c->rs.lds_cols, c->rs.split) *
                                                   sizeof(double) <= (size_t)c->rs.lds_max))
         return fail(c, GH_ERR_UNSUPPORTED, "batched chains with the wavelet-compressed forward need a problem "
                                            "small enough for the resident chain kernel");
@@ -1040,7 +1040,7 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     gh_ctx::Resident &r = c->rs;
     r.b_on = false;
     c->bt.run = gh_ctx::Batch::Run();  // anything gh_batch_run left in flight is discarded
-    if (resident_plan(c) &&
+    if (resident_usable(c) &&
         resident_lds_doubles(c->ld, r.cpw, C, r.lds_cols, r.split) * sizeof(double) <= (size_t)r.lds_max) {
         // small problem: the chains take turns inside the resident chain kernel (one launch per
         // round of trajectories, G loaded into LDS once for all of them) -- a sweep of a 30 MB G

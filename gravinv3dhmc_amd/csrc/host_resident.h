@@ -94,6 +94,14 @@ static bool resident_plan(gh_ctx *c)
     return true;
 }
 
+// resident_plan + what depends on the regulariser set at the moment
+static bool resident_usable(gh_ctx *c)
+{
+    if (!resident_plan(c)) return false;
+    const bool stencil = c->reg_kind == 1 || c->reg_kind == 3;
+    return !stencil || resident_stencil_fits(c->rs.cpw);
+}
+
 // One launch of the resident chain kernel: K trajectories of C chains (chain_of[k], nullptr: all
 // chain 0) whose current models are the rows of x_dev.  GH_RESIDENT_ABORTED: the kernel gave up
 // waiting for its workgroups, nothing was changed.
@@ -117,6 +125,9 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     const size_t lds = resident_lds_doubles(c->ld, r.cpw, q.C, r.lds_cols, r.split) * sizeof(double);
     if (q.C < 1 || q.C > RES_MAX_CHAINS || lds > (size_t)r.lds_max)
         return fail(c, GH_ERR_ARG, "resident chain kernel: %d chains do not fit the LDS", q.C);
+    if (!resident_usable(c))
+        return fail(c, GH_ERR_UNSUPPORTED, "resident chain kernel: this regulariser needs the sweep path at %d cells "
+                                           "per workgroup", r.cpw);
     HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(resident_for(r.rc, r.ct)), lds));
     if (!r.slabg) {
         // (+8 rows / entries: the abort test announces one phantom workgroup per cluster)

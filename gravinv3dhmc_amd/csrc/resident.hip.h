@@ -104,7 +104,21 @@ constexpr int RES_MAX_CHAINS = 16;
 static inline size_t resident_lds_doubles(int64_t ld, int cols_per_wg, int chains, int lds_cols, bool split)
 {
     return (size_t)lds_cols * (size_t)ld + (split ? 8 * (size_t)ld : 0) + (size_t)ld + RES_REDBUF + 16 +
-           (6 + 2 * (size_t)chains) * (size_t)cols_per_wg + 3 * RES_MAX_CHAINS + 8;
+           (6 + 2 * (size_t)chains) * (size_t)cols_per_wg + 3 * RES_MAX_CHAINS + 8 + 16;
+}
+
+// The stencil regularisers (Smoothness, TV) take one thread per (cell, neighbour) and 12 doubles of
+// the reduction buffer per cell: shapes with more cells per workgroup stay on the sweep path.
+static inline bool resident_stencil_fits(int cols_per_wg)
+{
+    return 6 * cols_per_wg <= RES_THREADS && 12 * cols_per_wg <= RES_REDBUF;
+}
+
+// the value, unknown to the optimiser (keeps what is derived from it where it is written)
+__device__ __forceinline__ int res_opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 // 8-byte write-through store (global_store_dwordx2 sc1)
@@ -233,6 +247,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid_k = tid;
     const int w = blockIdx.x;
     const int ld = (int)a.ld, ld2 = ld >> 1;
     const int cpw = a.cols_per_wg;
@@ -241,8 +256,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     const int nc = (int)((M - j0 < cpw) ? (M - j0) : cpw);
     const int nwg = a.nwg;
     const bool stencil = (a.kind == 1 || a.kind == 3);
-    // (stencil regularisers) one thread per (cell, neighbour) where that fits
-    const bool spread = 6 * cpw <= RES_THREADS && 12 * cpw <= RES_REDBUF;
+    // (stencil regularisers: one thread per (cell, neighbour), resident_stencil_fits)
 
     // split mode: columns [0, 8 CW) of the workgroup live in the waves' registers only
     const bool split = CW > 0 && a.split != 0;
@@ -268,17 +282,22 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     d2 *r_s2 = reinterpret_cast<d2 *>(r_s);
 
     int ev = 0, ng = 0;  // evaluations / scalar gathers so far in this launch
-    long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // per-phase clocks of thread 0 (diagnostic, GRAVHMC_RESIDENT_TIMING): accumulated in LDS -- as
+    // registers they would cost every thread 32 VGPRs in a kernel that has none to spare
+    long long *tacc_s = reinterpret_cast<long long *>(ucs + 3 * RES_MAX_CHAINS + 8);
     long long tlast = 0;
     const bool timing = a.dbg != nullptr && tid == 0 && (w == 0 || w == a.nwg - 1);
     auto tick = [&](int slot) {
         if (timing) {
             const long long now = wall_clock64();
-            tacc[slot] += now - tlast;
+            tacc_s[slot] += now - tlast;
             tlast = now;
         }
     };
-    if (timing) tlast = wall_clock64();
+    if (timing) {
+        for (int i = 0; i < 16; ++i) tacc_s[i] = 0;
+        tlast = wall_clock64();
+    }
 
     // ---- load the workgroup's columns (contiguous in the column-major G) and per-cell vectors
     {
@@ -392,7 +411,48 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     // regulariser gradient; with `last` also ud (data misfit) and Rw (this workgroup's share of
     // R) -- only the end of a trajectory needs the potential itself.  false: aborted.
     double ud = 0.0, Rw = 0.0;
+    // stencil regularisers, one thread per (cell, neighbour): the neighbour's model and prior model,
+    // the cell's prior model, whether the neighbour exists; gr_pending: the terms of the latest
+    // evaluation are still to be formed from them (by the dots pass, right before it needs gr:
+    // the residual and the dots in between hide the latency of these loads)
+    double xn1 = 0.0, an1 = 0.0, ap1 = 0.0;
+    bool ex1 = false, gr_pending = false;
+    const int c6 = tid / 6, q6 = tid - 6 * c6;
+    int nb_off = 0;  // the neighbour's cell index minus the cell's
+    if (stencil && c6 < nc) {
+        const int64_t j = j0 + c6, P = (int64_t)a.nx * a.ny;
+        const int64_t ci = j % a.nx, cj = (j / a.nx) % a.ny, ck = j / P;
+        const int ax = q6 >> 1;
+        const int64_t pos = ax == 0 ? ci : ax == 1 ? cj : ck, len = ax == 0 ? a.nx : ax == 1 ? a.ny : a.nz;
+        const int64_t str = ax == 0 ? 1 : ax == 1 ? a.nx : P;
+        ex1 = (q6 & 1) ? pos > 0 : pos < len - 1;
+        nb_off = ex1 ? (int)((q6 & 1) ? -str : str) : 0;
+        an1 = a.mwapr[j + nb_off];
+        ap1 = a.mwapr[j];
+    }
+    // term q6 of cell c6 -> redbuf[tid] (dR/dx share, signed) and, with_val, redbuf[6 cpw + tid] (R share)
+    auto stencil_terms = [&](bool with_val) {
+        if (c6 < nc) {
+            const double v = xs[c6] - ap1;
+            const double t = (q6 & 1) ? (xn1 - an1) - v : v - (xn1 - an1);
+            double gt, vt;
+            if (a.kind == 1) {  // Smoothness (potential.py:786-796)
+                gt = 2.0 * t;
+                vt = t * t;
+            } else {  // TV (potential.py:798-810)
+                vt = sqrt(t * t + a.beta);
+                gt = t / vt;
+            }
+            redbuf[tid] = ex1 ? ((q6 & 1) ? -gt : gt) : 0.0;
+            if (with_val) redbuf[6 * cpw + tid] = (ex1 && !(q6 & 1)) ? vt : 0.0;
+        }
+    };
     auto evaluate = [&](bool last) -> bool {
+        // (thread-index arithmetic redone from an opaque copy per call: hoisted out of the
+        // trajectory loop, the addresses derived from it stay live across the whole kernel and
+        // push the register copy of the columns into scratch)
+        const int tid = res_opaque(tid_k), lane = tid & 63, i0 = 2 * tid;
+        const int c6 = tid / 6, q6 = tid - 6 * c6;
         __syncthreads();  // xs complete
         tick(0);
         const unsigned tag = a.tag0 + (unsigned)ev + 1u;
@@ -568,32 +628,17 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         // residual below, which hides the memory latency.  Any row of d depends on a partial of
         // every workgroup, and those were published after the workgroup's model stores had drained
         // (write-through); the loads bypass L1: no fence needed.
-        // Where the workgroup's cells times six fit its threads, thread 6 c + q takes term q (axis
+        // Thread 6 c + q takes term q (axis
         // q / 2, forward / backward) of cell c -- one square root and one division per lane
         // instead of six of each on a few lanes of wave 0 -- and the terms meet again in LDS, added
         // in the order reg_stencil_eval adds them.
-        double xn[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, an[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double xn1 = 0.0, an1 = 0.0, ap1 = 0.0;
-        bool ex1 = false;
-        const int c6 = tid / 6, q6 = tid - 6 * c6;
         if (stencil) ra.x = a.xpub + (int64_t)par * M;
-        if (stencil && spread) {
-            if (c6 < nc) {
-                const int64_t j = j0 + c6, P = (int64_t)a.nx * a.ny;
-                const int64_t ci = j % a.nx, cj = (j / a.nx) % a.ny, ck = j / P;
-                const int ax = q6 >> 1;
-                const int64_t pos = ax == 0 ? ci : ax == 1 ? cj : ck, len = ax == 0 ? a.nx : ax == 1 ? a.ny : a.nz;
-                const int64_t str = ax == 0 ? 1 : ax == 1 ? a.nx : P;
-                ex1 = (q6 & 1) ? pos > 0 : pos < len - 1;
-                const int64_t qn = ex1 ? ((q6 & 1) ? j - str : j + str) : j;
+        if (stencil) {
+            if (c6 < nc)
                 xn1 = __longlong_as_double((long long)__hip_atomic_load(
-                    reinterpret_cast<const unsigned long long *>(ra.x + qn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                an1 = a.mwapr[qn];
-                ap1 = a.mwapr[j];
-            }
+                    reinterpret_cast<const unsigned long long *>(ra.x + (j0 + c6 + nb_off)), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT));
             __builtin_amdgcn_sched_barrier(0);
-        } else if (stencil && tid < nc) {
-            reg_stencil_load<false, true>(ra, j0 + tid, xn, an);
         }
         // mean removal, residual, data misfit (potential.py:700-706)
         double s = 0.0;
@@ -619,21 +664,10 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
             r_s2[tid] = rv;
         }
         // regulariser of the own cells at xs, neighbours from the published model (requested above)
-        if (stencil && spread) {
-            if (c6 < nc) {
-                const double v = xs[c6] - ap1;
-                const double t = (q6 & 1) ? (xn1 - an1) - v : v - (xn1 - an1);
-                double gt, vt;
-                if (a.kind == 1) {  // Smoothness (potential.py:786-796)
-                    gt = 2.0 * t;
-                    vt = t * t;
-                } else {  // TV (potential.py:798-810)
-                    vt = sqrt(t * t + a.beta);
-                    gt = t / vt;
-                }
-                redbuf[tid] = ex1 ? ((q6 & 1) ? -gt : gt) : 0.0;
-                redbuf[6 * cpw + tid] = (ex1 && !(q6 & 1)) ? vt : 0.0;
-            }
+        if (stencil && !last) {
+            gr_pending = true;  // formed by the dots pass that follows
+        } else if (stencil) {
+            stencil_terms(true);
             __syncthreads();
             if (tid < nc) {
                 double g = 0.0;
@@ -643,8 +677,6 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 for (int q = 0; q < 6; q += 2) val += redbuf[6 * cpw + 6 * tid + q];
                 gr[tid] = a.alpha * g;
             }
-        } else if (stencil && tid < nc) {
-            gr[tid] = a.alpha * reg_stencil_eval(ra, j0 + tid, xs[tid] - apr_j, xn, an, val);
         }
         if (last) {
             ud = res_block_sum(acc, red);
@@ -659,6 +691,8 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     // full gradient and, what = 0: store it in gs; 1: leapfrog update with momentum coefficient
     // cu; 2: last half momentum step (returns this workgroup's sum of p^2, gradient in gs).
     auto dots = [&](int what, double cu) -> double {
+        const int tid = res_opaque(tid_k), lane = tid & 63, wave = tid >> 6;
+        const int c6 = tid / 6, q6 = tid - 6 * c6;
         __syncthreads();  // r_s, gr complete
         tick(11);
         // (unconditional reads -- the few doubles past r_s belong to redbuf -- then zeroed: selects
@@ -723,12 +757,21 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 }
             }
         }
+        if (gr_pending) stencil_terms(false);
         tick(12);
         __syncthreads();
         tick(13);
         double pp = 0.0;
         if (tid < nc) {
-            const double gs_j = gs[tid], gr_j = gr[tid], ps_j = ps[tid], xs_j = xs[tid];
+            double gr_j = gr[tid];
+            if (gr_pending) {
+                double g6 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) g6 += redbuf[6 * tid + q];
+                gr_j = a.alpha * g6;
+                gr[tid] = gr_j;
+            }
+            const double gs_j = gs[tid], ps_j = ps[tid], xs_j = xs[tid];
             const double chi = hi[tid], clo = lo[tid];
             __builtin_amdgcn_sched_barrier(0);
             const double g = 2.0 * gs_j + gr_j;
@@ -752,6 +795,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 gs[tid] = g;
             }
         }
+        gr_pending = false;
         tick(14);
         if (what != 2) return 0.0;
         return res_block_sum(pp, red);
@@ -846,7 +890,7 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         }
         if (timing) {
             tick(10);
-            for (int i = 0; i < 16; ++i) a.dbg[(w == 0 ? 0 : 16) + i] += tacc[i];
+            for (int i = 0; i < 16; ++i) a.dbg[(w == 0 ? 0 : 16) + i] += tacc_s[i];
         }
     };
 
