@@ -114,13 +114,6 @@ static inline bool resident_stencil_fits(int cols_per_wg)
     return 6 * cols_per_wg <= RES_THREADS && 12 * cols_per_wg <= RES_REDBUF;
 }
 
-// the value, unknown to the optimiser (keeps what is derived from it where it is written)
-__device__ __forceinline__ int res_opaque(int v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 // 8-byte write-through store (global_store_dwordx2 sc1)
 __device__ __forceinline__ void st_wt(double *p, double v)
 {
@@ -247,7 +240,6 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tid_k = tid;
     const int w = blockIdx.x;
     const int ld = (int)a.ld, ld2 = ld >> 1;
     const int cpw = a.cols_per_wg;
@@ -448,11 +440,6 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
         }
     };
     auto evaluate = [&](bool last) -> bool {
-        // (thread-index arithmetic redone from an opaque copy per call: hoisted out of the
-        // trajectory loop, the addresses derived from it stay live across the whole kernel and
-        // push the register copy of the columns into scratch)
-        const int tid = res_opaque(tid_k), lane = tid & 63, i0 = 2 * tid;
-        const int c6 = tid / 6, q6 = tid - 6 * c6;
         __syncthreads();  // xs complete
         tick(0);
         const unsigned tag = a.tag0 + (unsigned)ev + 1u;
@@ -691,8 +678,6 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
     // full gradient and, what = 0: store it in gs; 1: leapfrog update with momentum coefficient
     // cu; 2: last half momentum step (returns this workgroup's sum of p^2, gradient in gs).
     auto dots = [&](int what, double cu) -> double {
-        const int tid = res_opaque(tid_k), lane = tid & 63, wave = tid >> 6;
-        const int c6 = tid / 6, q6 = tid - 6 * c6;
         __syncthreads();  // r_s, gr complete
         tick(11);
         // (unconditional reads -- the few doubles past r_s belong to redbuf -- then zeroed: selects
