@@ -75,6 +75,9 @@ EXTRA = {
     # C5: 200 x 200 x 60 prisms (M = 2.4e6), 200 x 200 obs (N = 4e4): G = 768 GB, one chain sharded
     # over 8 GPUs (--shard).  On one GPU use --cells-fraction 8: the 96 GB share one rank holds.
     "c5_uniform_200x200x60": dict(kind=0, reg="MS", alpha=1.0, beta=0.001, dt=0.001, hi=1.0, wavelet=0),
+    # the size of the reference's realdata example (625 x 10427, 52 MB) as prisms: larger than the
+    # LDS alone, the resident chain kernel keeps part of every column block in registers
+    "x1_prisms_625x10400": dict(kind=0, reg="MS", alpha=1.0, beta=0.001, dt=0.01, hi=1.0, wavelet=0),
 }
 
 
@@ -87,6 +90,12 @@ def make_extra(name):
         obs = (xp, yp, np.zeros_like(xp))
         rho = np.zeros(mesh.shape)
         rho[2:5, 10:18, 7:11] = 1.0
+    elif name == "x1_prisms_625x10400":
+        mesh = mesher.PrismMesh((0, 2600, 0, 2000, 0, 2000), (100, 100, 100))
+        yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 2000, 25), np.linspace(0, 2600, 25))]
+        obs = (xp, yp, np.zeros_like(xp))
+        rho = np.zeros(mesh.shape)
+        rho[4:9, 7:13, 10:16] = 1.0
     elif name == "c5_uniform_200x200x60":
         mesh = mesher.PrismMesh((0, 20000, 0, 20000, 0, 6000), (100, 100, 100))
         yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 20000, 200), np.linspace(0, 20000, 200))]

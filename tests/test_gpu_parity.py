@@ -762,6 +762,42 @@ def test_resident_chain_kernel_shapes(G, monkeypatch, N, M):
     assert relmax(bx, ax) < 1e-11
 
 
+def test_resident_chain_kernel_leaves_wide_stencil_shapes_to_the_sweep_path(G, monkeypatch):
+    """Smoothness / TV take one thread per (cell, neighbour) in the resident kernel: with more than 85
+    cells per workgroup (few observations, many cells) such a chain runs on the sweep path -- same
+    results as with the kernel switched off -- while a cell-local regulariser on the same context
+    uses the resident kernel."""
+    N, M, shape = 64, 24000, (10, 40, 60)       # 94 cells per workgroup
+    rng = np.random.default_rng(4242)
+    A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.2, 2.0, size=M))
+    dobs = rng.normal(size=N) * 3
+    trajs = [(int(rng.integers(1, 5)), rng.normal(size=M) * 0.05, float(rng.uniform())) for _ in range(6)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GRAVHMC_RESIDENT", mode)
+        e = G.Engine(N, M)
+        e.upload_G(A)
+        w = e.weight(0.5)
+        e.set_data(dobs)
+        e.set_reg("TV", 0.7, 0.01, shape, 0.001 * w)
+        e.chain_init(0.002 * w, 0.0 * w, 0.5 * w)
+        out = []
+        e.run_chain(iter(trajs), 0.01, lambda L, acc, o, x: out.append((acc, o.copy())), batch=3)
+        launches_tv = e.chain_stats()["resident_launches"]
+        x_tv = e.chain_get_x()
+        e.set_reg("Damping", 0.7, 0.01, None, 0.001 * w)
+        e.chain_init(0.002 * w, 0.0 * w, 0.5 * w)
+        e.run_chain(iter(trajs), 0.01, lambda L, acc, o, x: None, batch=3)
+        res[mode] = (out, x_tv, launches_tv, e.chain_stats()["resident_launches"])
+        e.close()
+    (a, ax, la_tv, la_d), (b, bx, lb_tv, lb_d) = res["0"], res["1"]
+    assert la_tv == 0 and la_d == 0
+    assert lb_tv == 0 and lb_d > 0
+    for (a1, o1), (a2, o2) in zip(a, b):
+        assert a1 == a2 and np.array_equal(o1, o2)
+    assert np.array_equal(ax, bx)
+
+
 def test_resident_chain_kernel_times_out_cleanly(G, monkeypatch, capfd):
     """Every wait inside the resident kernel is bounded.  With the test hook the workgroups wait for
     partners that never run: the kernel gives up after 2 s without touching the chain, the context
