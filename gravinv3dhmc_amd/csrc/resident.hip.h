@@ -18,12 +18,21 @@
 //   level 2      the chunk's eight cluster sums cross the XCDs once (write-through); every cluster's
 //                owner adds them in the same order -> the same d everywhere
 //   level 3      every workgroup reads d from its cluster's copy, removes the mean and forms r
-//                redundantly (potential.py:700-706: identical bits everywhere), evaluates the
-//                regulariser gradient of its own cells
-//   trajectory   last half momentum step, one all-gather of three scalars per workgroup
-//   end          (R, p'p before/after), Metropolis test (hmc.py:158-177) decided identically by
-//                every workgroup; the gradient at the proposal is kept for the next trajectory,
-//                so a trajectory of L steps costs exactly L evaluations
+//                redundantly (potential.py:700-706: identical bits everywhere); regulariser gradient
+//                of its own cells (Smoothness / TV: one thread per (cell, neighbour), the neighbour
+//                requested from the published model as soon as d is in, the terms formed by the
+//                next dots pass)
+//   trajectory   last half momentum step; three scalars per workgroup (R, p'p before/after) summed
+//   end          over the cluster by its member 0, the eight cluster sums read by everybody;
+//                Metropolis test (hmc.py:158-177) decided identically by every workgroup; the
+//                gradient at the proposal is kept for the next trajectory, so a trajectory of L
+//                steps costs exactly L evaluations
+//
+// The kernel is bound by latency (SQ counters in profiles/r01: VALU 6 %, LDS 3 % busy, 1 % bank
+// conflicts), so what matters inside a workgroup is how many dependent round trips a step makes:
+// LDS and global reads are issued in batches in front of scheduling fences
+// (__builtin_amdgcn_sched_barrier) -- at 256 VGPRs the scheduler otherwise orders read, wait, use
+// one by one.
 //
 // Inter-workgroup hand-offs: the data is the flag.  A double travels as two naturally aligned
 // 8-byte granules {tag = evaluation number, 32 bits of the value}, each written by ONE store and
@@ -32,7 +41,7 @@
 // buffer is only overwritten after every reader has published something that depends on having
 // read it (the cross-XCD sums are double-buffered by evaluation parity).  Measured steps from the
 // first version (arrival counters + agent-scope acquires, 19.9 us per evaluation at C1) to this
-// one (7.1 us): DESIGN.md 4.5.  Every spin is bounded: on a time-out the abort word is raised,
+// one (6.4 us): DESIGN.md 4.5.  Every spin is bounded: on a time-out the abort word is raised,
 // every workgroup leaves and the host falls back to the sweep path.  The grid (one workgroup per
 // CU by the LDS request) is checked against the occupancy query on the host.
 #pragma once
