@@ -762,6 +762,39 @@ def test_resident_chain_kernel_shapes(G, monkeypatch, N, M):
     assert relmax(bx, ax) < 1e-11
 
 
+@pytest.mark.parametrize("switch", ["GRAVHMC_RESIDENT_LOCAL", "GRAVHMC_RESIDENT_REGS"])
+@pytest.mark.parametrize("reg", ["Damping", "TV"])
+def test_resident_chain_kernel_fallback_forms(G, monkeypatch, switch, reg):
+    """The two forms of the resident kernel a placement or a shape can force: cluster-internal data
+    written through to memory instead of kept in the XCD's L2 (what the kernel does when the
+    workgroups of a cluster do not report the same XCC id), and the dots reading the columns from
+    LDS instead of a register copy.  Bit for bit the chain of the default form (the reduction order is
+    defined by logical indices only)."""
+    p = gold("potential_small.npz")
+    wm = p["wm"]
+    M = wm.size
+    rng = np.random.default_rng(77)
+    trajs = [(int(rng.integers(1, 9)), rng.normal(size=M) * 0.3, float(rng.uniform())) for _ in range(16)]
+    res = {}
+    for val in ("1", "0"):
+        monkeypatch.setenv("GRAVHMC_RESIDENT", "1")
+        monkeypatch.setenv(switch, val)
+        gm = _module_small(G, p)
+        eng = gm._engine
+        eng.set_reg(reg, 1.0, 0.001, p["shape"], 0.001 * wm)
+        eng.chain_init(0.001 * wm, 0.0 * wm, 0.02 * wm)
+        out = []
+        eng.run_chain(iter(trajs), 0.02, lambda L, acc, o, x: out.append((acc, o.copy())), batch=5)
+        res[val] = (out, eng.chain_get_x(), eng.chain_stats()["resident_launches"])
+        eng.close()
+    (a, ax, la), (b, bx, lb) = res["1"], res["0"]
+    assert la > 0 and lb > 0
+    assert 0 < sum(t[0] for t in a)
+    for (a1, o1), (a2, o2) in zip(a, b):
+        assert a1 == a2 and np.array_equal(o1, o2)
+    assert np.array_equal(ax, bx)
+
+
 def test_resident_chain_kernel_leaves_wide_stencil_shapes_to_the_sweep_path(G, monkeypatch):
     """Smoothness / TV take one thread per (cell, neighbour) in the resident kernel: with more than 85
     cells per workgroup (few observations, many cells) such a chain runs on the sweep path -- same
