@@ -66,15 +66,26 @@ static bool resident_plan(gh_ctx *c)
         // (register) copy of Aw
         if (c->wv.on && (r.ct == 0 || wavelet_dense_form(c) != GH_OK)) return false;
     } else {
-        // too large for the LDS alone: ONE copy, as many columns as the registers take (up to 20
-        // double2 per lane) with the waves, the rest in LDS next to 8 x ld doubles of scratch
+        // too large for the LDS alone: ONE copy, the first 8 ct columns of a workgroup with the waves
+        // (registers: up to 20 double2 per lane), the rest in LDS next to 8 x ld doubles of scratch.
+        // As few register columns as the LDS allows: their forward share goes through per-wave
+        // partials and an LDS sum (measured at 625 x 10400: ct 3 -> 7.9, ct 4 -> 8.4 us per evaluation).
         if (!regs || c->wv.on) return false;
-        r.ct = std::min(4, 20 / r.rc);
-        if (r.ct < 1) return false;
-        r.lds_cols = std::max(0, cpw - r.ct * RES_WAVES);
+        const int ct_max = std::min(4, 20 / r.rc);
+        const int ct_env = env_int("GRAVHMC_RESIDENT_CT", 0);  // diagnostic: force the number
         r.split = true;
-        lds = resident_lds_doubles(c->ld, cpw, 1, r.lds_cols, true) * sizeof(double);
-        if (lds > (size_t)lds_max) return false;
+        r.ct = 0;
+        for (int ct = 1; ct <= ct_max; ++ct) {
+            if (ct_env > 0 && ct != std::min(ct_env, ct_max)) continue;
+            const int lc = std::max(0, cpw - ct * RES_WAVES);
+            lds = resident_lds_doubles(c->ld, cpw, 1, lc, true) * sizeof(double);
+            if (lds <= (size_t)lds_max) {
+                r.ct = ct;
+                r.lds_cols = lc;
+                break;
+            }
+        }
+        if (r.ct < 1) return false;
     }
     r.lds = lds;
     resident_fn f = resident_for(r.rc, r.ct);
