@@ -98,5 +98,6 @@ static int shard_common_init(gh_ctx *c, int rank, int world, int64_t M_global, i
     c->sh.buf_n = (size_t)c->ld + 8;
     c->chain_ready = false;
     c->bt.ready = false;
+    c->rs.state = 0;  // a context that ran unsharded before must not keep the resident chain kernel
     return GH_OK;
 }

@@ -166,6 +166,8 @@ struct gh_ctx {
         bool b_on = false, b_state = false;
         double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
         int64_t launches = 0, evals = 0;
+        int aborts = 0;               // launches that timed out (3: the context stays on the sweep path)
+        bool granules_dirty = false;  // an aborted launch left tags behind: clear before the next launch
         long long *dbg = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
     } rs;

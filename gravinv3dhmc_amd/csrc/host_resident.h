@@ -172,16 +172,18 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     }
     int64_t steps = 0;
     for (int k = 0; k < K; ++k) steps += q.L[k];
-    if ((uint64_t)r.tag + (uint64_t)steps + (uint64_t)q.C + 2 > 0xf0000000ull ||
+    if (r.granules_dirty || (uint64_t)r.tag + (uint64_t)steps + (uint64_t)q.C + 2 > 0xf0000000ull ||
         (uint64_t)r.tagE + (uint64_t)K + (uint64_t)q.C + 2 > 0xf0000000ull) {
-        // 32-bit tags about to wrap: start the count again on zeroed granules
-        HIPCHK(c, hipMemsetAsync(r.slabg, 0, (size_t)r.nwg * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
+        // 32-bit tags about to wrap, or an aborted launch left granules carrying tags this launch
+        // would use again: start the count again on zeroed granules
+        HIPCHK(c, hipMemsetAsync(r.slabg, 0, (size_t)(r.nwg + 8) * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.xslabg, 0, 2 * (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.dclg, 0, (size_t)RES_CLUSTERS * (size_t)c->ld * 2 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.scalg, 0, (size_t)r.nwg * 8 * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.scalg, 0, (size_t)(r.nwg + 8) * 8 * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.xscalg, 0, (size_t)RES_CLUSTERS * 8 * sizeof(ghk::u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.xccg, 0, (size_t)r.nwg * sizeof(ghk::u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.xccg, 0, ((size_t)r.nwg + 8) * sizeof(ghk::u64), c->stream));
         r.tag = r.tagE = 0;
+        r.granules_dirty = false;
     }
     HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
     HIPCHK(c, hipMemcpyAsync(r.p0s, q.p0s, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -256,11 +258,17 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h_sync[0] != 0u) {
         // A workgroup waited 2 s for the others: they were not all resident (another process holding
-        // compute units of this device).  Nothing of the chain state was written; this context goes
-        // back to the sweep-per-launch path for good and the caller's batch is run there.
-        r.state = -1;
-        fprintf(stderr, "libgravhmc: resident chain kernel timed out waiting for its workgroups; "
-                        "continuing on the sweep-per-launch path\n");
+        // compute units of this device).  Nothing of the chain state was written; the caller's batch
+        // is run on the sweep-per-launch path.  A transient stall does not downgrade the context:
+        // the next batch tries the resident kernel again (on cleared exchange buffers); after three
+        // aborted launches the context stays on the sweep path.
+        r.aborts += 1;
+        r.granules_dirty = true;
+        const bool for_good = r.aborts >= 3;
+        if (for_good) r.state = -1;
+        fprintf(stderr, "libgravhmc: resident chain kernel timed out waiting for its workgroups (%d of 3); "
+                        "%s on the sweep-per-launch path\n", r.aborts,
+                for_good ? "continuing for good" : "running this batch");
         return GH_RESIDENT_ABORTED;
     }
     r.tag += (unsigned)h_run[1];

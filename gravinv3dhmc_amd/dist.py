@@ -241,6 +241,14 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
         def _full_vec(self, v):
             return self._full(v)
 
+        def run_chain(self, draws, dt, on_result, **kw):
+            # Host-staged (gloo) all-reduce: the library's per-step callback and the all_gather of
+            # _full_vec use ONE process group; issued from two threads their order would differ
+            # across ranks (mismatched collectives).  No batch may run while results are gathered.
+            if backend != "rccl":
+                kw["overlap"] = False
+            return Engine.run_chain(self, draws, dt, on_result, **kw)
+
         def posterior_read(self, want_arrays=True):
             out = Engine.posterior_read(self, want_arrays)
             if want_arrays:

@@ -61,6 +61,19 @@ class Engine(object):
     def _chk(self, rc):
         check(rc, self._h)
 
+    def _vecM(self, v, what):
+        """Contiguous float64 copy/view of a model vector; the library copies exactly M doubles."""
+        v = f64(v)
+        if v.shape != (self.M,):
+            raise ValueError("%s must have M = %d entries, got shape %r" % (what, self.M, v.shape))
+        return v
+
+    def _vecN(self, v, what):
+        v = f64(v)
+        if v.shape != (self.N,):
+            raise ValueError("%s must have N = %d entries, got shape %r" % (what, self.N, v.shape))
+        return v
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, mem = C.c_int(0), C.c_int64(0)
@@ -132,21 +145,22 @@ class Engine(object):
         self._chk(self._lib.gh_set_reg(self._h, _lib.REG_KINDS[regularization], float(alpha),
                                        float(beta), shp, ptr(mwapr)))
         self._chain_valid = False
+        self._reg_key = None   # (GravMagModule._use_reg records what it sent after this call)
 
     def forward(self, mw):
-        mw = f64(mw)
+        mw = self._vecM(mw, "mw")
         d = np.empty(self.N)
         self._chk(self._lib.gh_forward(self._h, ptr(mw), ptr(d)))
         return d
 
     def adjoint(self, r):
-        r = f64(r)
+        r = self._vecN(r, "r")
         g = np.empty(self.M)
         self._chk(self._lib.gh_adjoint(self._h, ptr(r), ptr(g)))
         return g
 
     def misfit_and_grad(self, x):
-        x = f64(x)
+        x = self._vecM(x, "x")
         out3, grad, dpre = np.empty(3), np.empty(self.M), np.empty(self.N)
         self._chk(self._lib.gh_misfit_and_grad(self._h, ptr(x), ptr(out3), ptr(grad), ptr(dpre)))
         return out3[0], grad, dpre, out3[1], out3[2]
@@ -156,7 +170,7 @@ class Engine(object):
         """(value, grad) of one regulariser alone (alpha = 1)."""
         if regularization not in _lib.REG_KINDS:
             raise ValueError("Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.")
-        mw, mwapr = f64(mw), f64(mwapr)
+        mw, mwapr = self._vecM(mw, "mw"), self._vecM(mwapr, "mwapr")
         shp = (C.c_int * 3)(*[int(s) for s in shape]) if shape is not None else None
         val = C.c_double(0)
         grad = np.empty(self.M) if want_grad else None
@@ -185,25 +199,25 @@ class Engine(object):
         return csr_matrix((data[:n], indices[:n], indptr), shape=(self.N, self.wavelet_ncols))
 
     def model_coeffs(self, mw):
-        mw = f64(mw)
+        mw = self._vecM(mw, "mw")
         out = np.empty(self.wavelet_ncols)
         self._chk(self._lib.gh_model_coeffs(self._h, ptr(mw), ptr(out)))
         return out
 
     def forward_wavelet(self, mw):
-        mw = f64(mw)
+        mw = self._vecM(mw, "mw")
         d = np.empty(self.N)
         self._chk(self._lib.gh_forward_wavelet(self._h, ptr(mw), ptr(d)))
         return d
 
     # -- chain --------------------------------------------------------------------
     def chain_init(self, x0, low, high):
-        x0, low, high = f64(x0), f64(low), f64(high)
+        x0, low, high = self._vecM(x0, "x0"), self._vecM(low, "low"), self._vecM(high, "high")
         self._chk(self._lib.gh_chain_init(self._h, ptr(x0), ptr(low), ptr(high)))
         self._chain_valid = True
 
     def chain_trajectory(self, p0, dt, L, u):
-        p0 = f64(p0)
+        p0 = self._vecM(p0, "p0")
         acc = C.c_int(0)
         out5 = np.empty(5)
         self._chk(self._lib.gh_chain_trajectory(self._h, ptr(p0), float(dt), int(L), float(u),
@@ -211,7 +225,7 @@ class Engine(object):
         return bool(acc.value), out5
 
     def chain_prefetch_momentum(self, p0_next):
-        p0_next = f64(p0_next)
+        p0_next = self._vecM(p0_next, "p0_next")
         self._chk(self._lib.gh_chain_prefetch_momentum(self._h, ptr(p0_next)))
 
     def chain_stats(self):
@@ -226,12 +240,12 @@ class Engine(object):
         """Arguments of one gh_chain_run call over a list of (L, p0, u), marshalled on the calling
         thread (the 4 MB per momentum of C2 are copied here, not between two batches on the GPU)."""
         K = len(batch)
-        p0s = np.ascontiguousarray(np.stack([self._loc_vec(b[1]) for b in batch]))
+        p0s = np.ascontiguousarray(np.stack([self._vecM(self._loc_vec(b[1]), "p0") for b in batch]))
         return {"K": K, "Ls": (C.c_int * K)(*[int(b[0]) for b in batch]), "p0s": p0s,
                 "us": np.ascontiguousarray([float(b[2]) for b in batch], dtype=np.float64),
-                "look": self._loc_vec(lookahead[1]) if lookahead is not None else None,
+                "look": self._vecM(self._loc_vec(lookahead[1]), "p0") if lookahead is not None else None,
                 "acc": (C.c_int * K)(), "out5": np.empty((K, 5)),
-                "xs": np.empty((K, p0s.shape[1])) if want_x else None, "n_run": C.c_int(0)}
+                "xs": np.empty((K, self.M)) if want_x else None, "n_run": C.c_int(0)}
 
     def _run_batch(self, batch, lookahead, dt, stop_at, record_from, want_x, prepared=None, entered=None):
         """One gh_chain_run call over a list of (L, p0, u); returns per-trajectory results.
@@ -350,8 +364,10 @@ class Engine(object):
     # -- several chains per GPU (MFMA) ----------------------------------------------
     def batch_init(self, x0s, low, high):
         x0s = np.ascontiguousarray(np.atleast_2d(x0s), dtype=np.float64)
+        if x0s.ndim != 2 or x0s.shape[1] != self.M:
+            raise ValueError("x0s must be (C, M)")
         self._batch_C = x0s.shape[0]
-        low, high = f64(low), f64(high)
+        low, high = self._vecM(low, "low"), self._vecM(high, "high")
         self._chk(self._lib.gh_batch_init(self._h, self._batch_C, ptr(x0s), ptr(low), ptr(high)))
 
     def batch_trajectory(self, p0s, dt, Ls, us):
@@ -418,8 +434,8 @@ class Engine(object):
         return {"n": n.value, "total": tot.value, "mean": mean, "std": sd}
 
     def leapfrog(self, x, p0, dt, L, low, high, u, want_dsyn=True):
-        x = f64(x).copy()
-        p0, low, high = f64(p0), f64(low), f64(high)
+        x = self._vecM(x, "x").copy()
+        p0, low, high = self._vecM(p0, "p0"), self._vecM(low, "low"), self._vecM(high, "high")
         acc = C.c_int(0)
         out5 = np.empty(5)
         dsyn = np.empty(self.N) if want_dsyn else None

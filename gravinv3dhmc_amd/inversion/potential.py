@@ -175,16 +175,21 @@ class GravMagModule(object):
         if regulization not in _lib.REG_KINDS:
             raise ValueError("Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.")
         mwapr = np.asarray(mwapr, dtype=np.float64)
-        key = (regulization, float(alpha), float(beta), mwapr.ctypes.data, mwapr.shape[0],
-               float(mwapr[0]), float(mwapr[-1]), float(mwapr.sum()))
-        if key != self._engine._reg_key:
+        # The decision to (re)send the regulariser must be the same on every rank of a sharded
+        # model (gh_set_reg is collective there) and must notice in-place edits: it depends only
+        # on the VALUES -- kind, alpha, beta and the content of the full mwapr vector (one
+        # memcmp-speed comparison against the copy sent last), never on addresses.
+        key = (regulization, float(alpha), float(beta))
+        last = self._engine._reg_key
+        if last is None or last[0] != key or last[1].shape != mwapr.shape or \
+                not np.array_equal(last[1], mwapr):
             m_model = getattr(self._engine, "M_global", self._engine.M)
             if regulization in ("Smoothness", "TV") and int(np.prod(self.mshape)) != m_model:
                 raise ValueError("Smoothness/TV need the full (uncarved) mesh: shape %r has %d "
                                  "cells, model has %d" % (self.mshape, int(np.prod(self.mshape)),
                                                           m_model))
             self._engine.set_reg(regulization, alpha, beta, self.mshape, mwapr)
-            self._engine._reg_key = key
+            self._engine._reg_key = (key, mwapr.copy())
 
     def misfit_and_grad(self, x, mwapr, low, high, constraint, log_fator, alpha,
                         regulization='Damping', beta=0.01):

@@ -1,0 +1,113 @@
+"""Worker of tests/test_gpu_parity.py::test_c5_shaped_row_panels_and_column_shards_together: three
+ranks share GPU 0; N = 4*10^4 observations (the C5 grid), 4800 cells of the C5 mesh in three
+z-planes, one plane per rank; all-reduces over gloo.  Rank 0 also runs the unsharded engine and the
+CPU oracle on the same cells and compares."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from gravinv3dhmc_amd.dist import Ranks, make_sharded_engine  # noqa: E402  (imports torch first)
+import gravinv3dhmc_amd as g  # noqa: E402
+from helpers import relmax  # noqa: E402
+
+
+def c5_block():
+    """40 x 40 x 3 cells of the 200 x 200 x 60 mesh (same bounds as in the full mesh: x0 + i dx with
+    integer metres), the full 200 x 200 observation grid on z = 0."""
+    mesh = g.mesher.PrismMesh((8000, 12000, 8000, 12000, 0, 300), (100, 100, 100))
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 20000, 200), np.linspace(0, 20000, 200))]
+    return mesh, xp, yp, np.zeros_like(xp)
+
+
+def setup(eng, mesh, xp, yp, zp, rho, noise):
+    eng.set_obs(xp, yp, zp)
+    eng.set_cells(mesh.cell_bounds(), 0)
+    eng.build_G()
+    d_true = eng.forward(rho)
+    wm = eng.weight(0.5)
+    dobs = d_true + noise * np.abs(d_true).max()
+    eng.set_data(dobs)
+    return d_true, wm, dobs
+
+
+def main():
+    ranks = Ranks()
+    ranks.local_rank = 0  # all ranks on GPU 0
+    mesh, xp, yp, zp = c5_block()
+    N, M = xp.size, mesh.size
+    rng = np.random.default_rng(55)
+    rho = np.zeros(mesh.shape)
+    rho[1:3, 10:30, 15:25] = 1.0
+    rho = rho.ravel()
+    noise = 0.02 * rng.normal(size=N)
+    x_test = rng.uniform(0, 1, M)
+    trajs = [(int(rng.integers(1, 7)), rng.normal(size=M) * 0.02, float(rng.uniform())) for _ in range(5)]
+    P = mesh.shape[1] * mesh.shape[2]
+    sh = make_sharded_engine(N, M, ranks, device=0, backend="gloo", align=P)
+    d_true, wm, dobs = setup(sh, mesh, xp, yp, zp, rho, noise)
+    low, high = 0.0 * wm, 0.3 * wm
+    got = {"sharded": {}}
+
+    def run(eng, store):
+        for reg in ("MS", "TV"):
+            eng.set_reg(reg, 0.7, 0.001, mesh.shape, 0.001 * wm)
+            store[reg] = eng.misfit_and_grad(x_test * wm)
+        eng.set_reg("MS", 0.7, 0.001, mesh.shape, 0.001 * wm)
+        eng.chain_init(0.001 * wm, low, high)
+        res = []
+        eng.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res.append((acc, o.copy(), xs)), want_x=True,
+                      batch=2)
+        store["chain"] = res
+
+    run(sh, got["sharded"])
+    info = {"M_local": ranks.gather(sh.M_local)}
+    ranks.barrier()
+    if ranks.rank == 0:
+        from oracle import oracle as orc
+        single = g.Engine(N, M)
+        d1, wm1, dobs1 = setup(single, mesh, xp, yp, zp, rho, noise)
+        assert np.array_equal(dobs1, dobs) or relmax(dobs1, dobs) < 1e-12
+        single.set_data(dobs)
+        got["single"] = {}
+        run(single, got["single"])
+        K = orc.prism_gz_kernel(xp, yp, zp, mesh.cell_bounds())
+        out = {"N": int(N), "M_local": info["M_local"], "fwd": relmax(d_true, K @ rho)}
+        Aw, wmo = orc.col_weight(K)
+        del K
+        out["wm"] = relmax(wm, wmo)
+        out["n_panels"] = 2 if N > 16384 else 1
+        ref = {}
+        for reg in ("MS", "TV"):
+            Pr = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.7, 0.001, wm=wm, shape=mesh.shape)
+            ref[reg] = Pr.misfit_and_grad(x_test * wm)
+        Pr = orc.Problem(Aw, dobs, 0.001 * wm, "MS", 0.7, 0.001, wm=wm, shape=mesh.shape)
+        xo, chain_ref = 0.001 * wm, []
+        for (L, p0, u) in trajs:
+            xo, acco, oo, _ = Pr.leapfrog(xo, p0, 0.002, L, low, high, u)
+            chain_ref.append((acco, oo.copy(), xo.copy()))
+        for tag in ("sharded", "single"):
+            o = {}
+            for reg in ("MS", "TV"):
+                a, b = got[tag][reg], ref[reg]
+                o[reg] = {"U": abs(a[0] - b[0]) / abs(b[0]), "grad": relmax(a[1], b[1]), "dpre": relmax(a[2], b[2])}
+            res = got[tag]["chain"]
+            o["chain"] = {"n": len(res),
+                          "decisions_equal": [r[0] for r in res] == [c[0] for c in chain_ref],
+                          "out5": max(relmax(r[1], c[1]) for r, c in zip(res, chain_ref)),
+                          "x": max([relmax(r[2], c[2]) for r, c in zip(res, chain_ref) if r[0]] or [0.0])}
+            out[tag] = o
+        single.close()
+        print("RESULT " + json.dumps(out))
+    ranks.barrier()
+    sh.close()
+    ranks.close()
+
+
+if __name__ == "__main__":
+    main()
