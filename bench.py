@@ -36,6 +36,16 @@ WORKLOADS = {
 }
 
 
+#: fp64 vector peak of MI355X: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz (half the
+#: FP32 vector rate of MI355X_MICROARCH.md's table, AMD's datasheet figure)
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+#: operation counts of the reference's formulas as written
+FLOPS_PER_TESS_LEAF = 244      # _tesseroid_numba.py:94-111 (49) + :135-157 (3) + :75-91,207-222 (192)
+FLOPS_PER_PRISM_ENTRY = 194    # _prism.pyx:265-290: 8 corners x (3 + 6 + 4 + 3 + 6 + 2) + 2
+FLOPS_PER_TESS_PAIR_HOISTED = 146  # per pair and step once the cell-only part is tabulated: 2 x (sub, cos)
+                                   # + 4 cospsi x 4 + 8 nodes x 15 + r^2 + sign, scale, sum, 2 unit factors
+
+
 def pmc_traffic(workload):
     """HBM bytes per sweep launch from the committed rocprofv3 PMC summary (profiles/rNN/),
     corrected as MI355X_MICROARCH.md prescribes; None when no profile of this workload exists."""
@@ -429,9 +439,44 @@ def main():
                 "fp64_matrix_TFLOPs": 4.0 * N * M * 16 * prof["sweeps"] / 2 / (prof["sweep_ms"] * 1e-3) / 1e12,
                 "reference_formulation_equiv_GBps": 2 * bytes_sweep * CPG * args.steps / elapsed / 1e9})
         if args.matrix_free:
-            line["roofline"].update({"bound": "fp64 transcendental throughput (no stored G)",
-                                     "achieved": None, "frac": None, "traffic": None,
-                                     "pair_evaluations_per_step": 2 * int(N) * int(M)})
+            # no stored G: the pass is bound by fp64 vector arithmetic.  FLOP model: the
+            # operations of the reference's formulas as written, every +, -, *, /, sqrt and
+            # trigonometric / logarithm call counted as ONE flop, times the work the kernel counted
+            # itself (GLQ leaves of the adaptive tesseroid engine / prism entries).
+            st = eng.matrix_free_stats()
+            tess = extra["kind"] == 1
+            near = tess and st["near_entries"] > 0
+            # executed per entry: prisms the whole entry; tesseroids the root leaf (with the near-field
+            # table: the leaf's pair-dependent part only -- what depends on the cell alone and the
+            # distance/size test are evaluated once at build time) or the adaptive engine's leaves
+            per_unit = (FLOPS_PER_TESS_PAIR_HOISTED if near else FLOPS_PER_TESS_LEAF) if tess \
+                else FLOPS_PER_PRISM_ENTRY
+            timed_launches = max(1, prof["sweeps"])
+            share = timed_launches / max(1, st["launches"])   # (events cover at most 4096 launches)
+            units = (st["entries"] if near else st["leaves"]) * share
+            secs = prof["sweep_ms"] * 1e-3
+            tflops = units * per_unit / secs / 1e12 if secs > 0 else None
+            # the same step priced as the reference formulates it: every pair through the adaptive
+            # engine (distance/size test + leaf, 244 flop per GLQ leaf)
+            ref_leaves = (st["entries"] - st["near_entries"] * st["launches"] + st["near_leaves"] * st["launches"]) \
+                if near else st["leaves"]
+            ref_unit = FLOPS_PER_TESS_LEAF if tess else FLOPS_PER_PRISM_ENTRY
+            line["roofline"] = {
+                "bound": "fp64 vector (no stored G: entries re-evaluated, every entry once per step)",
+                "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP64_VECTOR_PEAK_TFLOPS if tflops else None, "traffic": None,
+                "kernel": "mf_fused_kernel (entries of a cell's column evaluated once, dot with r, "
+                          "leapfrog update, forward accumulation)",
+                "launches": st["launches"], "avg_ms": sweep_ms,
+                "entries_per_launch": st["entries"] / max(1, st["launches"]),
+                "leaves_per_launch": st["leaves"] / max(1, st["launches"]),
+                "near_field_table": {"entries": st["near_entries"], "glq_leaves": st["near_leaves"],
+                                     "bytes": st["near_entries"] * 12} if tess else None,
+                "flop_model": "%d flop per %s (formulas as written; +, -, *, /, sqrt, cos, log, atan2 = 1 flop each)"
+                              % (per_unit, ("entry: pair-dependent part of the root GLQ leaf" if near else
+                                            "GLQ leaf incl. its distance/size test") if tess else "prism entry"),
+                "entries_per_s": st["entries"] * share / secs if secs > 0 else None,
+                "reference_formulation_equiv_TFLOPs": ref_leaves * share * ref_unit / secs / 1e12 if secs > 0 else None}
         if not args.no_cpu_baseline and world == 1 and args.workload in WORKLOADS:
             try:
                 line["cpu_baseline"] = cpu_baseline(mesh, xp, yp, zp, dobs)

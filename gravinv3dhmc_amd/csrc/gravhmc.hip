@@ -149,15 +149,7 @@ int gh_set_matrix_free(gh_ctx *c, int enable)
 {
     if (!c) return GH_ERR_ARG;
     if (c->have_G || c->slab) return fail(c, GH_ERR_ARG, "gh_set_matrix_free: call before gh_build_G");
-    c->mf = enable != 0;
-    if (c->mf) {
-        // partition used by the matrix-free passes: one wave per cell (adjoint), chunks of
-        // cells per forward partial
-        c->n_teams = (int)((c->M + 3) / 4);
-        const int64_t chunks = std::min<int64_t>(c->M, std::max<int64_t>(1, (int64_t)c->cus * 16 / std::max<int64_t>(1, (c->ld + 255) / 256)));
-        c->mf_cells_per_chunk = (c->M + chunks - 1) / chunks;
-        c->grid = (int)((c->M + c->mf_cells_per_chunk - 1) / c->mf_cells_per_chunk);
-    }
+    c->mf = enable != 0;  // (the passes are partitioned in gh_build_G, once the cell kind is known)
     return GH_OK;
 }
 
@@ -169,6 +161,8 @@ int gh_build_G(gh_ctx *c)
     c->warn_cells = 0;
     c->leaves = 0;
     if (c->mf) {
+        if (c->slab) return fail(c, GH_ERR_ARG, "gh_build_G: a matrix-free context is built once");
+        c->mf_fused = c->ld <= 16384 && env_int("GRAVHMC_MF_FUSED", 1) != 0;
         if (c->cell_kind == GH_CELL_TESSEROID) {
             const int64_t N = c->N;
             TRY(dalloc(c, &c->tconv, (size_t)(4 * N)));
@@ -176,7 +170,17 @@ int gh_build_G(gh_ctx *c)
                 c->obs[0], c->obs[1], c->obs[2], N, c->tconv, c->tconv + N, c->tconv + 2 * N,
                 c->tconv + 3 * N);
             HIPCHK(c, hipGetLastError());
+            if (c->mf_fused) {
+                // what depends on the cell alone, once per cell instead of once per (obs, cell) pair
+                TRY(dalloc(c, &c->mf_cellc, (size_t)c->M * TESS_NC, false));
+                tess_cellconst_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
+                    c->bounds, c->M, c->ratio, c->mf_cellc);
+                HIPCHK(c, hipGetLastError());
+                TRY(build_near_table(c));
+            }
         }
+        TRY(configure_mf(c));
+        TRY(dalloc(c, &c->mf_stats, 1));
         c->have_G = true;
         c->weighted = false;
         c->chain_ready = false;
@@ -1747,6 +1751,27 @@ int gh_profile_enable(gh_ctx *c, int enable)
     c->prof_ms_acc = 0.0;
     c->prof_launches = 0;
     c->prof_res_evals = 0;
+    if (enable) {  // (the matrix-free work counters stay readable after profiling is switched off)
+        c->mf_launches = 0;
+        if (c->mf_stats) HIPCHK(c, hipMemsetAsync(c->mf_stats, 0, sizeof(MfStats), c->stream));
+    }
+    return GH_OK;
+}
+
+int gh_matrix_free_stats(gh_ctx *c, int64_t *entries, int64_t *leaves, int64_t *launches, int64_t *near_entries,
+                         int64_t *near_leaves)
+{
+    if (c && near_entries) *near_entries = c->mf_near_on ? c->mf_near_n : 0;
+    if (c && near_leaves) *near_leaves = c->mf_near_on ? c->mf_near_leaves : 0;
+    if (!c) return GH_ERR_ARG;
+    TRY(need(c, c->mf && c->mf_stats, "gh_matrix_free_stats: context is not matrix-free (or not built)"));
+    HIPCHK(c, hipSetDevice(c->device));
+    MfStats h{};
+    HIPCHK(c, hipMemcpyAsync(&h, c->mf_stats, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (entries) *entries = (int64_t)h.entries;
+    if (leaves) *leaves = (int64_t)h.leaves;
+    if (launches) *launches = c->mf_launches;
     return GH_OK;
 }
 

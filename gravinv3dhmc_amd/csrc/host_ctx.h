@@ -31,6 +31,19 @@ struct gh_ctx {
     bool dense_ok = true;     // N fits the register-resident sweep (<= 16384 rows)
     double *tconv = nullptr;  // tesseroid obs converted to (lon rad, sin lat, cos lat, radius)
     int64_t mf_cells_per_chunk = 0;
+    // fused matrix-free pass (mf_fused_kernel: every entry evaluated once per step), N <= 16384
+    bool mf_fused = false;
+    int mf_T = 0, mf_EPT = 0;
+    size_t mf_lds = 0;
+    double *mf_cellc = nullptr;       // tesseroids: per-cell constants (tess_cellconst_kernel)
+    ghk::MfStats *mf_stats = nullptr; // entries / GLQ leaves evaluated while profiling is enabled
+    // tesseroids: near-field table (pairs that need the adaptive subdivision: evaluated once, kept)
+    bool mf_near_on = false;
+    int64_t *mf_near_ptr = nullptr;
+    int *mf_near_row = nullptr;
+    double *mf_near_val = nullptr;
+    int64_t mf_near_n = 0, mf_near_leaves = 0;
+    int64_t mf_launches = 0;
 
     // sweep configuration
     int TW = 0, EPT2 = 0, PF = 1;

@@ -184,26 +184,132 @@ static MfGeom mf_geom(const gh_ctx *c)
     return g;
 }
 
-// matrix-free counterpart of one sweep: adjoint/update pass, then forward pass
+typedef void (*mf_fused_fn)(MfGeom, SweepArgs, const double *, const double *, MfNear, MfStats *);
+
+template <int KIND>
+static mf_fused_fn mf_fused_for_kind(int T, int ept)
+{
+    if (T == 256) return ept <= 4 ? mf_fused_kernel<256, 4, KIND> : mf_fused_kernel<256, 8, KIND>;
+    if (T == 512) return ept <= 8 ? mf_fused_kernel<512, 8, KIND> : mf_fused_kernel<512, 16, KIND>;
+    if (ept <= 4) return mf_fused_kernel<1024, 4, KIND>;
+    if (ept <= 8) return mf_fused_kernel<1024, 8, KIND>;
+    return mf_fused_kernel<1024, 16, KIND>;
+}
+
+static mf_fused_fn mf_fused_for(const gh_ctx *c)
+{
+    if (c->cell_kind != GH_CELL_TESSEROID) return mf_fused_for_kind<0>(c->mf_T, c->mf_EPT);
+    return c->mf_near_on ? mf_fused_for_kind<2>(c->mf_T, c->mf_EPT) : mf_fused_for_kind<1>(c->mf_T, c->mf_EPT);
+}
+
+// Tesseroids, fused pass: list of the pairs whose root must be subdivided (or flags an error), with
+// their entries.  Kept only while it stays small next to what a stored G would take (1/64 of N*M
+// entries and 1/8 of the free memory); otherwise the pass subdivides inside (KIND 1).
+static int build_near_table(gh_ctx *c)
+{
+    c->mf_near_on = false;
+    if (env_int("GRAVHMC_MF_NEAR", 1) == 0) return GH_OK;
+    const MfGeom g = mf_geom(c);
+    int *count = nullptr;
+    HIPCHK(c, hipMalloc((void **)&count, sizeof(int) * (size_t)c->M));
+    tess_near_count_kernel<<<dim3((unsigned)c->M), dim3(256), 0, c->stream>>>(g, c->mf_cellc, count);
+    std::vector<int> hc((size_t)c->M);
+    hipError_t e = hipMemcpyAsync(hc.data(), count, sizeof(int) * (size_t)c->M, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(count);
+    if (e != hipSuccess) return fail(c, GH_ERR_HIP, "near-field count: %s", hipGetErrorString(e));
+    std::vector<int64_t> hp((size_t)c->M + 1, 0);
+    for (int64_t j = 0; j < c->M; ++j) hp[(size_t)j + 1] = hp[(size_t)j] + hc[(size_t)j];
+    const int64_t n = hp[(size_t)c->M];
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (n > c->N * c->M / 64 || (size_t)n * 12 > free_b / 8) return GH_OK;
+    TRY(dalloc(c, &c->mf_near_ptr, (size_t)c->M + 1, false));
+    TRY(dalloc(c, &c->mf_near_row, (size_t)std::max<int64_t>(n, 1), false));
+    TRY(dalloc(c, &c->mf_near_val, (size_t)std::max<int64_t>(n, 1), false));
+    HIPCHK(c, hipMemcpyAsync(c->mf_near_ptr, hp.data(), sizeof(int64_t) * ((size_t)c->M + 1), hipMemcpyHostToDevice,
+                             c->stream));
+    unsigned long long *leaves = nullptr;
+    HIPCHK(c, hipMalloc((void **)&leaves, sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(leaves, 0, sizeof(unsigned long long), c->stream));
+    tess_near_fill_kernel<<<dim3((unsigned)c->M), dim3(256), 0, c->stream>>>(g, c->mf_cellc, c->mf_near_ptr,
+                                                                           c->mf_near_row, c->mf_near_val, leaves);
+    unsigned long long hl = 0;
+    e = hipMemcpyAsync(&hl, leaves, sizeof hl, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // (hp must outlive the copy above)
+    hipFree(leaves);
+    if (e != hipSuccess) return fail(c, GH_ERR_HIP, "near-field fill: %s", hipGetErrorString(e));
+    c->mf_near_n = n;
+    c->mf_near_leaves = (int64_t)hl;
+    c->mf_near_on = true;
+    return GH_OK;
+}
+
+// Partition of the matrix-free passes.  N <= 16384: the fused pass (one workgroup per column at a
+// time, columns dealt round-robin); else the two-pass form (one wave per cell for the adjoint,
+// chunks of cells per forward partial).
+static int configure_mf(gh_ctx *c)
+{
+    if (c->mf_fused) {
+        const int64_t ld = c->ld;
+        c->mf_T = ld <= 2048 ? 256 : 1024;
+        {
+            // diagnostic override of the workgroup size (must still hold a column: 8 / 16 / 16 rows per thread)
+            const int t_env = env_int("GRAVHMC_MF_T", 0);
+            if ((t_env == 256 && ld <= 2048) || (t_env == 512 && ld <= 8192) || t_env == 1024) c->mf_T = t_env;
+        }
+        const int e = (int)((ld + c->mf_T - 1) / c->mf_T);
+        c->mf_EPT = c->mf_T == 256 ? (e <= 4 ? 4 : 8) : c->mf_T == 512 ? (e <= 8 ? 8 : 16) : (e <= 4 ? 4 : e <= 8 ? 8 : 16);
+        c->mf_lds = ((size_t)c->mf_T * c->mf_EPT + 2 * (c->mf_T / 64 + 8)) * sizeof(double);
+        mf_fused_fn f = mf_fused_for(c);
+        HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), c->mf_lds));
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(f), c->mf_T,
+                                                         c->mf_lds) != hipSuccess || occ < 1) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        occ = env_int("GRAVHMC_MF_WG_PER_CU", occ);
+        c->grid = (int)std::min<int64_t>(c->M, (int64_t)c->cus * occ);
+        c->n_teams = c->grid;  // one partial of p^2 per workgroup
+        return GH_OK;
+    }
+    c->n_teams = (int)((c->M + 3) / 4);
+    const int64_t chunks = std::min<int64_t>(c->M, std::max<int64_t>(1, (int64_t)c->cus * 16 / std::max<int64_t>(1, (c->ld + 255) / 256)));
+    c->mf_cells_per_chunk = (c->M + chunks - 1) / chunks;
+    c->grid = (int)((c->M + c->mf_cells_per_chunk - 1) / c->mf_cells_per_chunk);
+    return GH_OK;
+}
+
+// matrix-free counterpart of one sweep: the fused pass, or adjoint/update pass then forward pass
 static int launch_mf(gh_ctx *c, SweepArgs &a)
 {
     const MfGeom g = mf_geom(c);
     const double *wm = c->weighted ? c->wm : nullptr;
     bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
+    if ((a.mode & SW_ADJ) && !wm) return fail(c, GH_ERR_ARG, "matrix-free adjoint needs gh_weight first");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-    if (a.mode & SW_ADJ) {
-        if (!wm) return fail(c, GH_ERR_ARG, "matrix-free adjoint needs gh_weight first");
-        mf_adjoint_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(g, a, wm);
-    }
-    if (a.mode & SW_FWD) {
-        const double *x = (a.mode & SW_UPD) ? a.x_out : a.x_in;
-        mf_forward_kernel<<<dim3((unsigned)((c->ld + 255) / 256), (unsigned)c->grid), dim3(256), 0,
-                            c->stream>>>(g, x, wm, c->mf_cells_per_chunk, c->ld, a.slab);
+    if (c->mf_fused) {
+        a.ld = c->ld;
+        a.M = c->M;
+        MfNear near{c->mf_near_ptr, c->mf_near_row, c->mf_near_val};
+        hipLaunchKernelGGL(mf_fused_for(c), dim3(c->grid), dim3(c->mf_T), c->mf_lds, c->stream, g, a,
+                           wm, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr, near,
+                           c->prof ? c->mf_stats : nullptr);
+    } else {
+        if (a.mode & SW_ADJ)
+            mf_adjoint_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(g, a, wm);
+        if (a.mode & SW_FWD) {
+            const double *x = (a.mode & SW_UPD) ? a.x_out : a.x_in;
+            mf_forward_kernel<<<dim3((unsigned)((c->ld + 255) / 256), (unsigned)c->grid), dim3(256), 0,
+                                c->stream>>>(g, x, wm, c->mf_cells_per_chunk, c->ld, a.slab);
+        }
     }
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
     }
+    if (c->prof) c->mf_launches += 1;
     HIPCHK(c, hipGetLastError());
     return GH_OK;
 }

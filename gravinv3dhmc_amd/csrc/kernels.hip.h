@@ -1364,4 +1364,349 @@ mf_forward_kernel(MfGeom g, const double *x, const double *wm, int64_t cells_per
     slab[(int64_t)blockIdx.y * ld + i] = acc;
 }
 
+
+// ---- fused matrix-free pass: every entry evaluated ONCE per leapfrog step -------------------
+// The dense sweep's fusion applied to entries that are computed instead of loaded: a workgroup owns
+// column j, evaluates its N entries once (kept in LDS), forms the dot with r, applies the leapfrog
+// update of cell j and adds the column times the NEW x_j to its forward partial -- N*M entry
+// evaluations per step instead of 2*N*M (mf_adjoint_kernel + mf_forward_kernel, still used for
+// N > 16384).  Columns are dealt to the workgroups round-robin (cells near the poles / the top
+// layer cost several times the average: contiguous ranges would leave one workgroup with all of
+// them); the order of every sum is fixed by indices only, so results are reproducible bit for bit.
+//
+// Tesseroids: what depends on the cell alone -- the root's centre, its three size measures with
+// the two acos, the 2x2x2 GLQ nodes with their sin/cos -- is evaluated once per cell by
+// tess_cellconst_kernel (11 of the 14 trigonometric calls of a pair that needs no subdivision, and
+// that is 99.9 % of the pairs of the global model) with the same expressions, hence the same bits,
+// as tess_entry; a pair whose root must be subdivided (or flags an error) takes tess_entry itself.
+
+constexpr int TESS_NC = 24;  // doubles per cell in the table of cell constants
+
+// [0] rt [1] rt*rt [2] lont [3] sinlatt [4] coslatt [5] ratio*Llon [6] ratio*Llat [7] ratio*Lr
+// [8,9] lonc [10,11] sinlatc [12,13] coslatc [14,15] rc [16,17] rc*rc
+// [18..21] kappa[j][k] = rc[k]^2 * coslatc[j]  [22] scale
+__global__ void __launch_bounds__(256)
+tess_cellconst_kernel(const double *__restrict__ bounds6, int64_t M, double ratio, double *__restrict__ cc)
+{
+#pragma clang fp contract(off)
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const double MEAN_R = 6378137.0;
+    const double d2r = 3.14159265358979323846 / 180;
+    const double node[2] = {-0.577350269189625731058868041146, 0.577350269189625731058868041146};
+    const double *b = bounds6 + 6 * j;
+    const double w = b[0], e = b[1], s = b[2], n = b[3], top = b[4], bottom = b[5];
+    double *o = cc + (int64_t)TESS_NC * j;
+    // distance_size of the root (_tesseroid_numba.py:94-111)
+    const double rt = 0.5 * (top + bottom) + MEAN_R;
+    const double lont = d2r * 0.5 * (w + e);
+    const double latt = d2r * 0.5 * (s + n);
+    const double sinlatt = sin(latt), coslatt = cos(latt);
+    const double rtop = top + MEAN_R;
+    const double Llon = rtop * acos(sinlatt * sinlatt + (coslatt * coslatt) * cos(d2r * (e - w)));
+    const double Llat = rtop * acos(sin(d2r * n) * sin(d2r * s) + cos(d2r * n) * cos(d2r * s));
+    const double Lr = top - bottom;
+    o[0] = rt;
+    o[1] = rt * rt;
+    o[2] = lont;
+    o[3] = sinlatt;
+    o[4] = coslatt;
+    o[5] = ratio * Llon;
+    o[6] = ratio * Llat;
+    o[7] = ratio * Lr;
+    // scale_nodes of the root taken as a leaf (_tesseroid_numba.py:75-91)
+    const double dlon = d2r * (e - w), dlat = d2r * (n - s), dr = top - bottom;
+    double coslatc[2], rc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        o[8 + i] = 0.5 * dlon * node[i] + d2r * 0.5 * (e + w);
+        const double latc = 0.5 * dlat * node[i] + d2r * 0.5 * (n + s);
+        o[10 + i] = sin(latc);
+        coslatc[i] = cos(latc);
+        o[12 + i] = coslatc[i];
+        rc[i] = (0.5 * dr * node[i] + 0.5 * (top + bottom) + MEAN_R);
+        o[14 + i] = rc[i];
+        o[16 + i] = rc[i] * rc[i];
+    }
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) o[18 + 2 * jn + k] = (rc[k] * rc[k]) * coslatc[jn];
+    o[22] = dlon * dlat * dr * 0.125;
+    o[23] = 0.0;
+}
+
+__device__ __noinline__ double tess_entry_slow(double lon, double sinlat, double coslat, double radius,
+                                               const double *bounds, double ratio, unsigned &nleaf)
+{
+    int err = 0;
+    unsigned long long nl = 0;
+    bool ov = false;
+    const double v = tess_entry(lon, sinlat, coslat, radius, bounds, ratio, err, nl, ov);
+    nleaf += (unsigned)nl;
+    return v;
+}
+
+// The root taken as ONE 2x2x2 GLQ leaf (a pair that needs no subdivision), from the cell's constants:
+// the bits tess_entry produces for such a pair.
+__device__ __forceinline__ double tess_leaf_cc(double lon, double sinlat, double coslat, double radius,
+                                               const double *__restrict__ cc)
+{
+#pragma clang fp contract(off)
+    const double r_sqr = radius * radius;
+    double result = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double coslon = cos(lon - cc[8 + i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double cospsi = sinlat * cc[10 + j] + coslat * cc[12 + j] * coslon;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double rck = cc[14 + k];
+                const double l_sqr = r_sqr + cc[16 + k] - 2 * radius * rck * cospsi;
+                result += cc[18 + 2 * j + k] * (rck * cospsi - radius) / (l_sqr * sqrt(l_sqr));
+            }
+        }
+    }
+    result *= -1;
+    double acc = 0.0;
+    acc += cc[22] * result;
+    return acc * 100000.0 * 0.00000006673;
+}
+
+// Does the pair need more than the root leaf (subdivision, or an error flag)?  The root's
+// distance / size test of tess_entry (_tesseroid_numba.py:94-111,135-157) with the same bits.
+__device__ __forceinline__ bool tess_is_near_cc(double lon, double sinlat, double coslat, double radius,
+                                                const double *__restrict__ cc)
+{
+#pragma clang fp contract(off)
+    const double cospsi0 = sinlat * cc[3] + coslat * cc[4] * cos(lon - cc[2]);
+    const double distance = sqrt(radius * radius + cc[1] - 2 * radius * cc[0] * cospsi0);
+    return (distance <= cc[5]) || (distance <= cc[6]) || (distance <= cc[7]);
+}
+
+// One (observation, tesseroid) entry from the cell's constants; same bits as tess_entry.
+__device__ __forceinline__ double tess_entry_cc(double lon, double sinlat, double coslat, double radius,
+                                                const double *__restrict__ cc, const double *bounds, double ratio,
+                                                unsigned &nleaf)
+{
+    if (tess_is_near_cc(lon, sinlat, coslat, radius, cc))
+        return tess_entry_slow(lon, sinlat, coslat, radius, bounds, ratio, nleaf);
+    nleaf += 1;
+    return tess_leaf_cc(lon, sinlat, coslat, radius, cc);
+}
+
+// Near-field table.  Whether a pair needs the adaptive subdivision depends on the geometry alone,
+// and those pairs (0.02 % of the global model's 5.3*10^8, but 50 .. 2000 times the work of a far
+// pair each, and concentrated in the columns of the top layer and of the poles) are what unbalances
+// the matrix-free pass.  They are found once (count + ordered fill, one workgroup per column),
+// their entries evaluated once by tess_entry and kept as a sparse per-column list (row index,
+// value); the per-step pass evaluates the root leaf for every pair and then overwrites the listed
+// rows.  Everything else of G is still never stored.
+struct MfNear {
+    const int64_t *ptr;  // M + 1
+    const int *row;      // ptr[M]
+    const double *val;   // ptr[M], entries in mGal per g/cm^3 (unweighted, like tess_entry)
+};
+
+__global__ void __launch_bounds__(256)
+tess_near_count_kernel(MfGeom g, const double *__restrict__ cellc, int *__restrict__ count)
+{
+    __shared__ int wsum[4];
+    const int64_t j = blockIdx.x;
+    const double *cc = cellc + (int64_t)TESS_NC * j;
+    int n = 0;
+    for (int64_t i = threadIdx.x; i < g.N; i += 256)
+        n += tess_is_near_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, WAVE);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) count[j] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ordered compaction (rows ascending) + the entries themselves; leaves: GLQ leaves of these pairs
+__global__ void __launch_bounds__(256)
+tess_near_fill_kernel(MfGeom g, const double *__restrict__ cellc, const int64_t *__restrict__ ptr,
+                      int *__restrict__ row, double *__restrict__ val, unsigned long long *leaves)
+{
+    __shared__ int wsum[4];
+    const int64_t j = blockIdx.x;
+    const double *cc = cellc + (int64_t)TESS_NC * j;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t base = ptr[j];
+    if (ptr[j + 1] == base) return;
+    unsigned nl = 0;
+    for (int64_t i0 = 0; i0 < g.N; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool near = i < g.N && tess_is_near_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc);
+        const unsigned long long m = __ballot(near);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (near) {
+            row[base + woff + before] = (int)i;
+            val[base + woff + before] =
+                tess_entry_slow(g.o0[i], g.o1[i], g.o2[i], g.o3[i], g.bounds6 + 6 * j, g.ratio, nl);
+        }
+        base += tot;
+        __syncthreads();
+    }
+    unsigned long long t = nl;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, WAVE);
+    if (lane == 0 && t) atomicAdd(leaves, t);
+}
+
+struct MfStats {
+    unsigned long long entries, leaves;
+};
+
+// T threads per workgroup, EPT rows per thread (row of slot k: t + k*T): T*EPT >= ld; KIND: 0 prisms,
+// 1 tesseroids with the subdivision inside the pass, 2 tesseroids with the near-field table (separate kernels: the prism entry's log/atan2 and the tesseroid entry's trigonometry would
+// otherwise share one register budget).
+// LDS: T*EPT doubles (the column) + 2 x (T/64 + 8) doubles (ping-pong slots of the dot).
+template <int T, int EPT, int KIND>
+__global__ void __launch_bounds__(T)
+mf_fused_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const double *__restrict__ cellc,
+                MfNear near, MfStats *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = T / 64;
+    constexpr int SLOT = NW + 8;
+    double *Ks = smem;
+    double *scratch = smem + (size_t)T * EPT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mode = a.mode;
+    const int64_t N = g.N;
+    const int ept = (int)((a.ld + T - 1) / T);  // slots in use (<= EPT)
+    double dacc[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) dacc[k] = 0.0;
+    double pp = 0.0;
+    unsigned nleaf = 0, nent = 0;
+    int it = 0;
+    for (int64_t j = blockIdx.x; j < g.M; j += gridDim.x, ++it) {
+        const double *b = g.bounds6 + 6 * j;
+        const double *cc = cellc ? cellc + (int64_t)TESS_NC * j : nullptr;
+        double s = 0.0;
+        if (KIND == 2) {
+            // every pair as its root leaf (no test, no divergence); the rows of the near-field list
+            // are then overwritten with their stored entries, and the dot reads the finished column
+#pragma unroll 1
+            for (int k = 0; k < ept; ++k) {
+                const int64_t i = tid + (int64_t)k * T;
+                double v = 0.0;
+                if (i < N) {
+                    v = tess_leaf_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc);
+                    nent += 1;
+                }
+                Ks[(size_t)k * T + tid] = v;
+            }
+            const int64_t q0 = near.ptr[j], q1 = near.ptr[j + 1];
+            if (q1 > q0) {
+                __syncthreads();
+                for (int64_t q = q0 + tid; q < q1; q += T) Ks[near.row[q]] = near.val[q];
+                __syncthreads();
+            }
+            if (mode & SW_ADJ) {
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int64_t i = tid + (int64_t)k * T;
+                    if (k < ept && i < N) s += Ks[(size_t)k * T + tid] * a.r[i];
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < ept; ++k) {
+                const int64_t i = tid + (int64_t)k * T;
+                double v = 0.0;
+                if (i < N) {
+                    if (KIND == 0) {
+                        v = prism_entry(g.o0[i], g.o1[i], g.o2[i], b);
+                        nleaf += 1;
+                    } else {
+                        v = tess_entry_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc, b, g.ratio, nleaf);
+                    }
+                    nent += 1;
+                    if (mode & SW_ADJ) s += v * a.r[i];
+                }
+                Ks[(size_t)k * T + tid] = v;
+            }
+        }
+        double xj;
+        if (mode & SW_ADJ) {
+            s = wave_allreduce_sum(s);
+            double *slot = scratch + (it & 1) * SLOT;
+            if (lane == 0) slot[wave] = s;
+            __syncthreads();
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += slot[w];
+            const double w = wm[j];
+            t = (w != 0.0) ? t * (1.0 / w) : t;
+            const double gr = a.greg ? a.greg[j] : 0.0;
+            const double grad = 2.0 * t + gr;
+            xj = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+            if ((mode & SW_GOUT) && tid == 0) a.g_out[j] = grad;
+            if (mode & SW_PFIN) {
+                const double pf = a.p_in[j] - a.c_p * grad;
+                pp += pf * pf;
+                if (!(mode & SW_SPEC) && tid == 0) a.p_out[j] = pf;
+            }
+            if (mode & SW_UPD) {
+                const double psrc = (mode & SW_SPEC) ? a.pn_in[j] : a.p_in[j];
+                double pj = psrc - a.c_u * grad;
+                xj = xj + a.dt * pj;
+                const double hi = a.high[j], lo = a.low[j];
+                if (xj > hi) {
+                    xj = hi;
+                    pj = -pj;
+                } else if (xj < lo) {
+                    xj = lo;
+                    pj = -pj;
+                }
+                if (tid == 0) {
+                    a.p_out[j] = pj;
+                    a.x_out[j] = xj;
+                }
+            }
+        } else {
+            xj = a.x_in[j];
+        }
+        if (mode & SW_FWD) {
+            const double w = wm ? wm[j] : 1.0;
+            const double xs = (w != 0.0) ? xj * (1.0 / w) : xj;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (k < ept) dacc[k] += Ks[(size_t)k * T + tid] * xs;
+        }
+    }
+    if ((mode & SW_PFIN) && tid == 0) a.pp_part[blockIdx.x] = pp;
+    if (mode & SW_FWD) {
+        double *out = a.slab + (int64_t)blockIdx.x * a.ld;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int64_t i = tid + (int64_t)k * T;
+            if (i < a.ld) out[i] = dacc[k];
+        }
+    }
+    if (stats) {
+        unsigned long long e = nent, l = (KIND == 2) ? nent : nleaf;  // (KIND 2: one root leaf per entry)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            e += __shfl_xor(e, off, WAVE);
+            l += __shfl_xor(l, off, WAVE);
+        }
+        if (lane == 0) {
+            atomicAdd(&stats->entries, e);
+            atomicAdd(&stats->leaves, l);
+        }
+    }
+}
+
 }  // namespace ghk

@@ -99,6 +99,15 @@ class Engine(object):
     def set_matrix_free(self, on=True):
         self._chk(self._lib.gh_set_matrix_free(self._h, 1 if on else 0))
 
+    def matrix_free_stats(self):
+        """Entries / GLQ leaves evaluated and launches of the fused matrix-free pass since
+        profile_enable(True)."""
+        e, l, n, ne, nl = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_matrix_free_stats(self._h, C.byref(e), C.byref(l), C.byref(n), C.byref(ne),
+                                                 C.byref(nl)))
+        return {"entries": e.value, "leaves": l.value, "launches": n.value,
+                "near_entries": ne.value, "near_leaves": nl.value}
+
     def build_G(self):
         self._chk(self._lib.gh_build_G(self._h))
 

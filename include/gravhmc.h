@@ -64,10 +64,20 @@ int gh_set_obs(gh_ctx *ctx, const double *a, const double *b, const double *c);
  * w,e,s,n,top,bottom (tesseroid); `ratio` is the tesseroid distance-size ratio
  * (tesseroid.py:77, 1.6 for gz), ignored for prisms. */
 int gh_set_cells(gh_ctx *ctx, const double *bounds6, int kind, double ratio);
-/* Matrix-free mode (call before gh_build_G): the kernel matrix is never stored; every potential
- * evaluation re-evaluates the prism / tesseroid entries (two evaluations of each entry per
- * leapfrog step: adjoint pass, forward pass).  For problems whose G exceeds HBM; any N. */
+/* Matrix-free mode (call before gh_build_G): the kernel matrix is never stored; the prism /
+ * tesseroid entries are re-evaluated where they are needed.  With N <= 16384 observations a
+ * leapfrog step evaluates every entry ONCE (a workgroup keeps a cell's column on the chip between
+ * the dot with r, the leapfrog update and the forward accumulation, like the dense sweep); beyond
+ * that an adjoint pass and a forward pass evaluate it twice.  For problems whose G exceeds HBM. */
 int gh_set_matrix_free(gh_ctx *ctx, int enable);
+/* Work of the matrix-free passes since gh_profile_enable(ctx, 1) (fused form only): entries
+ * evaluated, 2x2x2 Gauss-Legendre leaves evaluated (tesseroids; = entries for prisms), launches.
+ * Tesseroids: the pairs that need the reference's adaptive subdivision (_tesseroid_numba.py:135-157)
+ * are a property of the geometry; when they are few (<= 1/64 of the pairs) gh_build_G evaluates
+ * them once and keeps them as a sparse near-field list -- near_entries pairs, near_leaves GLQ leaves
+ * (0 when the list is not in use and the passes subdivide inside).  Any pointer may be NULL. */
+int gh_matrix_free_stats(gh_ctx *ctx, int64_t *entries, int64_t *leaves, int64_t *launches,
+                         int64_t *near_entries, int64_t *near_leaves);
 /* Assemble the dense kernel on the device.  Replaces the Python cell loop + native calls of
  * prism.py:291-316 -> _prism.pyx:265-290, or tesseroid.py:189-232 -> _tesseroid_numba.py:32-71,
  * including the unit scaling G*SI2MGAL.  For tesseroids returns GH_ERR_OVERFLOW if any
