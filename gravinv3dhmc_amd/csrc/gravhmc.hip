@@ -4,6 +4,7 @@
 #include "kernels.hip.h"
 #include "batch.hip.h"
 #include "resident.hip.h"
+#include "teamsweep.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -457,7 +458,7 @@ int gh_forward(gh_ctx *c, const double *mw, double *dpre)
     reduce_slab(c, nullptr, c->tmpN);
     HIPCHK(c, hipGetLastError());
     TRY(comm_allreduce(c, c->tmpN, c->ld));
-    return d2h(c, dpre, c->tmpN, (size_t)c->N);
+    return d2h(c, dpre, c->tmpN, (size_t)c->N);  // (forward-only sweeps never run on teams)
 }
 
 int gh_adjoint(gh_ctx *c, const double *r, double *g)
@@ -844,6 +845,18 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
         HIPCHK(c, hipMemcpyAsync(h + 16 + 2 * nt + c->n_pp0, c->pn0_part, (size_t)c->n_pp0 * sizeof(double),
                                  hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        // a team sweep of this trajectory gave up (its workgroups were not all resident): nothing of
+        // the chain's current state was touched -- run the trajectory again, in row panels
+        bool failed = false;
+        TRY(team_failed(c, &failed));
+        if (failed) {
+            c->spec_valid = c->pn_valid = false;
+            const int rc = chain_trajectory_impl(c, p0, dt, L, u, p0_next, accepted, out5);
+            team_resume(c);
+            return rc;
+        }
+    }
     if (pn_deferred) {
         double s = 0.0;
         for (int t = 0; t < c->n_pp0; ++t) s += h[16 + 2 * nt + c->n_pp0 + t];
@@ -968,6 +981,15 @@ int gh_chain_stats(gh_ctx *c, int64_t *spec_hits, int64_t *spec_misses)
     if (!c) return GH_ERR_ARG;
     if (spec_hits) *spec_hits = c->spec_hits;
     if (spec_misses) *spec_misses = c->spec_misses;
+    return GH_OK;
+}
+
+int gh_team_sweep_stats(gh_ctx *c, int *members, int64_t *launches, int *timeouts)
+{
+    if (!c) return GH_ERR_ARG;
+    if (members) *members = c->tm.state != 0 ? c->tm.Q : 0;
+    if (launches) *launches = c->tm.launches;
+    if (timeouts) *timeouts = c->tm.aborts;
     return GH_OK;
 }
 
@@ -1743,6 +1765,7 @@ int gh_profile_enable(gh_ctx *c, int enable)
     if (enable && c->ev.empty()) {
         c->ev.resize(8192);
         for (auto &e : c->ev) HIPCHK(c, hipEventCreate(&e));
+        c->ev_bytes.assign(c->ev.size() / 2, 0);
     }
     c->prof = enable != 0;
     c->prof_stride = (c->ld * c->M * 8 < (int64_t)(1 << 30)) ? 16 : 1;
@@ -1791,9 +1814,13 @@ int gh_profile_read(gh_ctx *c, double *sweep_ms, int64_t *sweep_launches, int64_
     const int64_t timed = (int64_t)(c->ev_used / 2) + c->prof_res_evals;
     if (sweep_ms) *sweep_ms = ms;
     if (sweep_launches) *sweep_launches = timed;
-    // one launch reads one row panel of G (the whole matrix when N <= 16384)
-    if (bytes_per_sweep)
-        *bytes_per_sweep = (c->n_panels > 1 ? c->panel_rows : c->N) * c->M * (int64_t)sizeof(double);
+    // bytes of G an average timed launch read: the whole matrix for the one-read sweeps (one
+    // workgroup or a team per column), one row panel for the launches of the row-panel path
+    if (bytes_per_sweep) {
+        int64_t tot = c->prof_res_evals * c->N * c->M * (int64_t)sizeof(double);
+        for (size_t i = 0; i < c->ev_used / 2; ++i) tot += c->ev_bytes[i];
+        *bytes_per_sweep = timed > 0 ? tot / timed : c->N * c->M * (int64_t)sizeof(double);
+    }
     return GH_OK;
 }
 

@@ -77,6 +77,7 @@ static int batch_time_end(gh_ctx *c, bool timed)
 {
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_bytes[c->ev_used / 2] = c->N * c->M * (int64_t)sizeof(double);
         c->ev_used += 2;
     }
     c->bt.sweeps += 1;

@@ -50,6 +50,22 @@ struct gh_ctx {
     int n_panels = 1;        // row panels of the dense sweep (N > 16384 rows: > 1, two reads of G per step)
     int64_t panel_rows = 0;
     double *gbuf = nullptr;   // gradient accumulated over the panels
+    // team sweep (teamsweep.hip.h): N > 16384 with ONE read of G per fused step
+    struct Team {
+        int state = 0;        // 0 not planned, 1 usable, -1 not applicable / given up
+        int Q = 0, tpx = 0, grid = 0;
+        int threads = 0, ept2 = 0, depth = 0;  // instantiation of teamsweep_kernel
+        int64_t panel_rows = 0;                // rows per member
+        int64_t cols_per_team = 0;
+        size_t lds = 0;
+        ghk::u64 *gran = nullptr;
+        unsigned *abort_w = nullptr;
+        unsigned tag = 0;
+        bool inflight = false;  // launched since the abort word was last looked at
+        int aborts = 0;
+        int64_t launches = 0;
+    } tm;
+    int slab_live = 0;        // rows of the slab the last forward launch wrote
     bool NT = false;
     int n_teams = 0, grid = 0;
     int n_teams_sweep = 0;   // teams of the sweep launch (n_teams may be larger: size of the pp partials)
@@ -199,6 +215,8 @@ struct gh_ctx {
     size_t ev_used = 0;
     double prof_ms_acc = 0.0;
     int64_t prof_launches = 0;
+    std::vector<int64_t> ev_bytes;  // bytes of G the timed launch of event pair i read
+    int64_t prof_bytes_last = 0;
 };
 
 static int fail(gh_ctx *c, int code, const char *fmt, ...)

@@ -8,7 +8,7 @@
 // hundreds of rows serially.
 static void reduce_slab(gh_ctx *c, const double *gfix, double *d_out)
 {
-    const int rows = c->grid;
+    const int rows = c->slab_live > 0 ? c->slab_live : c->grid;
     if (rows > 64 && c->slab2) {
         const int nseg = c->slab2_rows;
         reduce_slab_kernel<<<dim3(c->n_dpart, nseg), dim3(32, 8), 0, c->stream>>>(c->slab, rows, c->ld, c->N,
@@ -87,12 +87,12 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         // finish_kernel sums the 16 segments
         nseg = c->slab2_rows;
         reduce_reg_kernel<<<dim3((unsigned)(c->n_dpart * nseg + c->n_regpart)), dim3(256), 0, c->stream>>>(
-            c->slab, c->grid, c->ld, nseg, c->n_dpart, c->slab2, ra);
+            c->slab, c->slab_live > 0 ? c->slab_live : c->grid, c->ld, nseg, c->n_dpart, c->slab2, ra);
         src = c->slab2;
     } else {
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
         src = c->slab;
-        nseg = c->grid;
+        nseg = c->slab_live > 0 ? c->slab_live : c->grid;
     }
     FinishArgs fa;
     fa.N = c->N;

@@ -307,6 +307,7 @@ static int launch_mf(gh_ctx *c, SweepArgs &a)
     }
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_bytes[c->ev_used / 2] = 0;
         c->ev_used += 2;
     }
     if (c->prof) c->mf_launches += 1;
@@ -329,6 +330,8 @@ static int launch_sweep_one(gh_ctx *c, SweepArgs &a)
     hipLaunchKernelGGL(f, dim3(c->grid), dim3(threads), c->lds_bytes, c->stream, a);
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_bytes[c->ev_used / 2] = a.rows < c->ld ? a.rows * c->M * (int64_t)sizeof(double)
+                                                      : c->N * c->M * (int64_t)sizeof(double);
         c->ev_used += 2;
     }
     if (c->prof) c->prof_launches += 1;
@@ -336,13 +339,168 @@ static int launch_sweep_one(gh_ctx *c, SweepArgs &a)
     return GH_OK;
 }
 
+// ---- team sweep: one read of G per fused step for N > 16384 (teamsweep.hip.h)
+
+typedef void (*team_fn)(TeamArgs);
+
+// Measured at the C5 share (N = 4*10^4, 3*10^5 cells, 96 GB; ms per team sweep): 1024 threads x 5
+// double2 x 3 buffers (4 members) 18.0; 1024 x 4 x 4 (5 members, 240 of 256 CUs) 19.8; 512 x 10 x 4
+// 17.5 + more variance; 512 x 10 x 5 25.8; 512 x 8 x 5 21.4 -- what a column costs beyond its bytes
+// is the per-column hand-off (two workgroup barriers and one L2 round trip), not the depth of the
+// prefetch, so the shape with the fewest, largest members is kept.
+static team_fn team_kernel_for(int threads, int ept2, int depth)
+{
+    if (threads == 1024 && ept2 == 5 && depth == 3) return teamsweep_kernel<1024, 5, 3>;
+    return nullptr;
+}
+
+static bool team_plan(gh_ctx *c)
+{
+    gh_ctx::Team &t = c->tm;
+    if (t.state != 0) return t.state > 0;
+    t.state = -1;
+    if (env_int("GRAVHMC_TEAM", 1) == 0) return false;
+    if (c->mf || c->n_panels < 2 || !c->G) return false;
+    // instantiation: threads x double2 per thread x column buffers
+    t.threads = 1024;
+    t.ept2 = 5;
+    t.depth = 3;
+    const int64_t cap = (int64_t)t.threads * t.ept2 * 2;  // rows a member holds of a column
+    t.Q = (int)((c->ld + cap - 1) / cap);
+    if (t.Q < 2) t.Q = 2;
+    if (t.Q > TS_MAXQ || c->cus < 8 * t.Q) return false;
+    t.panel_rows = ((c->ld + t.Q - 1) / t.Q + 15) / 16 * 16;
+    t.tpx = std::min(32, c->cus / 8) / t.Q;  // blocks with equal blockIdx % 8 share an XCD: 32 CUs each
+    if (t.tpx < 1) return false;
+    t.grid = 8 * t.tpx * t.Q;
+    const int n_teams = 8 * t.tpx;
+    if (n_teams > c->grid) return false;     // the slab was sized for the panel launches
+    t.cols_per_team = (c->M + n_teams - 1) / n_teams;
+    t.lds = ((size_t)t.panel_rows + 2 * TS_MAXWAVES + TS_RING * 8 + 4) * sizeof(double);
+    team_fn f = team_kernel_for(t.threads, t.ept2, t.depth);
+    if (allow_dynamic_lds(reinterpret_cast<const void *>(f), t.lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), t.threads,
+                                                     t.lds) != hipSuccess ||
+        per_cu < 1 || (int64_t)per_cu * c->cus < t.grid) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const size_t ng = (size_t)n_teams * TS_MAXQ * TS_RING * 2;
+    if (dalloc(c, &t.gran, ng) != GH_OK || dalloc(c, &t.abort_w, 4) != GH_OK) return false;
+    {
+        // where does the dispatcher put the blocks of such a grid?  Round-robin over the XCDs means
+        // equal blockIdx % 8 <-> one XCD: the members of a team then share an L2, which their scalar
+        // polls read.  (A launch placed differently later only times out -> row panels.)
+        unsigned *xcc = nullptr;
+        std::vector<unsigned> hx((size_t)t.grid, 0u);
+        bool same = true;
+        if (hipMalloc((void **)&xcc, sizeof(unsigned) * (size_t)t.grid) == hipSuccess) {
+            hipLaunchKernelGGL(team_probe_kernel, dim3(t.grid), dim3(1024), 64 * 1024, c->stream, xcc);
+            if (hipMemcpyAsync(hx.data(), xcc, sizeof(unsigned) * (size_t)t.grid, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) {
+                (void)hipGetLastError();
+                same = false;
+            }
+            hipFree(xcc);
+            for (int b = 8; b < t.grid && same; ++b) same = hx[(size_t)b] == hx[(size_t)(b & 7)];
+        } else {
+            same = false;
+        }
+        if (!same) return false;  // members of a team would not share an L2: stay on row panels
+    }
+    t.tag = 0;
+    t.state = 1;
+    return true;
+}
+
+static int launch_team(gh_ctx *c, const SweepArgs &full)
+{
+    gh_ctx::Team &t = c->tm;
+    if ((uint64_t)t.tag + (uint64_t)t.cols_per_team + 2 > 0xf0000000ull) {
+        // 32-bit tags about to wrap: start again on zeroed granules
+        HIPCHK(c, hipMemsetAsync(t.gran, 0, (size_t)8 * t.tpx * TS_MAXQ * TS_RING * 2 * sizeof(u64), c->stream));
+        t.tag = 0;
+    }
+    TeamArgs a{};
+    a.s = full;
+    a.s.G = c->G;
+    a.s.ld = c->ld;
+    a.s.M = c->M;
+    a.Q = t.Q;
+    // test hook: the members wait for a part that never comes, time out and give up
+    a.poll_q = t.Q + ((env_int("GRAVHMC_TEAM_TEST_ABORT", 0) && t.Q < TS_MAXQ) ? 1 : 0);
+    a.tpx = t.tpx;
+    a.panel_rows = t.panel_rows;
+    a.cols_per_team = t.cols_per_team;
+    a.n_pp = c->n_teams;
+    a.gran = t.gran;
+    a.tag0 = t.tag;
+    a.abort_w = t.abort_w;
+    bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    hipLaunchKernelGGL(team_kernel_for(t.threads, t.ept2, t.depth), dim3(t.grid), dim3(t.threads), t.lds, c->stream, a);
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_bytes[c->ev_used / 2] = c->N * c->M * (int64_t)sizeof(double);
+        c->ev_used += 2;
+    }
+    if (c->prof) c->prof_launches += 1;
+    HIPCHK(c, hipGetLastError());
+    t.tag += (unsigned)t.cols_per_team + 1u;
+    t.inflight = true;
+    t.launches += 1;
+    return GH_OK;
+}
+
+// After a synchronisation point: did a team sweep since the last look give up (its workgroups were
+// not all resident)?  Then everything it fed is void: the caller repeats its work, which now runs in
+// row panels (again on teams after a transient stall; for good after three).
+static int team_failed(gh_ctx *c, bool *failed)
+{
+    gh_ctx::Team &t = c->tm;
+    *failed = false;
+    if (!t.inflight) return GH_OK;
+    t.inflight = false;
+    unsigned w[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(w, t.abort_w, sizeof w, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (w[0] == 0u) return GH_OK;
+    t.aborts += 1;
+    const bool for_good = t.aborts >= 3;
+    fprintf(stderr, "libgravhmc: team sweep timed out waiting for its workgroups (%d of 3); repeating %s in row panels\n",
+            t.aborts, for_good ? "this and everything after it" : "the step");
+    HIPCHK(c, hipMemsetAsync(t.abort_w, 0, 4 * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(t.gran, 0, (size_t)8 * t.tpx * TS_MAXQ * TS_RING * 2 * sizeof(u64), c->stream));
+    t.tag = 0;
+    t.state = for_good ? -1 : 2;  // 2: skip the teams until the repeated work is done (team_resume)
+    *failed = true;
+    return GH_OK;
+}
+
+static void team_resume(gh_ctx *c)
+{
+    if (c->tm.state == 2) c->tm.state = 1;
+}
+
 static int launch_sweep(gh_ctx *c, SweepArgs &a)
 {
+    if (a.mode & SW_FWD) c->slab_live = c->grid;
     if (c->mf) return launch_mf(c, a);
     if (c->n_panels == 1) {
         a.row0 = 0;
         a.rows = c->ld;
         return launch_sweep_one(c, a);
+    }
+    // more rows than one workgroup holds of a column.  The fused step (adjoint + update + forward)
+    // runs on teams of workgroups: one read of G.  Adjoint-only and forward-only sweeps read G once
+    // in row panels anyway.
+    if ((a.mode & SW_ADJ) && (a.mode & SW_FWD) && !(a.mode & SW_GACC) && team_plan(c) && c->tm.state == 1) {
+        c->slab_live = 8 * c->tm.tpx;
+        return launch_team(c, a);
     }
     // row panels: adjoint of every panel into gbuf, elementwise update, forward of every panel
     const SweepArgs full = a;
@@ -359,7 +517,7 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
         }
         if (full.mode & (SW_UPD | SW_PFIN)) {
             SweepArgs u = full;
-            vec_update_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(u, gdst, c->M);
+            vec_update_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(u, gdst, c->M, c->n_teams);
             HIPCHK(c, hipGetLastError());
         }
     }

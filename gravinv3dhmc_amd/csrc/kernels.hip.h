@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(1024) sum_kernel(const double *part, int n, do
 
 // Leapfrog update from a ready gradient g (row-panel path for N > 16384: the adjoint of all
 // panels is accumulated first, then this elementwise pass does what sweep_kernel does per column).
-__global__ void __launch_bounds__(256) vec_update_kernel(SweepArgs a, const double *g, int64_t M)
+__global__ void __launch_bounds__(256) vec_update_kernel(SweepArgs a, const double *g, int64_t M, int n_pp)
 {
     __shared__ double red[4];
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -709,6 +709,10 @@ __global__ void __launch_bounds__(256) vec_update_kernel(SweepArgs a, const doub
     if (mode & SW_PFIN) {
         const double t = block_allreduce_sum(pp, red, 4);
         if (threadIdx.x == 0) a.pp_part[blockIdx.x] = t;
+        // the host sums n_pp partials; a team sweep (teamsweep.hip.h) may have left its own in the
+        // entries this launch does not write
+        if (blockIdx.x == 0)
+            for (int q = (int)gridDim.x + (int)threadIdx.x; q < n_pp; q += 256) a.pp_part[q] = 0.0;
     }
 }
 

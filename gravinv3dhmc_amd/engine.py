@@ -242,8 +242,11 @@ class Engine(object):
         self._chk(self._lib.gh_chain_stats(self._h, C.byref(a), C.byref(b)))
         la, ev = C.c_int64(0), C.c_int64(0)
         self._chk(self._lib.gh_chain_resident_stats(self._h, C.byref(la), C.byref(ev)))
+        q, tl, to = C.c_int(0), C.c_int64(0), C.c_int(0)
+        self._chk(self._lib.gh_team_sweep_stats(self._h, C.byref(q), C.byref(tl), C.byref(to)))
         return {"spec_hits": a.value, "spec_misses": b.value,
-                "resident_launches": la.value, "resident_evaluations": ev.value}
+                "resident_launches": la.value, "resident_evaluations": ev.value,
+                "team_members": q.value, "team_launches": tl.value, "team_timeouts": to.value}
 
     def _prepare_batch(self, batch, lookahead, want_x):
         """Arguments of one gh_chain_run call over a list of (L, p0, u), marshalled on the calling

@@ -193,6 +193,12 @@ int gh_chain_stats(gh_ctx *ctx, int64_t *spec_hits, int64_t *spec_misses);
  * contract and results to rounding (the summation order over the cells differs); environment
  * GRAVHMC_RESIDENT=0 switches it off.  launches / evaluations: how much ran there so far. */
 int gh_chain_resident_stats(gh_ctx *ctx, int64_t *launches, int64_t *evaluations);
+/* More observations than one workgroup holds of a column (N > 16384, stored G): the fused leapfrog
+ * step runs on teams of `members` workgroups that share each column (csrc/teamsweep.hip.h), still
+ * ONE read of G per step; adjoint-only / forward-only sweeps and the steps after a team timed out
+ * run in row panels.  members: workgroups per team (0: not in use), launches: team sweeps so far,
+ * timeouts: launches that gave up (after three the context stays on row panels). */
+int gh_team_sweep_stats(gh_ctx *ctx, int *members, int64_t *launches, int *timeouts);
 int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
 int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state */);
 /* ---- several chains sharing every sweep of G (fp64 MFMA) ---------------------------------- */

@@ -1339,37 +1339,55 @@ def test_hmcsample_batch_reproduces_reference_chains(G, tmp_path, capsys):
                                    c[tag + "_model"], atol=2e-8)
 
 
-def test_row_panels_chain_matches_oracle(G, orc):
-    """N > 16384 observations: the dense sweep runs in row panels (adjoint of all panels, update,
-    forward of all panels); potential, gradient and trajectories against the CPU oracle."""
+def test_row_panels_chain_matches_oracle(G, orc, monkeypatch, capfd):
+    """N > 16384 observations: a column no longer fits one workgroup's registers.  The fused leapfrog
+    step runs on teams of workgroups that share a column (one read of G, teamsweep.hip.h); with
+    GRAVHMC_TEAM=0, and after a team timed out, in row panels (adjoint of all panels, update,
+    forward of all panels).  Potential, gradient and trajectories against the CPU oracle on both
+    paths; a time-out of the teams (test hook) repeats the trajectory in row panels: same bits as
+    the row-panel run."""
     rng = np.random.default_rng(8)
     N, M = 17011, 150
     A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.2, 2, size=M))
     dobs = rng.normal(size=N) * 3
-    eng = G.Engine(N, M)
-    eng.upload_G(A)
-    wm = eng.weight(0.5)
-    Aw, wmo = orc.col_weight(A)
-    assert relmax(wm, wmo) < 1e-13 and relmax(eng.download_G(), Aw) < 1e-13
-    eng.set_data(dobs)
-    for reg, shape in (("MS", (1, 1, M)), ("TV", (5, 5, 6))):
-        eng.set_reg(reg, 0.7, 0.01, shape, 0.001 * wm)
-        P = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.7, 0.01, wm=wm, shape=shape)
-        x = rng.uniform(0, 1, M) * wm
-        a, b = eng.misfit_and_grad(x), P.misfit_and_grad(x)
-        assert abs(a[0] - b[0]) < 1e-11 * abs(b[0]) and relmax(a[1], b[1]) < 1e-11 and relmax(a[2], b[2]) < 1e-11
-        low, high = 0.0 * wm, 0.3 * wm
-        xg = xo = 0.001 * wm
-        eng.chain_init(xg, low, high)
-        trajs = [(int(rng.integers(1, 7)), rng.normal(size=M) * 0.02, float(rng.uniform())) for _ in range(5)]
-        res = []
-        eng.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res.append((acc, o.copy(), xs)), want_x=True)
-        for (L, p0, u), (acc, o, xs) in zip(trajs, res):
-            xo, acco, oo, _ = P.leapfrog(xo, p0, 0.002, L, low, high, u)
-            assert acc == acco and relmax(o, oo) < 1e-9
-            if acc:
-                assert relmax(xs, xo) < 1e-9
-    eng.close()
+    seeds = {}
+    runs = {}
+    for path in ("team", "panels", "team-abort"):
+        monkeypatch.setenv("GRAVHMC_TEAM", "0" if path == "panels" else "1")
+        monkeypatch.setenv("GRAVHMC_TEAM_TEST_ABORT", "1" if path == "team-abort" else "0")
+        rng = np.random.default_rng(80)
+        eng = G.Engine(N, M)
+        eng.upload_G(A)
+        wm = eng.weight(0.5)
+        Aw, wmo = orc.col_weight(A)
+        assert relmax(wm, wmo) < 1e-13 and relmax(eng.download_G(), Aw) < 1e-13
+        eng.set_data(dobs)
+        runs[path] = []
+        for reg, shape in (("MS", (1, 1, M)), ("TV", (5, 5, 6))):
+            eng.set_reg(reg, 0.7, 0.01, shape, 0.001 * wm)
+            P = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.7, 0.01, wm=wm, shape=shape)
+            x = rng.uniform(0, 1, M) * wm
+            a, b = eng.misfit_and_grad(x), P.misfit_and_grad(x)
+            assert abs(a[0] - b[0]) < 1e-11 * abs(b[0]) and relmax(a[1], b[1]) < 1e-11 and relmax(a[2], b[2]) < 1e-11
+            low, high = 0.0 * wm, 0.3 * wm
+            xg = xo = 0.001 * wm
+            eng.chain_init(xg, low, high)
+            ntr = 2 if path == "team-abort" else 5          # (every aborted launch waits 2 s)
+            trajs = [(int(rng.integers(1, 7)), rng.normal(size=M) * 0.02, float(rng.uniform())) for _ in range(5)][:ntr]
+            res = []
+            eng.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res.append((acc, o.copy(), xs)), want_x=True)
+            for (L, p0, u), (acc, o, xs) in zip(trajs, res):
+                xo, acco, oo, _ = P.leapfrog(xo, p0, 0.002, L, low, high, u)
+                assert acc == acco and relmax(o, oo) < 1e-9
+                if acc:
+                    assert relmax(xs, xo) < 1e-9
+            runs[path].append(res)
+        eng.close()
+    err = capfd.readouterr().err
+    assert err.count("team sweep timed out") == 3 and "(3 of 3)" in err
+    for ra, rb in zip(runs["team-abort"], runs["panels"]):
+        for (a1, o1, x1), (a2, o2, x2) in zip(ra, rb):       # repeated in row panels: the panel run's bits
+            assert a1 == a2 and np.array_equal(o1, o2) and (x1 is None or np.array_equal(x1, x2))
 
 
 # ------------------------------------------------------------- conjugate gradient (reginv)
