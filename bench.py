@@ -47,19 +47,49 @@ FLOPS_PER_TESS_PAIR_HOISTED = 146  # per pair and step once the cell-only part i
 
 
 def pmc_traffic(workload):
-    """HBM bytes per sweep launch from the committed rocprofv3 PMC summary (profiles/rNN/),
-    corrected as MI355X_MICROARCH.md prescribes; None when no profile of this workload exists."""
+    """HBM bytes per sweep launch from the newest committed rocprofv3 PMC summary of this workload
+    (profiles/rNN/<tag>_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    command, corrected as MI355X_MICROARCH.md prescribes).  Hardware counters cannot be read from
+    inside the benchmark process, so this is NOT measured in the run that prints it: returns
+    (bytes, {"file", "note"}) for the line's `traffic` / `traffic_from_profile` fields, or
+    (None, None) when no profile of this workload exists."""
     import glob
     tag = workload.split("_")[0]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", tag + "_pmc_summary.json")),
                     reverse=True):
         try:
-            ks = json.load(open(f))["kernels"]
+            doc = json.load(open(f))
+            ks = doc["kernels"]
             k = [v for n, v in ks.items() if "sweep_kernel" in n][0]
-            return k["hbm_read_bytes"] + k["hbm_write_bytes"]
+            b = k["hbm_read_bytes"] + k["hbm_write_bytes"]
+            return b, {"file": os.path.relpath(f, ROOT), "bytes_per_launch": b,
+                       "note": "separate rocprofv3 --pmc passes of this command, committed with the "
+                               "sources (commit %s); not a counter of this run" % doc.get("commit", "n/a")}
         except Exception:
             continue
-    return None
+    return None, None
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota
+    (a GPU box hands a container 16 of its 64+ cores: more BLAS/OpenMP threads than that are
+    throttled, which made 64 threads look no faster than one in round 1)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
 
 
 def make_problem(name):
@@ -122,64 +152,160 @@ def make_extra(name):
     return mesh, obs, rho.ravel()
 
 
-def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=12.0):
-    """The reference's CPU formulation (NumPy + multi-threaded BLAS dgemv pair per potential
-    evaluation, NumPy leapfrog; oracle/numpy_port.py, kind "port") on a column-subsampled copy
-    of the same workload: same N, every k-th cell; steps/s is scaled by the subsampling factor
-    (cost per step is linear in the number of cells).  The sample kernel is assembled by the
-    C oracle."""
+def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=16.0, max_cells=10000):
+    """The reference's CPU formulation of the same step, timed on this box's host cores on a
+    bounded sample: same N observations, every k-th cell (cost per step is linear in the number of
+    cells: steps/s is scaled by the sampling factor).  Two restatements are timed, each on all
+    usable cores and on one: the NumPy + OpenBLAS mirror of potential.py:688-845 / hmc.py:85-177
+    (oracle/numpy_port.py: what the reference itself executes) and the C oracle with OpenMP
+    (oracle/gravhmc_oracle.c); `value` is the faster.  kind "port": the reference itself cannot
+    travel to the GPU box."""
+    import ctypes
     from oracle import oracle
     from oracle.numpy_port import NumpyProblem
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()
-                     if p.get("user_api") == "blas"] or [1])
-    except Exception:
-        cores = os.cpu_count()
+    from threadpoolctl import threadpool_limits
+    cores = usable_cores()
     M = mesh.size
-    k = max(1, M // 10000)
+    k = max(1, M // max_cells)
     b = mesh.cell_bounds()[::k]
     t0 = time.time()
     K = oracle.prism_gz_kernel(xp, yp, zp, b)
     Aw, wm = oracle.col_weight(K)
     t_build = time.time() - t0
     del K
-    P = NumpyProblem(Aw, dobs, 0.001 * wm, "Damping", 1.0, 0.01, wm=wm)
     Ms = wm.size
     rng = np.random.default_rng(1)
-    x = 0.001 * wm
-    L, steps, t_run = 10, 0, 0.0
-    P.leapfrog(x, rng.normal(size=Ms) * 0.001, 0.01, 2, 0.0 * wm, 1.0 * wm, 0.5)   # warm-up
-    while t_run < target_s and steps < 2000:
-        p0 = rng.normal(size=Ms) * 0.001
-        t1 = time.time()
-        x, acc, out, _ = P.leapfrog(x, p0, 0.01, L, 0.0 * wm, 1.0 * wm, 0.5)
-        t_run += time.time() - t1
-        steps += L
-    sps_sample = steps / t_run
-    # the same on one BLAS thread (SURVEY 8d asks for both), shorter
-    single = None
-    try:
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=1, user_api="blas"):
-            s1, t1run = 0, 0.0
-            while t1run < target_s / 3 and s1 < 2000:
-                p0 = rng.normal(size=Ms) * 0.001
-                t1 = time.time()
-                x, acc, out, _ = P.leapfrog(x, p0, 0.01, L, 0.0 * wm, 1.0 * wm, 0.5)
-                t1run += time.time() - t1
-                s1 += L
-            single = s1 / t1run * Ms / M
-    except Exception:
-        single = None
-    return {"value": sps_sample * Ms / M, "unit": "leapfrog steps/s", "cores": cores,
-            "single_core_value": single,
-            "kind": "port",
-            "sample": "NumPy/OpenBLAS mirror of potential.py:688-845 + hmc.py:85-177; same N=%d "
-                      "observations, every %d-th cell (%d of %d); %d steps in %.1f s (%.2f steps/s "
-                      "on the sample, scaled by %d/%d); %d BLAS threads; sample kernel build + "
-                      "weighting %.1f s" % (xp.size, k, Ms, M, steps, t_run, sps_sample, Ms, M,
-                                            cores, t_build)}
+    L = 10
+    low, high = 0.0 * wm, 1.0 * wm
+    gomp = None
+    for name in ("libgomp.so.1", "libgomp.so"):
+        try:
+            gomp = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+
+    def timed(problem, budget):
+        x = 0.001 * wm
+        problem.leapfrog(x, rng.normal(size=Ms) * 0.001, 0.01, 2, low, high, 0.5)   # warm-up
+        steps, t_run = 0, 0.0
+        while t_run < budget and steps < 4000:
+            p0 = rng.normal(size=Ms) * 0.001
+            t1 = time.time()
+            x, _acc, _out, _ = problem.leapfrog(x, p0, 0.01, L, low, high, 0.5)
+            t_run += time.time() - t1
+            steps += L
+        return steps / t_run, steps, t_run
+
+    res = {}
+    Pn = NumpyProblem(Aw, dobs, 0.001 * wm, "Damping", 1.0, 0.01, wm=wm)
+    Pc = oracle.Problem(Aw, dobs, 0.001 * wm, "Damping", 1.0, 0.01, wm=wm)
+    share = target_s / 6.0
+    for threads, budget in ((cores, 2 * share), (1, share)):
+        with threadpool_limits(limits=threads, user_api="blas"):
+            res[("numpy_openblas", threads)] = timed(Pn, budget)
+        if gomp is not None:
+            gomp.omp_set_num_threads(threads)
+        res[("c_openmp", threads)] = timed(Pc, budget)
+    if gomp is not None:
+        gomp.omp_set_num_threads(cores)
+    best = max((("numpy_openblas", cores), ("c_openmp", cores)), key=lambda kk: res[kk][0])
+    scale = Ms / M
+    table = {"%s_%dthr" % kk: res[kk][0] * scale for kk in sorted(res)}
+    return {"value": res[best][0] * scale, "unit": "leapfrog steps/s", "cores": cores,
+            "kind": "port", "restatement": best[0],
+            "single_core_value": max(res[("numpy_openblas", 1)][0], res[("c_openmp", 1)][0]) * scale,
+            "thread_scaling_steps_per_s": table,
+            "host_cpus_visible": os.cpu_count(),
+            "sample": "same N=%d observations, every %d-th cell (%d of %d, G sample %.0f MB); L=%d; "
+                      "%s on %d threads: %d steps in %.1f s (%.2f steps/s on the sample, scaled by %d/%d); "
+                      "sample kernel build + weighting %.1f s; cores = affinity capped by the cgroup CPU quota "
+                      "(os.cpu_count() = %s)"
+                      % (xp.size, k, Ms, M, Aw.nbytes / 1e6, L, best[0], cores, res[best][1], res[best][2],
+                         res[best][0], Ms, M, t_build, os.cpu_count())}
+
+
+def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: None):
+    """One chain through the sampler's own path (Engine.run_chain), momenta drawn in the reference's
+    RNG order (legacy global generator, hmc.py:95,164).  Returns (elapsed_s, accepted, trajectories,
+    profile).  ONE trajectory is drawn before the clock starts; every other draw (the first look-ahead
+    included) happens inside the timed region, overlapped with the GPU where the pipeline manages to."""
+    import itertools
+    np.random.seed(seed)
+
+    def prepare(total_steps):
+        plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
+
+        def draws():
+            for n in plan:
+                yield n, np.random.randn(M) * Sigma, np.random.rand()
+
+        gen = draws()
+        head = list(itertools.islice(gen, 1))          # the first trajectory only
+        return plan, itertools.chain(head, gen)
+
+    def run(prepared):
+        plan, gen = prepared
+        stat = {"acc": 0, "traj": 0}
+
+        def on_result(n, acc, out5, x):
+            stat["acc"] += int(acc)
+            stat["traj"] += 1
+
+        eng.run_chain(gen, dt, on_result)
+        return stat["acc"], stat["traj"]
+
+    if warmup > 0:
+        run(prepare(warmup))
+    prepared = prepare(steps)
+    eng.synchronize()
+    barrier()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    naccept, ntraj = run(prepared)
+    eng.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    return elapsed, naccept, ntraj, prof
+
+
+def c1_block(device, want_cpu):
+    """BASELINE.json's target configuration (north_star: uniformgrid 20 x 30 x 10, Damping, one chain)
+    measured in the same process, for the `extra` field of the line: steps/s, us per potential
+    evaluation inside the resident chain kernel, and the CPU baseline at full size."""
+    import gravinv3dhmc_amd as g
+    name = "c1_uniform_20x30x10"
+    mesh, xp, yp, zp, rho = make_problem(name)
+    N, M = xp.size, mesh.size
+    eng = g.Engine(N, M, device=device)
+    eng.set_obs(xp, yp, zp)
+    eng.set_cells(mesh.cell_bounds(), 0)
+    eng.build_G()
+    d_true = eng.forward(rho)
+    wm = eng.weight(0.5)
+    dobs = d_true + np.random.default_rng(0).normal(0.0, 0.02 * np.abs(d_true).max(), N)
+    eng.set_data(dobs)
+    eng.set_reg("Damping", 1.0, 0.01, mesh.shape, 0.001 * wm)
+    eng.chain_init(0.001 * wm, 0.0 * wm, 1.0 * wm)
+    steps, warmup, L, dt = 20000, 2000, 10, WORKLOADS[name][4]
+    elapsed, nacc, ntraj, prof = run_single_chain(eng, M, 0.001, dt, L, steps, warmup, 100)
+    cstat = eng.chain_stats()
+    out = {"workload": name, "N_obs": int(N), "M_cells": int(M), "G_bytes": int(N) * int(M) * 8,
+           "value": steps / elapsed, "unit": "leapfrog steps/s", "steps": steps, "warmup": warmup,
+           "us_per_step": elapsed / steps * 1e6, "trajectories": ntraj, "accepted": nacc,
+           "kernel": "resident_chain_kernel (G in LDS, %d launches)" % cstat["resident_launches"]
+                     if cstat["resident_evaluations"] else "sweep_kernel per launch",
+           "us_per_evaluation_in_kernel": prof["sweep_ms"] * 1e3 / max(1, prof["sweeps"]),
+           "reference_formulation_equiv_GBps": 2 * N * M * 8 * steps / elapsed / 1e9}
+    if want_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(mesh, xp, yp, zp, dobs, target_s=6.0, max_cells=M)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    eng.close()
+    return out
 
 
 def main():
@@ -199,6 +325,8 @@ def main():
                     help="never store G: re-evaluate the kernel entries in every pass")
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra block (C1, north_star's target configuration) of the default line")
     ap.add_argument("--shard", action="store_true",
                     help="ONE chain whose cells (columns of G) are split over the ranks' GPUs, "
                          "all-reduce of the forward partial per step (strong scaling); default "
@@ -329,51 +457,13 @@ def main():
         elapsed = time.perf_counter() - t0
         barrier()
     else:
-        # the reference's RNG stream (legacy global generator), one chain per rank
-        np.random.seed(100 if args.shard else 100 + rank)   # a sharded chain shares one stream
-
-        def prepare(total_steps):
-            """Trajectories of L steps until total_steps leapfrog steps are done, pipelined as the
-            sampler does it (Engine.run_chain): momenta are drawn in the reference's RNG order one
-            trajectory ahead, so the host draw overlaps the GPU and an accepted proposal's last
-            sweep already takes the next trajectory's first step."""
-            plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
-
-            def draws():
-                for n in plan:
-                    yield n, np.random.randn(M) * Sigma, np.random.rand()
-
-            # a sampler in steady state has its next batch drawn while the GPU was busy: draw the
-            # first batch (+ its lookahead) before the clock starts, the rest overlaps as usual
-            import itertools
-            gen = draws()
-            head = list(itertools.islice(gen, eng.default_batch() + 1))
-            return plan, itertools.chain(head, gen)
-
-        def run(prepared):
-            plan, gen = prepared
-            stat = {"acc": 0, "traj": 0}
-
-            def on_result(n, acc, out5, x):
-                stat["acc"] += int(acc)
-                stat["traj"] += 1
-
-            eng.run_chain(gen, dt, on_result)
-            return stat["acc"], stat["traj"]
-
-        if args.warmup > 0:
-            run(prepare(args.warmup))
-        prepared = prepare(args.steps)
-        eng.synchronize()
-        barrier()
-        eng.profile_enable(True)
-        t0 = time.perf_counter()
-        naccept, ntraj = run(prepared)
-        eng.synchronize()
-        elapsed = time.perf_counter() - t0
-        barrier()
-    prof = eng.profile_read()
-    eng.profile_enable(False)
+        # the reference's RNG stream (legacy global generator), one chain per rank (a sharded chain
+        # shares one stream)
+        elapsed, naccept, ntraj, prof = run_single_chain(eng, M, Sigma, dt, L, args.steps, args.warmup,
+                                                         100 if args.shard else 100 + rank, barrier)
+    if CPG > 1:
+        prof = eng.profile_read()
+        eng.profile_enable(False)
     # what a pure read of the same matrix reaches on this device (outside the timed region)
     stream_gbps = None
     if not args.matrix_free and int(N) * int(M) * 8 >= (1 << 30):
@@ -381,6 +471,7 @@ def main():
     elapsed = ranks.max(elapsed)
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic(args.workload)
         sweep_ms = prof["sweep_ms"] / max(1, prof["sweeps"])
         bytes_sweep = prof["bytes_per_sweep"]          # N*M_local*8: one read of this rank's G
         achieved = bytes_sweep / (sweep_ms * 1e-3) / 1e9
@@ -403,7 +494,7 @@ def main():
                        "device": info["name"], "cus": info["cus"],
                        "G_build_s": round(t_build, 3), "weighting_s": round(t_weight, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": pmc_traffic(args.workload),
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_from_profile": traffic_src,
                          "kernel": "sweep_kernel (fused adjoint+update+forward, one read of G)",
                          "launches": prof["sweeps"], "avg_ms": sweep_ms,
                          "algorithmic_bytes_per_launch": bytes_sweep,
@@ -482,8 +573,16 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(mesh, xp, yp, zp, dobs)
             except Exception as e:  # the baseline is a reported extra, never the product path
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(line))
     eng.close()
+    if rank == 0:
+        if world == 1 and args.workload == "c2_uniform_100x100x50" and CPG == 1 and not args.shard \
+                and not args.matrix_free and not args.no_extra:
+            # north_star's target configuration next to the headline workload, same process
+            try:
+                line["extra"] = {"c1_uniform_20x30x10": c1_block(dev, not args.no_cpu_baseline)}
+            except Exception as e:
+                line["extra"] = {"c1_uniform_20x30x10": {"error": "%s: %s" % (type(e).__name__, e)}}
+        print(json.dumps(line))
     ranks.close()
 
 

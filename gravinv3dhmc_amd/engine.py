@@ -338,7 +338,9 @@ class Engine(object):
                 raise job[1]["e"]
             return job[1]["r"]
 
-        cur = take(batch)
+        # a momentum of >= 1 MB takes milliseconds to draw: the first call then carries ONE trajectory,
+        # so the device starts after two draws instead of batch + 1
+        cur = take(1 if self.M * 8 >= (1 << 20) else batch)
         look = take(1) if cur else []
         job = start(cur, look, self._prepare_batch(cur, look[0] if look else None, want_x)) if cur else None
         while cur:
