@@ -225,6 +225,11 @@ def cpu_baseline(mesh, xp, yp, zp, dobs, target_s=16.0, max_cells=10000):
                          res[best][0], Ms, M, t_build, os.cpu_count())}
 
 
+#: (U, U_data, U_model) of the chain after its last trajectory: lets two runs of the same workload
+#: (e.g. sharded and unsharded) be compared through their JSON lines
+LAST_STATE = {"U": None}
+
+
 def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: None):
     """One chain through the sampler's own path (Engine.run_chain), momenta drawn in the reference's
     RNG order (legacy global generator, hmc.py:95,164).  Returns (elapsed_s, accepted, trajectories,
@@ -251,6 +256,7 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
         def on_result(n, acc, out5, x):
             stat["acc"] += int(acc)
             stat["traj"] += 1
+            LAST_STATE["U"] = [float(v) for v in out5[:3]]
 
         eng.run_chain(gen, dt, on_result)
         return stat["acc"], stat["traj"]
@@ -488,7 +494,8 @@ def main():
                        "G_bytes": int(N) * int(M) * 8, "regulariser": extra["reg"],
                        "matrix_free": bool(args.matrix_free), "wavelet_nnz": nnz,
                        "chains_per_gpu": CPG, "dt": dt, "traj_len": L, "trajectories": ntraj,
-                       "accepted": naccept, "speculative_first_steps": eng.chain_stats() if CPG == 1 else None, "parallelism": ("1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step"
+                       "accepted": naccept, "final_U": LAST_STATE["U"] if CPG == 1 else None,
+                       "speculative_first_steps": eng.chain_stats() if CPG == 1 else None, "parallelism": ("1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step"
                                        % (world, args.shard_backend)) if args.shard
                        else "chain-parallel x%d (no collective)" % world,
                        "device": info["name"], "cus": info["cus"],

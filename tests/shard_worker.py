@@ -25,7 +25,8 @@ from helpers import c1_inputs, relmax  # noqa: E402
 def main():
     ranks = Ranks()
     backend = sys.argv[1] if len(sys.argv) > 1 else "gloo"
-    ranks.local_rank = 0  # all ranks on GPU 0
+    if not (len(sys.argv) > 2 and sys.argv[2] == "one-gpu-per-rank"):
+        ranks.local_rank = 0  # all ranks on GPU 0
     gc = gold("c1_chain.npz")
     mesh, xp, yp, zp = c1_inputs()
     dobs = gc["dobs"]
@@ -48,6 +49,52 @@ def main():
         b = single.misfit_and_grad(x, 0.001 * wm1, None, None, "mandatory", 1000, 0.7, regulization=reg, beta=0.001)
         errs += [abs(a[0] - b[0]) / abs(b[0]), relmax(a[1], b[1]), relmax(a[2], b[2]), abs(a[4] - b[4]) / abs(b[4])]
     out["potential"] = max(errs)
+    # the regulariser is re-sent only when its VALUES change, decided identically on every rank
+    # (gh_set_reg is collective for the stencil kinds): fresh temporaries of equal content, whose
+    # addresses differ from rank to rank and call to call, must neither desynchronise the ranks nor
+    # trigger a re-send; an in-place edit must
+    eng = sharded._engine
+    sharded._resend_count = 0
+    orig = eng.set_reg
+
+    def counting(*a, **k):
+        sharded._resend_count += 1
+        return orig(*a, **k)
+
+    eng.set_reg = counting
+    prior = 0.001 * wm1
+    for k in range(3):
+        tmp = np.array(prior) + 0.0                          # fresh temporary every call
+        a = sharded.misfit_and_grad(x, tmp, None, None, "mandatory", 1000, 0.7, regulization="TV", beta=0.001)
+        b = single.misfit_and_grad(x, prior * 1.0, None, None, "mandatory", 1000, 0.7, regulization="TV", beta=0.001)
+        errs.append(abs(a[0] - b[0]) / abs(b[0]))
+    out["resends_equal_content"] = sharded._resend_count      # 0: TV with this prior was the last one sent
+    prior2 = prior.copy()
+    prior2[ranks.world] *= 1.5                                 # same edit on every rank
+    a = sharded.misfit_and_grad(x, prior2, None, None, "mandatory", 1000, 0.7, regulization="TV", beta=0.001)
+    b = single.misfit_and_grad(x, prior2, None, None, "mandatory", 1000, 0.7, regulization="TV", beta=0.001)
+    out["resends_after_edit"] = sharded._resend_count
+    out["edit_potential"] = abs(a[0] - b[0]) / abs(b[0])
+    eng.set_reg = orig
+    out["potential"] = max(errs)
+    # more than three batches of two trajectories through run_chain with overlap requested: with the
+    # host-staged (gloo) all-reduce no batch may run while results are gathered (one process group,
+    # two threads); same chain as the unsharded engine
+    rngc = np.random.default_rng(11)
+    trajs = [(int(rngc.integers(2, 7)), rngc.normal(size=M) * 0.001, float(rngc.uniform())) for _ in range(9)]
+    got = {}
+    for tag, model in (("sharded", sharded), ("single", single)):
+        e = model._engine
+        e.set_reg("MS", 1.0, 0.001, model.mshape, 0.001 * wm1)
+        e.chain_init(0.001 * wm1, 0.0 * wm1, 1.0 * wm1)
+        res = []
+        e.run_chain(iter(trajs), 0.01, lambda L, acc, o, xs, res=res: res.append((acc, o.copy(), xs)), want_x=True,
+                    batch=2, overlap=True)
+        got[tag] = res
+    out["overlap_n"] = len(got["sharded"])
+    out["overlap_decisions"] = [r[0] for r in got["sharded"]] == [r[0] for r in got["single"]]
+    out["overlap_out5"] = max(relmax(a[1], b[1]) for a, b in zip(got["sharded"], got["single"]))
+    out["overlap_x"] = max([relmax(a[2], b[2]) for a, b in zip(got["sharded"], got["single"]) if a[0]] or [0.0])
     # cells split without regard to the planes (2000 each): the stencil kinds are refused
     ragged = g.GravMagModule(dobs, (0, 2000, 0, 3000, 0, 1000), (100, 100, 100), (xp, yp, zp),
                              shard=ranks, shard_backend=backend, **kw)

@@ -991,7 +991,48 @@ def test_sharded_chain_three_ranks_one_gpu():
         assert r["tv_lines_equal"] and r["tv_misfit"] < 1e-9 and r["tv_model"] < 2e-8
         assert r["ref_rows"] < 1e-7               # and they are the reference's rows (8 decimals)
         assert r["spec"]["spec_hits"] > 0
+        # regulariser cache keyed by content: no re-send for fresh temporaries, one after an edit
+        assert r["resends_equal_content"] == 0 and r["resends_after_edit"] == 1 and r["edit_potential"] < 1e-12
+        # batches of two through run_chain(overlap=True): nothing overlaps over gloo, same chain
+        assert r["overlap_n"] == 9 and r["overlap_decisions"] and r["overlap_out5"] < 1e-9 and r["overlap_x"] < 1e-9
     print("sharded 3-rank check:", res[0])
+
+
+def test_sharded_chain_rccl_one_gpu_per_rank():
+    """The RCCL transport with more than one rank (ncclAllReduce over xGMI on the context streams):
+    two ranks, one GPU each, the same checks as the gloo run above -- identical chain lines on all
+    ranks, agreement with the unsharded engine.  Needs two GPUs: skipped on the 1-GPU boxes the suite
+    normally runs on (multi-rank RCCL is then UNVERIFIED ON HARDWARE)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import ctypes
+    # (not torch.cuda.device_count(): torch brings its own HIP runtime, and two of them in the
+    # process that holds libgravhmc contexts corrupt the heap at exit)
+    ndev = ctypes.c_int(0)
+    ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ndev))
+    if ndev.value < 2:
+        pytest.skip("needs two GPUs (multi-rank RCCL cannot run on one)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "shard_worker.py"), "rccl", "one-gpu-per-rank"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert [r["rank"] for r in res] == [0, 1] and [r["M_local"] for r in res] == [3000, 3000]
+    for r in res:
+        assert r["wm"] == 0.0 and r["fwd"] < 1e-13 and r["adj"] == 0.0 and r["potential"] < 1e-12
+        assert r["lines_equal"] and r["misfit"] < 1e-9 and r["model"] < 2e-8
+        assert r["tv_lines_equal"] and r["tv_misfit"] < 1e-9 and r["tv_model"] < 2e-8
+        assert r["overlap_n"] == 9 and r["overlap_decisions"] and r["overlap_out5"] < 1e-9
 
 
 # ------------------------------------------------------------------------------ matrix-free
@@ -1623,3 +1664,43 @@ def test_c5_shaped_row_panels_and_column_shards_together():
             assert r["U"] < 1e-11 and r["grad"] < 1e-10 and r["dpre"] < 1e-10, (tag, reg, r)
         c = res[tag]["chain"]
         assert c["decisions_equal"] and c["n"] == 5 and c["out5"] < 1e-9 and c["x"] < 1e-9, (tag, c)
+
+
+def test_bench_shard_rehearsal_two_ranks_one_gpu():
+    """The N > 1 launch path of bench.py as the driver starts it (torch.distributed.run, one rank per
+    process), rehearsed on one GPU: ONE chain whose cells are sharded over two ranks
+    (`--shard --shard-backend gloo --rehearse-on-one-gpu`) on a small C5-shaped workload (the full
+    200 x 200 observation grid, 1/600 of the cells).  The JSON line must say strong scaling, count the
+    chain's steps once, and the chain must end where the unsharded run of the same command ends."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    common = ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "600", "--steps", "30", "--warmup", "10",
+              "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--shard", "--shard-backend", "gloo", "--rehearse-on-one-gpu"] + common
+    two = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, (two.stdout[-1000:], two.stderr[-3000:])
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 prints, once
+    sh = json.loads(lines[0])
+    assert sh["scaling"] == "strong" and sh["n_gpus"] == 2 and sh["steps"] == 30
+    assert abs(sh["value"] - 30 / (sh["ms_per_step"] * 30e-3)) < 1e-6 * sh["value"]   # steps counted once
+    assert sh["config"]["M_cells"] == single["config"]["M_cells"] == 4000 and sh["config"]["N_obs"] == 40000
+    assert sh["config"]["trajectories"] == single["config"]["trajectories"] == 3
+    assert sh["config"]["accepted"] == single["config"]["accepted"]
+    assert relmax(sh["config"]["final_U"], single["config"]["final_U"]) < 1e-9
+    print("bench --shard rehearsal: %.1f steps/s on 2 ranks of one GPU (gloo), unsharded %.1f; final U %r"
+          % (sh["value"], single["value"], sh["config"]["final_U"]))
