@@ -364,6 +364,7 @@ int gh_set_data(gh_ctx *c, const double *dobs, const double *grav_fix)
     for (auto &v : t) v -= mean;
     TRY(h2d(c, c->dobs_c, t.data(), N));
     c->have_fix = grav_fix != nullptr;
+    c->gfix_sum = grav_fix ? PW::sum(grav_fix, N) : 0.0;
     if (grav_fix) TRY(h2d(c, c->gfix, grav_fix, N));
     c->have_data = true;
     c->chain_ready = false;
@@ -495,6 +496,7 @@ int gh_misfit_and_grad(gh_ctx *c, const double *x, double out3[3], double *grad,
     a.greg = o.greg;
     a.g_out = c->tmpM;
     TRY(launch_sweep(c, a));
+    TRY(scal_ready(c, o));
     HIPCHK(c, hipMemcpyAsync(c->h_scal, o.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TRY(d2h(c, grad, c->tmpM, (size_t)c->M));
     if (dpre) TRY(d2h(c, dpre, o.d, (size_t)c->N));
@@ -688,6 +690,7 @@ int gh_chain_init(gh_ctx *c, const double *x0, const double *low, const double *
     TRY(h2d(c, c->low, low, (size_t)c->M));
     TRY(h2d(c, c->high, high, (size_t)c->M));
     TRY(eval_forward(c, c->xb[0], c->st[0]));
+    TRY(scal_ready(c, c->st[0]));
     TRY(d2h(c, c->h_scal, c->st[0].scal, 4));
     c->U_cur[0] = c->h_scal[2];
     c->U_cur[1] = c->h_scal[0];
@@ -831,6 +834,8 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
         if (spec) TRY(finalize(c, c->xb[xs], c->st[ss]));
     }
     double *h = c->h_scal;
+    TRY(scal_ready(c, c->st[sin]));
+    if (spec) TRY(scal_ready(c, c->st[ss]));
     HIPCHK(c, hipMemcpyAsync(h, c->st[sin].scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h + 16, c->pp_part, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost,
                              c->stream));

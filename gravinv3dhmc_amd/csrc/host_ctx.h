@@ -66,6 +66,10 @@ struct gh_ctx {
         int64_t launches = 0;
     } tm;
     int slab_live = 0;        // rows of the slab the last forward launch wrote
+    // one-launch epilogue (reduce_finish_kernel): sums of the slab rows from the sweep, |r|^2 partials
+    double *dsum = nullptr;
+    bool dsum_live = false;   // the last forward launch delivered dsum for all slab_live rows
+    double gfix_sum = 0.0;
     bool NT = false;
     int n_teams = 0, grid = 0;
     int n_teams_sweep = 0;   // teams of the sweep launch (n_teams may be larger: size of the pp partials)
@@ -84,6 +88,8 @@ struct gh_ctx {
     // private to gh_misfit_and_grad.  Swapping indices makes accept/reject free.
     struct StateSet {
         double *r = nullptr, *greg = nullptr, *d = nullptr, *scal = nullptr;
+        double *part = nullptr;        // |r|^2 and R partials of a one-launch epilogue
+        mutable bool pending = false;  // scal[0..2] still to be summed from `part` (scal_ready)
     } st[4];
     double *xb[4] = {nullptr, nullptr, nullptr, nullptr};
     double *pb[2] = {nullptr, nullptr};

@@ -82,6 +82,29 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
         src = d_out;
         nseg = 1;
+    } else if (c->grid > 64 && c->slab2 && c->slab2_rows == 1 && c->dsum_live && o.part) {
+        // one reduction stage and the slab rows' sums at hand: the whole epilogue in one launch
+        ReduceFinishArgs fa{};
+        fa.slab = c->slab;
+        fa.n_rows_slab = c->slab_live > 0 ? c->slab_live : c->grid;
+        fa.n_dpart = c->n_dpart;
+        fa.n_regpart = c->n_regpart;
+        fa.ld = c->ld;
+        fa.N = c->N;
+        fa.dsum = c->dsum;
+        fa.gfix_sum = gfix ? c->gfix_sum : 0.0;
+        fa.gfix = gfix;
+        fa.dobs_c = c->dobs_c;
+        fa.d = d_out;
+        fa.r = r_out;
+        fa.scal = scal_out;
+        fa.r2part = o.part;
+        fa.ra = ra;
+        fa.ra.regpart = o.part + c->n_dpart;
+        reduce_finish_kernel<<<dim3((unsigned)(c->n_dpart + c->n_regpart)), dim3(256), 0, c->stream>>>(fa);
+        HIPCHK(c, hipGetLastError());
+        o.pending = true;
+        return GH_OK;
     } else if (c->grid > 64 && c->slab2) {
         // many slab rows: first stage of the reduction and the regulariser share one launch,
         // finish_kernel sums the 16 segments
@@ -94,6 +117,7 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         src = c->slab;
         nseg = c->slab_live > 0 ? c->slab_live : c->grid;
     }
+    o.pending = false;
     FinishArgs fa;
     fa.N = c->N;
     fa.ld = c->ld;
@@ -109,6 +133,16 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
     fa.scal = scal_out;
     finish_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(fa);
     HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+// scal[0..2] of a state set, summed from the partials of a one-launch epilogue if still pending
+static int scal_ready(gh_ctx *c, const gh_ctx::StateSet &o)
+{
+    if (!o.pending) return GH_OK;
+    scal_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(o.part, c->n_dpart, c->n_regpart, c->alpha, o.scal);
+    HIPCHK(c, hipGetLastError());
+    o.pending = false;
     return GH_OK;
 }
 
@@ -148,6 +182,11 @@ static int ensure_work(gh_ctx *c)
         TRY(dalloc(c, &c->slab2, (size_t)c->slab2_rows * ld));
     }
     c->n_dpart = (int)((c->ld + 31) / 32);
+    if (c->grid > 64 && c->slab2_rows == 1 && c->TW == 16 && c->n_panels == 1 && !c->mf &&
+        env_int("GRAVHMC_EPILOGUE1", 1) != 0) {
+        TRY(dalloc(c, &c->dsum, (size_t)c->grid));
+        for (int i = 0; i < 4; ++i) TRY(dalloc(c, &c->st[i].part, (size_t)c->n_dpart + (size_t)((c->M + 255) / 256)));
+    }
     c->n_regpart = (int)((c->M + 255) / 256);
     c->n_pp0 = (int)std::min<int64_t>(1024, (c->M + 255) / 256);
     TRY(dalloc(c, &c->dpart, (size_t)c->n_dpart));

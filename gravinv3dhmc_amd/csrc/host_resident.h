@@ -321,6 +321,7 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
     // bring the per-launch state (d, r, scalars of the current sample) back in step with x
     c->spec_valid = c->pn_valid = false;
     TRY(eval_forward(c, c->xb[c->xcur], c->st[c->cur]));
+    TRY(scal_ready(c, c->st[c->cur]));
     TRY(d2h(c, c->h_scal, c->st[c->cur].scal, 4));
     c->U_cur[0] = c->h_scal[2];
     c->U_cur[1] = c->h_scal[0];

@@ -488,11 +488,18 @@ static void team_resume(gh_ctx *c)
 
 static int launch_sweep(gh_ctx *c, SweepArgs &a)
 {
-    if (a.mode & SW_FWD) c->slab_live = c->grid;
+    if (a.mode & SW_FWD) {
+        c->slab_live = c->grid;
+        c->dsum_live = false;
+    }
     if (c->mf) return launch_mf(c, a);
     if (c->n_panels == 1) {
         a.row0 = 0;
         a.rows = c->ld;
+        if ((a.mode & SW_FWD) && c->TW == 16 && c->dsum) {
+            a.dsum = c->dsum;  // sums of the slab rows: the epilogue then needs one launch
+            c->dsum_live = true;
+        }
         return launch_sweep_one(c, a);
     }
     // more rows than one workgroup holds of a column.  The fused step (adjoint + update + forward)

@@ -79,6 +79,7 @@ struct SweepArgs {
     double *g_out;        // M (SW_GOUT)
     double *slab;         // gridDim.x x ld (SW_FWD)
     double *pp_part;      // n_teams (SW_PFIN): sum of p_j^2 over the team's columns
+    double *dsum;         // gridDim.x or nullptr (SW_FWD, TW == 16): sum over the rows of the block's slab row
 };
 
 using d2 = double __attribute__((ext_vector_type(2)));
@@ -293,10 +294,21 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
             }
         } else {
             d2 *out = reinterpret_cast<d2 *>(a.slab + (int64_t)blockIdx.x * ld + a.row0);
+            double ds = 0.0;
 #pragma unroll
             for (int k = 0; k < EPT2; ++k) {
                 const int e = k * TEAM_THREADS + ttid;
-                if (e < ld2) out[e] = dacc[k];
+                if (e < ld2) {
+                    out[e] = dacc[k];
+                    ds += dacc[k].x;
+                    ds += dacc[k].y;
+                }
+            }
+            if (TW == 16 && a.dsum) {
+                // sum of this slab row (pad rows are zero): lets the epilogue know mean(d) before it
+                // has reduced the slab (reduce_finish_kernel)
+                const double t = block_allreduce_sum(ds, scratch, TW);
+                if (tid == 0) a.dsum[blockIdx.x] = t;
             }
         }
     }
@@ -550,6 +562,101 @@ reduce_reg_kernel(const double *slab, int n_rows_slab, int64_t ld, int nseg, int
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += red8[q][rx];
         slab2[(int64_t)seg * ld + i] = s;
+    }
+}
+
+// The whole per-step epilogue in ONE launch, for d that needs a single reduction stage (ld > 8192)
+// after a sweep that also delivered the sums of its slab rows (dsum).  Because
+//     sum_i d_i = sum_t sum_i slab[t][i] = sum_t dsum[t],
+// every block knows mean(d + grav_fix) (potential.py:706) before the slab is reduced, so the blocks
+// that reduce the slab for 32 observations each can form the residual and their share of |r|^2 at
+// once; the other blocks evaluate the regulariser.  What finish_kernel -- ONE workgroup walking
+// 570 KB at N = 10^4, 14 us -- did in a second launch is gone; the three scalars are summed from
+// the partials by scal_kernel when somebody reads them (once per trajectory).  A last-block ticket
+// inside this kernel was tried first: the agent-scope release fence every block needs costs more
+// than the launch it saves (30 us).  (The mean is the same number up to the association of its
+// sum; a shift delta of the mean changes |r|^2 by N delta^2 only, sum r = 0.)
+struct ReduceFinishArgs {
+    const double *slab;
+    int n_rows_slab, n_dpart, n_regpart;
+    int64_t ld, N;
+    const double *dsum;      // n_rows_slab
+    double gfix_sum;         // sum of grav_fix (0 without)
+    const double *gfix, *dobs_c;
+    double *d, *r, *scal;    // as FinishArgs (scal: only [3] = mean is written here)
+    double *r2part;          // n_dpart (ra.regpart: the n_regpart partials of R, kept with them)
+    RegArgs ra;
+};
+
+__global__ void __launch_bounds__(256) reduce_finish_kernel(ReduceFinishArgs a)
+{
+    __shared__ double red8[8][33];
+    __shared__ double red[4];
+    const int n_red = a.n_dpart;
+    if ((int)blockIdx.x >= n_red) {
+        reg_block(a.ra, blockIdx.x - n_red, red);
+    } else {
+        // mean of d + grav_fix from the slab rows' sums, identical bits in every block
+        double ds = 0.0;
+        for (int t = threadIdx.x; t < a.n_rows_slab; t += 256) ds += a.dsum[t];
+        const double mean = (block_allreduce_sum(ds, red, 4) + a.gfix_sum) / (double)a.N;
+        const int rx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int64_t i = (int64_t)blockIdx.x * 32 + rx;
+        double acc = 0.0;
+        if (i < a.ld) {
+            int t = ty;
+            for (; t + 56 < a.n_rows_slab; t += 64) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = a.slab[(int64_t)(t + 8 * u) * a.ld + i];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; t < a.n_rows_slab; t += 8) acc += a.slab[(int64_t)t * a.ld + i];
+        }
+        red8[ty][rx] = acc;
+        __syncthreads();
+        if (ty == 0) {
+            double di = 0.0, ri = 0.0;
+            if (i < a.ld) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) di += red8[q][rx];
+                a.d[i] = di;
+                if (i < a.N) {
+                    const double dinv = di + (a.gfix ? a.gfix[i] : 0.0);
+                    ri = (dinv - mean) - a.dobs_c[i];
+                }
+                a.r[i] = ri;
+            }
+            double r2 = ri * ri;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) r2 += __shfl_xor(r2, off, WAVE);
+            if (rx == 0) {
+                a.r2part[blockIdx.x] = r2;
+                if (blockIdx.x == 0) a.scal[3] = mean;
+            }
+        }
+    }
+}
+
+// The scalars of an evaluation whose epilogue ran as reduce_finish_kernel: sums of its partials in
+// index order.  Launched only when the host (or the Metropolis test) is about to read them -- once
+// per trajectory, not once per step.  part: n_dpart |r|^2 partials, then n_regpart of R.
+__global__ void __launch_bounds__(1024) scal_kernel(const double *part, int n_dpart, int n_regpart, double alpha,
+                                                    double *scal)
+{
+    __shared__ double red[16];
+    double s2 = 0.0, sr = 0.0;
+    for (int t = threadIdx.x; t < n_dpart; t += 1024) s2 += part[t];
+    for (int t = threadIdx.x; t < n_regpart; t += 1024) sr += part[n_dpart + t];
+    const double ud = block_allreduce_sum(s2, red, 16);
+    const double R = block_allreduce_sum(sr, red, 16);
+    if (threadIdx.x == 0) {
+        scal[0] = ud;
+        scal[1] = R;
+        scal[2] = ud + alpha * R;
     }
 }
 

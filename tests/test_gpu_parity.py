@@ -1704,3 +1704,47 @@ def test_bench_shard_rehearsal_two_ranks_one_gpu():
     assert relmax(sh["config"]["final_U"], single["config"]["final_U"]) < 1e-9
     print("bench --shard rehearsal: %.1f steps/s on 2 ranks of one GPU (gloo), unsharded %.1f; final U %r"
           % (sh["value"], single["value"], sh["config"]["final_U"]))
+
+
+def test_one_launch_epilogue_matches_oracle_and_two_launch_form(G, orc, monkeypatch):
+    """N > 8192: the sweep delivers the sums of its slab rows, so mean(d) is known before the slab is
+    reduced and reduction, regulariser, residual and |r|^2 take ONE launch (reduce_finish_kernel)
+    instead of two with a single-workgroup finish.  Potential, gradient and a chain against the
+    oracle, with grav_fix, for a cell-local and a stencil regulariser; and against the two-launch
+    form (GRAVHMC_EPILOGUE1=0), which differs only in the association of the mean."""
+    rng = np.random.default_rng(77)
+    N, M = 10007, 600
+    A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.2, 2, size=M))
+    dobs, gfix = rng.normal(size=N) * 3, rng.normal(size=N) * 5 + 40.0
+    Aw, wmo = orc.col_weight(A)
+    x = rng.uniform(0, 1, M) * wmo
+    trajs = [(int(rng.integers(1, 7)), rng.normal(size=M) * 0.02, float(rng.uniform())) for _ in range(6)]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GRAVHMC_EPILOGUE1", mode)
+        eng = G.Engine(N, M)
+        eng.upload_G(A)
+        wm = eng.weight(0.5)
+        eng.set_data(dobs, gfix)
+        got[mode] = []
+        for reg, shape in (("MS", (1, 1, M)), ("TV", (6, 10, 10))):
+            eng.set_reg(reg, 0.7, 0.01, shape, 0.001 * wm)
+            P = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.7, 0.01, wm=wm, shape=shape, grav_fix=gfix)
+            a, b = eng.misfit_and_grad(x), P.misfit_and_grad(x)
+            assert abs(a[0] - b[0]) < 1e-11 * abs(b[0]) and relmax(a[1], b[1]) < 1e-11 and relmax(a[2], b[2]) < 1e-11
+            low, high = 0.0 * wm, 0.3 * wm
+            xo = 0.001 * wm
+            eng.chain_init(xo, low, high)
+            res = []
+            eng.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res.append((acc, o.copy(), xs)), want_x=True)
+            for (L, p0, u), (acc, o, xs) in zip(trajs, res):
+                xo, acco, oo, _ = P.leapfrog(xo, p0, 0.002, L, low, high, u)
+                assert acc == acco and relmax(o, oo) < 1e-9
+                if acc:
+                    assert relmax(xs, xo) < 1e-9
+            got[mode].append((a, res))
+        eng.close()
+    for (a1, r1), (a0, r0) in zip(got["1"], got["0"]):
+        assert abs(a1[0] - a0[0]) <= 1e-13 * abs(a0[0]) and relmax(a1[1], a0[1]) < 1e-12
+        for (c1, o1, x1), (c0, o0, x0) in zip(r1, r0):
+            assert c1 == c0 and relmax(o1, o0) < 1e-11
