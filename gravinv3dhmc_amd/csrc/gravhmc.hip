@@ -166,11 +166,12 @@ int gh_build_G(gh_ctx *c)
         c->mf_fused = c->ld <= 16384 && env_int("GRAVHMC_MF_FUSED", 1) != 0;
         if (c->cell_kind == GH_CELL_TESSEROID) {
             const int64_t N = c->N;
-            TRY(dalloc(c, &c->tconv, (size_t)(4 * N)));
+            TRY(dalloc(c, &c->tconv, (size_t)(6 * N)));
             tess_convert_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream>>>(
                 c->obs[0], c->obs[1], c->obs[2], N, c->tconv, c->tconv + N, c->tconv + 2 * N,
-                c->tconv + 3 * N);
+                c->tconv + 3 * N, c->tconv + 4 * N, c->tconv + 5 * N);
             HIPCHK(c, hipGetLastError());
+            c->mf_exact = env_int("GRAVHMC_MF_EXACT", 0) != 0;
             if (c->mf_fused) {
                 // what depends on the cell alone, once per cell instead of once per (obs, cell) pair
                 TRY(dalloc(c, &c->mf_cellc, (size_t)c->M * TESS_NC, false));

@@ -173,11 +173,14 @@ static MfGeom mf_geom(const gh_ctx *c)
         g.o1 = c->tconv + c->N;
         g.o2 = c->tconv + 2 * c->N;
         g.o3 = c->tconv + 3 * c->N;
+        g.o4 = c->tconv + 4 * c->N;
+        g.o5 = c->tconv + 5 * c->N;
     } else {
         g.o0 = c->obs[0];
         g.o1 = c->obs[1];
         g.o2 = c->obs[2];
         g.o3 = nullptr;
+        g.o4 = g.o5 = nullptr;
     }
     g.bounds6 = c->bounds;
     g.ratio = c->ratio;
@@ -199,7 +202,8 @@ static mf_fused_fn mf_fused_for_kind(int T, int ept)
 static mf_fused_fn mf_fused_for(const gh_ctx *c)
 {
     if (c->cell_kind != GH_CELL_TESSEROID) return mf_fused_for_kind<0>(c->mf_T, c->mf_EPT);
-    return c->mf_near_on ? mf_fused_for_kind<2>(c->mf_T, c->mf_EPT) : mf_fused_for_kind<1>(c->mf_T, c->mf_EPT);
+    if (!c->mf_near_on) return mf_fused_for_kind<1>(c->mf_T, c->mf_EPT);
+    return c->mf_exact ? mf_fused_for_kind<2>(c->mf_T, c->mf_EPT) : mf_fused_for_kind<3>(c->mf_T, c->mf_EPT);
 }
 
 // Tesseroids, fused pass: list of the pairs whose root must be subdivided (or flags an error), with

@@ -1120,7 +1120,7 @@ tess_gz_kernel(const double *__restrict__ lon_r, const double *__restrict__ sinl
 // obs (lon, lat, height) -> (lon rad, sin lat, cos lat, R + h)   (tesseroid.py:109-123)
 __global__ void tess_convert_kernel(const double *lon, const double *lat, const double *h,
                                     int64_t N, double *lon_r, double *sinlat, double *coslat,
-                                    double *radius)
+                                    double *radius, double *sinlon = nullptr, double *coslon = nullptr)
 {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1131,6 +1131,10 @@ __global__ void tess_convert_kernel(const double *lon, const double *lat, const 
     sinlat[i] = sin(la);
     coslat[i] = cos(la);
     radius[i] = 6378137.0 + h[i];
+    if (sinlon) {
+        sinlon[i] = sin(lon_r[i]);
+        coslon[i] = cos(lon_r[i]);
+    }
 }
 
 // ------------------------------------------------------------- wavelet-compressed forward
@@ -1376,6 +1380,7 @@ struct MfGeom {
     int kind;  // 0 prism, 1 tesseroid
     int64_t N, M;
     const double *o0, *o1, *o2, *o3;  // prism: x,y,z,-  tesseroid: lon_r, sinlat, coslat, radius
+    const double *o4, *o5;            // tesseroid: sin lon, cos lon (fast leaf)
     const double *bounds6;
     double ratio;
 };
@@ -1491,11 +1496,12 @@ mf_forward_kernel(MfGeom g, const double *x, const double *wm, int64_t cells_per
 // that is 99.9 % of the pairs of the global model) with the same expressions, hence the same bits,
 // as tess_entry; a pair whose root must be subdivided (or flags an error) takes tess_entry itself.
 
-constexpr int TESS_NC = 24;  // doubles per cell in the table of cell constants
+constexpr int TESS_NC = 28;  // doubles per cell in the table of cell constants
 
 // [0] rt [1] rt*rt [2] lont [3] sinlatt [4] coslatt [5] ratio*Llon [6] ratio*Llat [7] ratio*Lr
 // [8,9] lonc [10,11] sinlatc [12,13] coslatc [14,15] rc [16,17] rc*rc
-// [18..21] kappa[j][k] = rc[k]^2 * coslatc[j]  [22] scale
+// [18..21] kappa[j][k] = rc[k]^2 * coslatc[j]  [22] scale  [23] -
+// [24,25] cos lonc  [26,27] sin lonc   (fast leaf: cos(lon - lonc) by the addition theorem)
 __global__ void __launch_bounds__(256)
 tess_cellconst_kernel(const double *__restrict__ bounds6, int64_t M, double ratio, double *__restrict__ cc)
 {
@@ -1545,6 +1551,11 @@ tess_cellconst_kernel(const double *__restrict__ bounds6, int64_t M, double rati
         for (int k = 0; k < 2; ++k) o[18 + 2 * jn + k] = (rc[k] * rc[k]) * coslatc[jn];
     o[22] = dlon * dlat * dr * 0.125;
     o[23] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        o[24 + i] = cos(o[8 + i]);
+        o[26 + i] = sin(o[8 + i]);
+    }
 }
 
 __device__ __noinline__ double tess_entry_slow(double lon, double sinlat, double coslat, double radius,
@@ -1584,6 +1595,44 @@ __device__ __forceinline__ double tess_leaf_cc(double lon, double sinlat, double
     double acc = 0.0;
     acc += cc[22] * result;
     return acc * 100000.0 * 0.00000006673;
+}
+
+// The same root leaf with the arithmetic re-arranged for throughput (the per-step pass of the
+// matrix-free mode; the decisions -- which pairs are NOT a single leaf -- were taken once, exactly,
+// when the near-field table was built).  cos(lon - lonc) by the addition theorem from sin / cos of
+// the observation's longitude (tabulated per observation) and of the nodes' (per cell): 2 FMAs
+// instead of a ~55-instruction cos; 1 / l^3 as rsq(l^2)^3 with the hardware reciprocal square root
+// refined by two Newton steps (to the last bit or two) instead of an IEEE sqrt and an IEEE divide
+// (~28 instructions); contraction allowed.  The reference itself writes l_sqr**1.5
+// (_tesseroid_numba.py:218), so no form is bitwise its pow(); this one agrees with tess_leaf_cc to
+// <= 1e-13 of the entry for pairs that are far by the reference's own criterion (the conditioning
+// of l^2 = r^2 + r'^2 - 2 r r' cos psi is the formulation's: an ulp of cos psi moves l^2 by
+// 2 r r' 1e-16 ~ 1e-2 m^2 against l^2 >= 1e10 m^2).  Stated tolerance of the path: 1e-10.
+__device__ __forceinline__ double tess_leaf_fast(double sinlon, double coslon_o, double sinlat, double coslat,
+                                                 double radius, const double *__restrict__ cc)
+{
+    const double r_sqr = radius * radius;
+    const double two_r = 2.0 * radius;
+    double result = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double coslon = coslon_o * cc[24 + i] + sinlon * cc[26 + i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double cospsi = sinlat * cc[10 + j] + coslat * cc[12 + j] * coslon;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double rck = cc[14 + k];
+                const double l_sqr = (r_sqr + cc[16 + k]) - two_r * rck * cospsi;
+                double y = __builtin_amdgcn_rsq(l_sqr);
+                const double h = 0.5 * l_sqr;
+                y = fma(y, fma(-h * y, y, 0.5), y);
+                y = fma(y, fma(-h * y, y, 0.5), y);
+                result = fma(cc[18 + 2 * j + k] * (rck * cospsi - radius), y * y * y, result);
+            }
+        }
+    }
+    return (cc[22] * -result) * (100000.0 * 0.00000006673);
 }
 
 // Does the pair need more than the root leaf (subdivision, or an error flag)?  The root's
@@ -1678,7 +1727,8 @@ struct MfStats {
 };
 
 // T threads per workgroup, EPT rows per thread (row of slot k: t + k*T): T*EPT >= ld; KIND: 0 prisms,
-// 1 tesseroids with the subdivision inside the pass, 2 tesseroids with the near-field table (separate kernels: the prism entry's log/atan2 and the tesseroid entry's trigonometry would
+// 1 tesseroids with the subdivision inside the pass, 2 / 3 tesseroids with the near-field table and the
+// exact-order / the fast root leaf (separate kernels: the prism entry's log/atan2 and the tesseroid entry's trigonometry would
 // otherwise share one register budget).
 // LDS: T*EPT doubles (the column) + 2 x (T/64 + 8) doubles (ping-pong slots of the dot).
 template <int T, int EPT, int KIND>
@@ -1705,7 +1755,7 @@ mf_fused_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const doub
         const double *b = g.bounds6 + 6 * j;
         const double *cc = cellc ? cellc + (int64_t)TESS_NC * j : nullptr;
         double s = 0.0;
-        if (KIND == 2) {
+        if (KIND >= 2) {
             // every pair as its root leaf (no test, no divergence); the rows of the near-field list
             // are then overwritten with their stored entries, and the dot reads the finished column
 #pragma unroll 1
@@ -1713,7 +1763,8 @@ mf_fused_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const doub
                 const int64_t i = tid + (int64_t)k * T;
                 double v = 0.0;
                 if (i < N) {
-                    v = tess_leaf_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc);
+                    v = (KIND == 3) ? tess_leaf_fast(g.o4[i], g.o5[i], g.o1[i], g.o2[i], g.o3[i], cc)
+                                    : tess_leaf_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc);
                     nent += 1;
                 }
                 Ks[(size_t)k * T + tid] = v;
@@ -1807,7 +1858,7 @@ mf_fused_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const doub
         }
     }
     if (stats) {
-        unsigned long long e = nent, l = (KIND == 2) ? nent : nleaf;  // (KIND 2: one root leaf per entry)
+        unsigned long long e = nent, l = (KIND >= 2) ? nent : nleaf;  // (KIND 2, 3: one root leaf per entry)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             e += __shfl_xor(e, off, WAVE);
