@@ -1750,25 +1750,73 @@ mf_fused_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const doub
     for (int k = 0; k < EPT; ++k) dacc[k] = 0.0;
     double pp = 0.0;
     unsigned nleaf = 0, nent = 0;
+    // (table forms: a thread's rows of r are the same for every column -- kept in registers)
+    double rr[KIND >= 2 ? EPT : 1];
+    if (KIND >= 2) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int64_t i = tid + (int64_t)k * T;
+            rr[k] = ((mode & SW_ADJ) && k < ept && i < N) ? a.r[i] : 0.0;
+        }
+    }
     int it = 0;
     for (int64_t j = blockIdx.x; j < g.M; j += gridDim.x, ++it) {
         const double *b = g.bounds6 + 6 * j;
         const double *cc = cellc ? cellc + (int64_t)TESS_NC * j : nullptr;
         double s = 0.0;
-        if (KIND >= 2) {
+        if (KIND == 3) {
             // every pair as its root leaf (no test, no divergence); the rows of the near-field list
-            // are then overwritten with their stored entries, and the dot reads the finished column
+            // are then overwritten with their stored entries, and the dot reads the finished column.
+            // The observation's five numbers for slot k + 1 are requested before slot k is evaluated
+            // (they are the same for every column: L2 hits, but ~1 us away): at 160 instructions
+            // per slot the pass otherwise waits for memory more than half of its time.
+            int64_t i = tid;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0;
+            if (i < N) {
+                c0 = g.o4[i];
+                c1 = g.o5[i];
+                c2 = g.o1[i];
+                c3 = g.o2[i];
+                c4 = g.o3[i];
+            }
+#pragma unroll 1
+            for (int k = 0; k < ept; ++k) {
+                const int64_t in = i + T;
+                double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, n4 = 0.0;
+                if (k + 1 < ept && in < N) {
+                    n0 = g.o4[in];
+                    n1 = g.o5[in];
+                    n2 = g.o1[in];
+                    n3 = g.o2[in];
+                    n4 = g.o3[in];
+                }
+                double v = 0.0;
+                if (i < N) {
+                    v = tess_leaf_fast(c0, c1, c2, c3, c4, cc);
+                    nent += 1;
+                }
+                Ks[(size_t)k * T + tid] = v;
+                i = in;
+                c0 = n0;
+                c1 = n1;
+                c2 = n2;
+                c3 = n3;
+                c4 = n4;
+            }
+        }
+        if (KIND == 2) {
 #pragma unroll 1
             for (int k = 0; k < ept; ++k) {
                 const int64_t i = tid + (int64_t)k * T;
                 double v = 0.0;
                 if (i < N) {
-                    v = (KIND == 3) ? tess_leaf_fast(g.o4[i], g.o5[i], g.o1[i], g.o2[i], g.o3[i], cc)
-                                    : tess_leaf_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc);
+                    v = tess_leaf_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc);
                     nent += 1;
                 }
                 Ks[(size_t)k * T + tid] = v;
             }
+        }
+        if (KIND >= 2) {
             const int64_t q0 = near.ptr[j], q1 = near.ptr[j + 1];
             if (q1 > q0) {
                 __syncthreads();
@@ -1777,10 +1825,8 @@ mf_fused_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const doub
             }
             if (mode & SW_ADJ) {
 #pragma unroll
-                for (int k = 0; k < EPT; ++k) {
-                    const int64_t i = tid + (int64_t)k * T;
-                    if (k < ept && i < N) s += Ks[(size_t)k * T + tid] * a.r[i];
-                }
+                for (int k = 0; k < EPT; ++k)
+                    if (k < ept) s += Ks[(size_t)k * T + tid] * rr[k];
             }
         } else {
 #pragma unroll 1
