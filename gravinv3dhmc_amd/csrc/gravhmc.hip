@@ -630,6 +630,7 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     TRY(dalloc(c, &w.coeff, (size_t)Mp));
     TRY(dalloc(c, &w.s1, (size_t)Mp));
     TRY(dalloc(c, &w.s2, (size_t)Mp));
+    wavelet_plan_lds(c);
     w.on = true;
     w.F_valid = false;
     c->rs.state = 0;  // plan the resident chain kernel again (it would need the dense form)

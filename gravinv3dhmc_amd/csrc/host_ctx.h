@@ -149,6 +149,8 @@ struct gh_ctx {
         int *indices = nullptr;
         double *data = nullptr;
         double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
+        ghk::DwtLdsPlan lds_plan;  // one-launch transform of one model vector (dwt_lds_kernel)
+        size_t lds_bytes = 0;      // 0: the working block does not fit the LDS -> one launch per pass
         double *F = nullptr;  // dense model-space form Awcp W (ld x M, column-major), built on demand
         bool F_valid = false;
     } wv;

@@ -20,6 +20,60 @@ static void wavelet_plan(gh_ctx::Wavelet &w)
     w.Mp = (int64_t)a[0] * a[1] * a[2];
 }
 
+// Passes of the one-launch transform (dwt_lds_kernel): the same sequence run_dwt launches, every
+// block dense in LDS.  lds_bytes = 0 when a block exceeds the LDS or a thread's register budget.
+static void wavelet_plan_lds(gh_ctx *c)
+{
+    gh_ctx::Wavelet &w = c->wv;
+    DwtLdsPlan &pl = w.lds_plan;
+    pl = DwtLdsPlan();
+    w.lds_bytes = 0;
+    // One workgroup does what the pass-per-launch form spreads over the chip: it wins only while the
+    // launches cost more than the arithmetic.  Measured (sweep path, per potential evaluation):
+    // 19 x 30 x 30 = 17100 cells (ratiogrid): +52 us (one CU needs ~46 us for the 7*10^6 lane
+    // operations of the six passes); 10 x 30 x 20 = 6000 cells (C3 on the sweep path): +7 us.  Used for blocks <= GRAVHMC_DWT_LDS_MAX = 2048 doubles.
+    if (env_int("GRAVHMC_DWT_LDS", 1) == 0) return;
+    pl.M = c->M;
+    pl.Cs[0] = (int64_t)w.D[1] * w.D[2];
+    pl.Cs[1] = w.D[2];
+    pl.Cs[2] = 1;
+    int axes[3], na = 0;
+    for (int k = 0; k < 3; ++k)
+        if (w.tax[k]) axes[na++] = k;
+    int64_t maxvol = c->M;
+    int np = 0;
+    for (int lev = 1; lev <= w.levels; ++lev) {
+        int e[3] = {w.X[lev - 1][0], w.X[lev - 1][1], w.X[lev - 1][2]};
+        for (int p = 0; p < na; ++p) {
+            if (np >= DWT_LDS_MAXPASS) return;
+            const int ax = axes[p];
+            DwtLdsPass &P = pl.p[np++];
+            for (int k = 0; k < 3; ++k) P.e[k] = e[k];
+            P.axis = ax;
+            P.last = (p == na - 1) ? 1 : 0;
+            for (int k = 0; k < 3; ++k) {
+                P.split[k] = w.tax[k] ? w.X[lev][k] : 0x7fffffff;
+                P.off1[k] = w.tax[k] ? w.offd[lev][k] : 0;
+            }
+            const int h = (e[ax] + 1) / 2;
+            e[ax] = 2 * h;
+            const int64_t vol = (int64_t)e[0] * e[1] * e[2];
+            maxvol = std::max(maxvol, vol);
+            if (vol / 2 > (int64_t)DWT_LDS_NP * DWT_LDS_THREADS) return;
+        }
+    }
+    pl.npass = np;
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) return;
+    const size_t need = (size_t)maxvol * sizeof(double);
+    if (need > (size_t)lds_max || maxvol > env_int("GRAVHMC_DWT_LDS_MAX", 2048)) return;
+    if (allow_dynamic_lds(reinterpret_cast<const void *>(dwt_lds_kernel), need) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    w.lds_bytes = need;
+}
+
 // Multi-level DWT of `batch` model-shaped vectors x (batch stride xb) into the packed
 // coefficient layout C (batch stride Mp, must be zero-initialised: odd lengths leave gaps).
 static int run_dwt(gh_ctx *c, const double *x, int64_t xb, int64_t batch, double *C, double *S1,
@@ -120,8 +174,13 @@ static int run_dwt(gh_ctx *c, const double *x, int64_t xb, int64_t batch, double
 static int wavelet_forward(gh_ctx *c, const double *x, double *d_out)
 {
     gh_ctx::Wavelet &w = c->wv;
-    HIPCHK(c, hipMemsetAsync(w.coeff, 0, sizeof(double) * (size_t)w.Mp, c->stream));
-    TRY(run_dwt(c, x, c->M, 1, w.coeff, w.s1, w.s2));
+    if (w.lds_bytes) {
+        // (w.coeff was zeroed when it was allocated; the transform never writes the packing's gaps)
+        dwt_lds_kernel<<<dim3(1), dim3(DWT_LDS_THREADS), w.lds_bytes, c->stream>>>(w.lds_plan, x, w.coeff);
+    } else {
+        HIPCHK(c, hipMemsetAsync(w.coeff, 0, sizeof(double) * (size_t)w.Mp, c->stream));
+        TRY(run_dwt(c, x, c->M, 1, w.coeff, w.s1, w.s2));
+    }
     spmv_kernel<<<dim3((unsigned)((c->ld + 3) / 4)), dim3(256), 0, c->stream>>>(
         w.indptr, w.indices, w.data, w.coeff, c->N, c->ld, d_out);
     HIPCHK(c, hipGetLastError());

@@ -1215,6 +1215,128 @@ __global__ void __launch_bounds__(256) dwt_axis_kernel(DwtArgs a)
     }
 }
 
+// The whole multi-level transform of ONE model vector in one launch of one workgroup: the working
+// block lives in LDS, every pass reads it, keeps its outputs in registers across a barrier and
+// writes them back in place (intermediate passes: dense block; the last pass of a level: the packed
+// coefficient vector in global memory, plus the approximation block back to LDS for the next
+// level).  Replaces levels x axes launches of dwt_axis_kernel (and the memset of the coefficient
+// vector: the gaps odd lengths leave in the packing are zeroed once) per potential evaluation of a
+// compressed problem too large for the resident chain kernel (the reference's ratiogrid example).
+// Same taps, same index arithmetic, same order of the eight products as dwt_axis_kernel.
+constexpr int DWT_LDS_THREADS = 1024;
+constexpr int DWT_LDS_NP = 10;      // (lo, hi) pairs a thread holds per pass: blocks <= 20480 doubles
+constexpr int DWT_LDS_MAXPASS = 12;
+
+struct DwtLdsPass {
+    int e[3];          // extents of the input block (dense in LDS)
+    int axis, last;
+    int split[3];      // last pass: first index of the detail piece per axis (INT_MAX: untransformed)
+    int64_t off1[3];   // last pass: packed offset of the detail piece per axis
+};
+
+struct DwtLdsPlan {
+    int npass;
+    int64_t M;         // model length = volume of pass 0's block
+    int64_t Cs[3];     // strides of the packed coefficient cube
+    DwtLdsPass p[DWT_LDS_MAXPASS];
+};
+
+__global__ void __launch_bounds__(DWT_LDS_THREADS)
+dwt_lds_kernel(DwtLdsPlan plan, const double *__restrict__ x, double *__restrict__ coeff)
+{
+    extern __shared__ __attribute__((aligned(16))) double blk[];
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < plan.M; i += DWT_LDS_THREADS) blk[i] = x[i];
+    __syncthreads();
+    for (int pi = 0; pi < plan.npass; ++pi) {
+        const DwtLdsPass &P = plan.p[pi];
+        const int ax = P.axis;
+        const int n = P.e[ax], np = n + (n & 1), half = np >> 1;
+        int oe[3] = {P.e[0], P.e[1], P.e[2]};
+        oe[ax] = half;
+        const int per = oe[0] * oe[1] * oe[2];
+        const int is[3] = {P.e[1] * P.e[2], P.e[2], 1};
+        double lo[DWT_LDS_NP], hi[DWT_LDS_NP];
+#pragma unroll
+        for (int q = 0; q < DWT_LDS_NP; ++q) {
+            const int t = tid + q * DWT_LDS_THREADS;
+            lo[q] = hi[q] = 0.0;
+            if (t < per) {
+                int r = t, i[3];
+                i[2] = r % oe[2];
+                r /= oe[2];
+                i[1] = r % oe[1];
+                i[0] = r / oe[1];
+                const int o = i[ax];
+                int base = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if (d != ax) base += i[d] * is[d];
+                double l = 0.0, h = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int k = (4 + 2 * o - j) % np;
+                    if (k < 0) k += np;
+                    if (k >= n) k = n - 1;  // the repeated last sample of an odd-length signal
+                    const double v = blk[base + k * is[ax]];
+                    l += DB4_LO[j] * v;
+                    h += DB4_HI[j] * v;
+                }
+                lo[q] = l;
+                hi[q] = h;
+            }
+        }
+        __syncthreads();  // every read of this pass is done: the block may be overwritten
+        int de[3] = {P.e[0], P.e[1], P.e[2]};   // dense output block (intermediate pass)
+        de[ax] = 2 * half;
+        int ae[3];                               // approximation block the next level reads (last pass)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ae[d] = (P.split[d] == 0x7fffffff) ? P.e[d] : P.split[d];
+        ae[ax] = half;
+#pragma unroll
+        for (int q = 0; q < DWT_LDS_NP; ++q) {
+            const int t = tid + q * DWT_LDS_THREADS;
+            if (t < per) {
+                int r = t, i[3];
+                i[2] = r % oe[2];
+                r /= oe[2];
+                i[1] = r % oe[1];
+                i[0] = r / oe[1];
+                const int o = i[ax];
+                if (!P.last) {
+                    const int os[3] = {de[1] * de[2], de[2], 1};
+                    int base = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        if (d != ax) base += i[d] * os[d];
+                    blk[base + o * os[ax]] = lo[q];
+                    blk[base + (half + o) * os[ax]] = hi[q];
+                } else {
+                    int64_t ob = 0;
+                    bool approx = true;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        if (d == ax) continue;
+                        const int64_t pos = i[d] < P.split[d] ? (int64_t)i[d] : P.off1[d] + (i[d] - P.split[d]);
+                        ob += pos * plan.Cs[d];
+                        approx = approx && i[d] < P.split[d];
+                    }
+                    coeff[ob + (int64_t)o * plan.Cs[ax]] = lo[q];
+                    coeff[ob + (P.off1[ax] + o) * plan.Cs[ax]] = hi[q];
+                    if (approx) {
+                        const int as[3] = {ae[1] * ae[2], ae[2], 1};
+                        int base = 0;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) base += (d == ax ? o : i[d]) * as[d];
+                        blk[base] = lo[q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // rows [i0, i0+nrows) of the column-major G as a dense row-major block out[nrows][M]
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const double *G, int64_t ld, int64_t M, int64_t i0, int64_t nrows, double *out)

@@ -477,6 +477,31 @@ def test_c5_per_gpu_share_full_size_properties(G):
 
 # ------------------------------------------------------------------ wavelet-compressed forward
 
+@pytest.mark.parametrize("dims,shape", [(3, (19, 30, 30)), (3, (7, 9, 5)), (1, (1, 1, 1237)), (1, (1, 1, 16001))])
+def test_wavelet_forward_one_launch_transform_is_bitwise_the_pass_per_launch_one(G, monkeypatch, dims, shape):
+    """dwt_lds_kernel (the whole multi-level transform of a model vector in one launch, working block
+    in LDS) against one launch per axis and level: same taps, same index arithmetic, same order of
+    the products -> the same bits, odd lengths on both levels (the ratiogrid example's 19 x 30 x 30)
+    and the 1-D variant included."""
+    M = int(np.prod(shape))
+    N = 23
+    rng = np.random.default_rng(M)
+    A = rng.normal(size=(N, M)) * np.exp(-np.arange(M) / (0.3 * M))[None, :]
+    xs = [rng.normal(size=M) for _ in range(3)]
+    out = {}
+    monkeypatch.setenv("GRAVHMC_DWT_LDS_MAX", "20480")      # (by default only blocks <= 2048 take it)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GRAVHMC_DWT_LDS", mode)
+        eng = G.Engine(N, M)
+        eng.upload_G(A)
+        eng.weight(0.5)
+        eng.compress_wavelet(dims, shape if dims == 3 else None, 1e-3, 2)
+        out[mode] = [eng.forward_wavelet(x) for x in xs] + [eng.model_coeffs(xs[0])]
+        eng.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("dims,shape", [(3, (10, 30, 20)), (3, (7, 9, 5)), (3, (4, 6, 8)),
                                         (1, (1, 1, 6000)), (1, (1, 1, 1237))])
 def test_wavelet_transform_and_csr_vs_oracle(G, dims, shape):
