@@ -395,27 +395,6 @@ static bool team_plan(gh_ctx *c)
     }
     const size_t ng = (size_t)n_teams * TS_MAXQ * TS_RING * 2;
     if (dalloc(c, &t.gran, ng) != GH_OK || dalloc(c, &t.abort_w, 4) != GH_OK) return false;
-    {
-        // where does the dispatcher put the blocks of such a grid?  Round-robin over the XCDs means
-        // equal blockIdx % 8 <-> one XCD: the members of a team then share an L2, which their scalar
-        // polls read.  (A launch placed differently later only times out -> row panels.)
-        unsigned *xcc = nullptr;
-        std::vector<unsigned> hx((size_t)t.grid, 0u);
-        bool same = true;
-        if (hipMalloc((void **)&xcc, sizeof(unsigned) * (size_t)t.grid) == hipSuccess) {
-            hipLaunchKernelGGL(team_probe_kernel, dim3(t.grid), dim3(1024), 64 * 1024, c->stream, xcc);
-            if (hipMemcpyAsync(hx.data(), xcc, sizeof(unsigned) * (size_t)t.grid, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) {
-                (void)hipGetLastError();
-                same = false;
-            }
-            hipFree(xcc);
-            for (int b = 8; b < t.grid && same; ++b) same = hx[(size_t)b] == hx[(size_t)(b & 7)];
-        } else {
-            same = false;
-        }
-        if (!same) return false;  // members of a team would not share an L2: stay on row panels
-    }
     t.tag = 0;
     t.state = 1;
     return true;

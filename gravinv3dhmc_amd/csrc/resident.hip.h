@@ -178,43 +178,6 @@ __device__ __forceinline__ bool res_poll(unsigned *abort_w, F &&try_load)
     }
 }
 
-// v + (v of the lane the DPP control selects; 0 where that lane does not exist or the row is masked)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
-    return v + __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
-}
-
-// Sum over the 64 lanes on the VALU (row_shr 1/2/4/8 scan inside the rows of 16, row_bcast 15/31
-// across them, total read from lane 63): fixed order, result uniform.  The LDS-crossbar butterfly
-// (ds_bpermute) of wave_allreduce_sum costs ~10x as much when 8 waves reduce several values each.
-__device__ __forceinline__ double wave_sum_dpp(double v)
-{
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
-    v = dpp_add<0x142, 0xa>(v);
-    v = dpp_add<0x143, 0xc>(v);
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, 63);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
-    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
-}
-
-// inclusive scan over each row of 16 lanes: lane 15 of a row holds the row's sum
-__device__ __forceinline__ double row16_sum_dpp(double v)
-{
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
-    return v;
-}
-
 // Workgroup-wide sum (RES_WAVES waves), fixed order, result valid in every thread
 __device__ __forceinline__ double res_block_sum(double v, double *red)
 {

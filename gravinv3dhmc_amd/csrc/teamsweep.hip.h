@@ -12,22 +12,24 @@
 // its part of the forward partial.  One read of G again.
 //
 // The exchange is the resident chain kernel's (resident.hip.h): the data is the flag -- a double
-// travels as two 8-byte granules {tag, 32 bits}, each written by one write-through store; no
-// counters, no fences.  Two things keep it off the critical path:
-//   * a lag of one column: a member publishes its part of column i and only then collects the parts
-//     of column i-1 -- published a whole column (~3 us of HBM streaming) earlier -- finishes that
-//     column, whose registers it kept meanwhile, and requests the column after next into them
-//     (three column buffers rotate: finishing | dotted | in flight);
-//   * the parts are polled with ONE scalar load (s_load_dwordx16 glc: the Q granule pairs of a ring
-//     slot are contiguous).  Scalar memory operations are counted by lgkmcnt, not vmcnt: the poll
-//     does not queue behind the wave's column loads in flight.  (A vector poll returns only after
-//     every older vector load of its wave: measured, the team then streams one column at a time,
-//     5.2 instead of 6 TB/s.)  A scalar load reads the XCD's L2, so the members of a team must share
-//     an XCD: they are blocks with equal blockIdx % 8, and the host checks once with a probe launch
-//     that the dispatcher places such blocks on one XCD (else: row panels).
-// A ring of four slots suffices (no member is ever more than two columns ahead of another of its
-// team).  Every wait is bounded (2 s): on a time-out the abort word is raised, every workgroup
-// leaves, later launches of the stream return at once and the host repeats the work in row panels
+// travels as two 8-byte granules {tag, 32 bits}, each written by one write-through store and read
+// with sc1 loads; no counters, no fences; correct under any placement of the workgroups.  Two
+// things keep it off the critical path:
+//   * a lag of one column: a member publishes its part of column i and only then finishes column
+//     i-1 -- whose parts were published a whole column (~3 us of HBM streaming) earlier -- from the
+//     registers it kept it in meanwhile (three column buffers rotate: finishing | dotted | in
+//     flight);
+//   * the poll for column i-1 is ISSUED at the start of iteration i, in front of the request for
+//     column i+1, and looked at only after the dot of column i.  A wave's vector loads return in
+//     order: issued there the poll comes back with column i's data, which the dot waits for anyway;
+//     issued after the dot it would come back behind column i+1 -- a full column later -- and the
+//     team would stream one column at a time (measured 5.2 TB/s; a scalar poll, which is not ordered
+//     with the vector loads but pays its L2 round trip inside the hand-off, 5.3 TB/s).
+// A ring of four granule slots per member suffices (no member is ever more than two columns ahead
+// of another of its team).  Members of a team are blocks with equal blockIdx % 8, i.e. on one XCD
+// under the round-robin dispatch (their exchange then stays in that L2), but nothing depends on it.
+// Every wait is bounded (2 s): on a time-out the abort word is raised, every workgroup leaves, later
+// launches of the stream return at once and the host repeats the work in row panels
 // (host_sweep.h: team_failed).
 #pragma once
 
@@ -36,38 +38,6 @@ namespace ghk {
 constexpr int TS_MAXQ = 8;
 constexpr int TS_RING = 4;
 constexpr int TS_MAXWAVES = 16;
-
-// The granule pairs of up to 8 members (16 bytes each, contiguous) with scalar loads that bypass the
-// scalar cache (glc) and read the XCD's L2, where a same-XCD writer's write-through store has just
-// passed.  ok: every one of the first n pairs carries `tag`; sum: their values added in member
-// order (the first nsum of them).
-typedef unsigned ts_u16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ bool poll_parts_scalar(const u64 *g, int n, int nsum, unsigned tag, double &sum)
-{
-    ts_u16 lo, hi;
-    if (n > 4) {
-        asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(lo), "=&s"(hi)
-                     : "s"(g)
-                     : "memory");
-    } else {
-        asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(lo) : "s"(g) : "memory");
-        hi = lo;
-    }
-    bool ok = true;
-    double t = 0.0;
-#pragma unroll
-    for (int m = 0; m < TS_MAXQ; ++m) {
-        if (m < n) {
-            const ts_u16 &w = m < 4 ? lo : hi;
-            const int o = 4 * (m & 3);
-            ok = ok && w[o + 1] == tag && w[o + 3] == tag;
-            if (m < nsum) t += __longlong_as_double((long long)(((u64)w[o + 2] << 32) | (u64)w[o]));
-        }
-    }
-    sum = t;
-    return ok;
-}
 
 struct TeamArgs {
     SweepArgs s;          // mode, G, ld, M, vectors, coefficients (row0 / rows / n_teams unused)
@@ -142,6 +112,10 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
         c.sc = sc;
     };
 
+    // the member's granule pair of column i (ring slot i & 3; the Q pairs of a slot are contiguous)
+    auto gran_of = [&](int member, int i) -> u64 * {
+        return gteam + ((size_t)(i & (TS_RING - 1)) * TS_MAXQ + member) * 2;
+    };
     // B(i): the member's part of <G_j, r>, published for the team
     auto stage_dot = [&](const ColRegs<TS_EPT2> &cur, int i) {
         const d2 *rs2 = reinterpret_cast<const d2 *>(r_s);
@@ -155,42 +129,40 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
                 sd += cur.v[k].y * rv.y;
             }
         }
-        sd = wave_allreduce_sum(sd);
+        sd = wave_sum_dpp(sd);  // on the VALU: the hand-off chain of a column starts here
         double *slot = part + (i & 1) * TS_MAXWAVES;
         if (lane == 0) slot[wave] = sd;
         if (wave == 0 && lane < 6) scal[(i & (TS_RING - 1)) * 8 + lane] = cur.sc;
         __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < TS_WAVES; ++w) t += slot[w];
-            st_gran(gteam + ((size_t)(i & (TS_RING - 1)) * TS_MAXQ + q) * 2, a.tag0 + (unsigned)i + 1u, t);
+        if (wave == 0) {
+            // the waves' partials: one LDS read per lane, a row scan, lane 15 publishes
+            const double t = row16_sum_dpp(lane < TS_WAVES ? slot[lane] : 0.0);
+            if (lane == 15) st_gran(gran_of(q, i), a.tag0 + (unsigned)i + 1u, t);
         }
     };
 
+    // issue the poll for column i (wave 0, lane = member): value and "tag matched" come back with the
+    // loads already in flight
+    auto poll_issue = [&](int i, double &pv, bool &pok) {
+        pok = true;
+        if (wave == 0 && lane < a.poll_q) pok = ld_gran(gran_of(lane, i), a.tag0 + (unsigned)i + 1u, pv);
+        __builtin_amdgcn_sched_barrier(0);  // in front of the column request that follows
+    };
+
     // C(i): the Q parts of column i in member order -> gradient, leapfrog update, forward axpy.
-    // false: a wait timed out (or another workgroup gave up): leave.
-    auto stage_finish = [&](const ColRegs<TS_EPT2> &cur, int i) -> bool {
+    // pv / pok: what the early poll brought.  false: a wait timed out (or another workgroup gave
+    // up): leave.
+    auto stage_finish = [&](const ColRegs<TS_EPT2> &cur, int i, double pv, bool pok) -> bool {
         if (wave == 0) {
-            const unsigned tag = a.tag0 + (unsigned)i + 1u;
-            const u64 *g = gteam + (size_t)(i & (TS_RING - 1)) * TS_MAXQ * 2;
-            double t = 0.0;
             bool ok = true;
-            unsigned spins = 0;
-            long long t0 = 0;
-            while (!poll_parts_scalar(g, a.poll_q, a.Q, tag, t)) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 63u) == 0) {
-                    const long long now = wall_clock64();
-                    if (t0 == 0) t0 = now;
-                    if (__hip_atomic_load(a.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                        now - t0 > RES_TIMEOUT_TICKS) {
-                        __hip_atomic_store(a.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = false;
-                        break;
-                    }
-                }
+            if (!__all(pok)) {
+                // (rare: a member lags by more than a column) poll until every part is there
+                ok = res_poll(a.abort_w, [&]() {
+                    return lane >= a.poll_q || ld_gran(gran_of(lane, i), a.tag0 + (unsigned)i + 1u, pv);
+                });
             }
+            double t = 0.0;
+            for (int m = 0; m < a.Q; ++m) t += __shfl(pv, m, WAVE);
             if (lane == 0) {
                 tot_s[0] = t;
                 if (!ok) *abort_s = 1;
@@ -237,11 +209,8 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
     };
 
     // TS_D column buffers rotate: finishing (i-1) | dotted (i) | in flight (i+1 .. i+TS_D-2).
-    // Iteration i: request column i+TS_D-2 into the registers column i-2 left in the last iteration;
-    // dot and publish column i; THEN collect the parts of column i-1 -- published a whole column
-    // (~3 us of streaming) earlier, so the poll finds them at its first look -- and finish it.
-    // (Collecting right after publishing instead exposes the exchange latency every column:
-    // measured 18.6 against 17.0 ms per sweep of 96 GB.)
+    // Iteration i: issue the poll for column i-1, request column i+TS_D-2 into the registers column
+    // i-2 left in the last iteration, dot and publish column i, finish column i-1.
     ColRegs<TS_EPT2> B[TS_D];
     bool ok = true;
 #pragma unroll
@@ -252,19 +221,25 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
 #pragma unroll
         for (int r = 0; r < TS_D; ++r) {  // r == i % TS_D: every buffer index below is a constant
             if (i >= cnt) break;
+            double pv = 0.0;
+            bool pok = true;
+            if (i > 0) poll_issue(i - 1, pv, pok);
             if (i + TS_D - 2 < cnt) load_col(B[(r + TS_D - 2) % TS_D], i + TS_D - 2);
             stage_dot(B[r], i);
             if (i > 0) {
-                if (!(ok = stage_finish(B[(r + TS_D - 1) % TS_D], i - 1))) break;
+                if (!(ok = stage_finish(B[(r + TS_D - 1) % TS_D], i - 1, pv, pok))) break;
             }
             ++i;
         }
     }
     if (ok && cnt > 0) {
         const int last = cnt - 1;
+        double pv = 0.0;
+        bool pok = true;
+        poll_issue(last, pv, pok);
 #pragma unroll
         for (int r = 0; r < TS_D; ++r)
-            if (last % TS_D == r) ok = stage_finish(B[r], last);
+            if (last % TS_D == r) ok = stage_finish(B[r], last, pv, pok);
     }
     if (!ok) return;
 
@@ -282,12 +257,6 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
             if (e < ld2) out[e] = dacc[k];
         }
     }
-}
-
-// placement probe: XCC_ID of every block of a grid shaped like the team sweep's
-__global__ void __launch_bounds__(1024) team_probe_kernel(unsigned *xcc)
-{
-    if (threadIdx.x == 0) xcc[blockIdx.x] = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
 }
 
 }  // namespace ghk
