@@ -262,10 +262,13 @@ int gh_leapfrog(gh_ctx *ctx, double *x_inout, const double *p0, double dt, int L
 /* Column-block sharding: rank g of `world` creates its context with its own cell count
  * (gh_create(N, M_local)) and passes only its cells / slices of every M-vector; N-vectors
  * (dobs, grav_fix, dpre) are replicated.  Per potential evaluation the ranks exchange ONE
- * all-reduce of N+1 doubles (forward partial + regulariser partial); the gradient, the
+ * all-reduce of N+2 doubles (forward partial + regulariser partial); the gradient, the
  * regulariser gradient and the leapfrog updates stay local, so the fused one-read sweep is
- * kept.  Damping and MS only (Smoothness/TV would need a halo exchange).  Every rank ends up
- * with bit-identical scalars, hence identical Metropolis decisions.
+ * kept.  Damping and MS with any partition; Smoothness / TV with shards of whole z-planes (the
+ * boundary planes of the model travel in the same all-reduce, see gh_set_reg).  Every rank ends up
+ * with bit-identical scalars, hence identical Metropolis decisions.  (Row blocks -- every rank a
+ * slice of the observations -- would need the M-vector gradient all-reduced between the adjoint
+ * and the update: two reads of G per step)
  *
  * RCCL flavour: rank 0 obtains a 128-byte id with gh_shard_unique_id, the launcher
  * broadcasts it, every rank calls gh_shard_init (ncclCommInitRank, collective).  The

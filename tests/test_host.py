@@ -170,3 +170,16 @@ def test_fixed8_row_formatter_is_savetxt_bit_for_bit(tmp_path):
         write_rows_fixed8(fh, cases[0])
         write_rows_fixed8(fh, cases[3])
     assert f.read_bytes() == ref(cases[0]) + ref(cases[3])
+
+
+def test_bench_helpers_cores_and_labelled_traffic():
+    """bench.py's host-side helpers: the cores the cgroup grants (never more than the affinity mask)
+    and the PMC traffic figure, which must come with the profile it was read from."""
+    import bench
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    b, src = bench.pmc_traffic("c2_uniform_100x100x50")
+    assert src is not None and os.path.exists(os.path.join(ROOT, src["file"])) and "not a counter of this run" in src["note"]
+    assert abs(b - 4.0e10) < 0.01 * 4.0e10            # one read of the 40 GB matrix, nothing re-read
+    assert bench.pmc_traffic("no_such_workload") == (None, None)
+    assert bench.FP64_VECTOR_PEAK_TFLOPS == 78.6 and bench.FLOPS_PER_TESS_LEAF == 244
