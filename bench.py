@@ -118,6 +118,10 @@ EXTRA = {
     # the size of the reference's realdata example (625 x 10427, 52 MB) as prisms: larger than the
     # LDS alone, the resident chain kernel keeps part of every column block in registers
     "x1_prisms_625x10400": dict(kind=0, reg="MS", alpha=1.0, beta=0.001, dt=0.01, hi=1.0, wavelet=0),
+    # the reference's ratiogrid example (900 x 17100, dz growing by 1.05, wavelet 3D, MS): 123 MB of Aw
+    # + 123 MB of the dense compressed-forward form -- beyond LDS + registers: resident kernel with
+    # the columns that do not fit streamed from L2 / Infinity Cache
+    "x2_ratiogrid_900x17100_wavelet3d": dict(kind=0, reg="MS", alpha=1.0, beta=0.001, dt=0.01, hi=0.4, wavelet=3),
 }
 
 
@@ -136,6 +140,12 @@ def make_extra(name):
         obs = (xp, yp, np.zeros_like(xp))
         rho = np.zeros(mesh.shape)
         rho[4:9, 7:13, 10:16] = 1.0
+    elif name == "x2_ratiogrid_900x17100_wavelet3d":
+        mesh = mesher.PrismMesh((0, 6000, 0, 6000, 0, 6000), (200, 200, 200), 1.05)
+        yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 6000, 30), np.linspace(0, 6000, 30))]
+        obs = (xp, yp, np.zeros_like(xp))
+        rho = np.zeros(mesh.shape)
+        rho[4:9, 10:20, 10:20] = 0.4
     elif name == "c5_uniform_200x200x60":
         mesh = mesher.PrismMesh((0, 20000, 0, 20000, 0, 6000), (100, 100, 100))
         yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 20000, 200), np.linspace(0, 20000, 200))]

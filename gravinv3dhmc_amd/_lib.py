@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgravhmc.so")
+#: GRAVHMC_LIB: another build of the library (A/B measurements of one kernel change on one box)
+LIB_PATH = os.environ.get("GRAVHMC_LIB") or os.path.join(_HERE, "libgravhmc.so")
 
 GH_OK, GH_ERR_ARG, GH_ERR_HIP, GH_ERR_NOMEM, GH_ERR_OVERFLOW, GH_ERR_UNSUPPORTED, GH_ERR_COMM = \
     0, -1, -2, -3, -4, -5, -6

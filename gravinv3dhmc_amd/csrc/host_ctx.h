@@ -191,6 +191,7 @@ struct gh_ctx {
         int cpw = 0, nwg = 0, rc = 0, ct = 0;  // ct: columns per wave kept in registers
         int lds_cols = 0;     // columns of a workgroup held in LDS
         bool split = false;   // one copy: the first 8 ct columns in registers only, the rest in LDS
+        bool stream = false;  // columns beyond lds_cols are read from memory in every pass (resident.hip.h)
         size_t lds = 0;
         ghk::u64 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr, *scalg = nullptr, *xscalg = nullptr, *xccg = nullptr;
         double *xpub = nullptr;

@@ -56,6 +56,7 @@ static bool resident_plan(gh_ctx *c)
     const bool regs = env_int("GRAVHMC_RESIDENT_REGS", 1) != 0;
     size_t lds = resident_lds_doubles(c->ld, cpw, 1, cpw, false) * sizeof(double);
     r.split = false;
+    r.stream = false;
     r.lds_cols = cpw;
     if (lds <= (size_t)lds_max) {
         // every column in LDS; where the registers allow it (what resident_for compiles), the
@@ -70,7 +71,6 @@ static bool resident_plan(gh_ctx *c)
         // (registers: up to 20 double2 per lane), the rest in LDS next to 8 x ld doubles of scratch.
         // As few register columns as the LDS allows: their forward share goes through per-wave
         // partials and an LDS sum (measured at 625 x 10400: ct 3 -> 7.9, ct 4 -> 8.4 us per evaluation).
-        if (!regs || c->wv.on) return false;
         const int ct_max = std::min(4, 20 / r.rc);
         const int ct_env = env_int("GRAVHMC_RESIDENT_CT", 0);  // diagnostic: force the number
         r.split = true;
@@ -85,7 +85,26 @@ static bool resident_plan(gh_ctx *c)
                 break;
             }
         }
-        if (r.ct < 1) return false;
+        if (!regs || c->wv.on) r.ct = 0;  // (one-copy mode needs the register copies and Gl == G)
+        if (r.ct < 1) {
+            // Larger than the chip holds: as many columns per workgroup as fit stay in LDS, the rest
+            // is read from L2 / Infinity Cache in both passes of every evaluation.  Still one launch
+            // per batch of trajectories and ~3 us of exchange per evaluation instead of 3-11
+            // launches per step; worth it while the streamed bytes (two passes; with the wavelet
+            // forward: Aw for the dots and the dense compressed form for the forward) stay within
+            // what the Infinity Cache serves -- beyond that the one-read sweep path wins.
+            const int64_t stream_budget = (int64_t)env_int("GRAVHMC_RESIDENT_STREAM_MB", 320) << 20;
+            if (env_int("GRAVHMC_RESIDENT_STREAM", 1) == 0 || 2 * c->ld * c->M * 8 > stream_budget) return false;
+            if (c->wv.on && wavelet_dense_form(c) != GH_OK) return false;
+            r.split = false;
+            r.stream = true;
+            r.ct = 0;
+            int lc = cpw;
+            while (lc > 0 && resident_lds_doubles(c->ld, cpw, 1, lc, false) * sizeof(double) > (size_t)lds_max) --lc;
+            r.lds_cols = lc;
+            lds = resident_lds_doubles(c->ld, cpw, 1, lc, false) * sizeof(double);
+            if (lds > (size_t)lds_max) return false;
+        }
     }
     r.lds = lds;
     resident_fn f = resident_for(r.rc, r.ct);
@@ -199,6 +218,8 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     a.M = c->M;
     a.cols_per_wg = r.cpw;
     a.split = r.split ? 1 : 0;
+    a.stream = r.stream ? 1 : 0;
+    a.lds_cap = r.lds_cols;
     a.nwg = r.nwg;
     // test hook: the workgroups wait for partners that do not exist, time out and abort
     if (env_int("GRAVHMC_RESIDENT_TEST_ABORT", 0)) a.nwg += 8;

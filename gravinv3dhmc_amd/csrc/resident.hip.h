@@ -68,6 +68,11 @@ struct ResArgs {
     int cols_per_wg, nwg;
     int split;      // 1 (CW > 0, Gl == G): ONE copy of the workgroup's columns, the first 8 CW of them in
                     // the waves' registers, only the rest in LDS -- for kernels up to ~1.8x the LDS
+    int stream;     // 1 (CW == 0): columns [lds_cap, cols_per_wg) of the workgroup are not resident: both
+    int lds_cap;    // passes read them from global memory (L2 / Infinity Cache) in every evaluation --
+                    // kernels of up to a few hundred MB with N <= 1024 (the reference's ratiogrid
+                    // example: 123 MB + its dense compressed-forward form).  With Gl != G (wavelet
+                    // forward) the dots read ALL their columns of Aw from memory.
     int try_local;  // 1: keep intra-cluster traffic in the XCD's L2 when the placement allows it
     const double *gfix, *dobs_c, *low, *high;
     // regulariser (x is set per evaluation inside the kernel)
@@ -224,9 +229,11 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
 
     // split mode: columns [0, 8 CW) of the workgroup live in the waves' registers only
     const bool split = CW > 0 && a.split != 0;
+    const bool stream = CW == 0 && a.stream != 0;
     const int lds_c0 = split ? CW * RES_WAVES : 0;             // first column held in LDS
-    const int lds_cols = cpw > lds_c0 ? cpw - lds_c0 : 0;      // capacity (columns)
-    const int nl = nc > lds_c0 ? nc - lds_c0 : 0;              // LDS columns of this workgroup
+    const int lds_cols = stream ? a.lds_cap : (cpw > lds_c0 ? cpw - lds_c0 : 0);  // capacity (columns)
+    const int nl = stream ? (nc < a.lds_cap ? nc : a.lds_cap)
+                          : (nc > lds_c0 ? nc - lds_c0 : 0);   // LDS columns of this workgroup
     double *Gs = smem;                                   // lds_cols x ld
     double *fsc = Gs + (size_t)lds_cols * ld;            // split: 8 x ld forward partials of the waves
     double *r_s = fsc + (split ? 8 * (size_t)ld : 0);    // ld
@@ -487,6 +494,32 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                 facc.x += g.x * x;
                 facc.y += g.y * x;
             }
+            if (stream) {
+                // the columns that are not resident: coalesced reads of the forward operator from
+                // L2 / Infinity Cache, eight in flight per thread, same order of the sums
+                const d2 *Gg = reinterpret_cast<const d2 *>(a.Gl + j0 * a.ld);
+                for (c = nl; c + 8 <= nc; c += 8) {
+                    d2 g[8];
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = Gg[(int64_t)(c + u) * ld2 + tid];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = xs[c + u];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        facc.x += g[u].x * x[u];
+                        facc.y += g[u].y * x[u];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (; c < nc; ++c) {
+                    const d2 g = Gg[(int64_t)c * ld2 + tid];
+                    const double x = xs[c];
+                    facc.x += g.x * x;
+                    facc.y += g.y * x;
+                }
+            }
         }
         if (stencil) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -691,10 +724,15 @@ __global__ void __launch_bounds__(RES_THREADS) resident_chain_kernel(ResArgs a)
                     if (c < nc) {
                         // (rows past the column read its last chunk again and meet rr = 0)
                         d2 g[RC];
+                        // (stream mode: a column that is not resident -- or, with the compressed
+                        // forward in LDS, any column of Aw -- comes from memory)
+                        const d2 *colp = (stream && (c >= nl || a.G != a.Gl))
+                                             ? reinterpret_cast<const d2 *>(a.G + (j0 + c) * a.ld)
+                                             : Gs2 + (c - lds_c0) * ld2;
 #pragma unroll
                         for (int k = 0; k < RC; ++k) {
                             const int e = lane + 64 * k;
-                            g[k] = Gs2[(c - lds_c0) * ld2 + (e < ld2 ? e : ld2 - 1)];
+                            g[k] = colp[e < ld2 ? e : ld2 - 1];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

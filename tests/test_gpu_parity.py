@@ -1792,3 +1792,56 @@ def test_one_launch_epilogue_matches_oracle_and_two_launch_form(G, orc, monkeypa
         assert abs(a1[0] - a0[0]) <= 1e-13 * abs(a0[0]) and relmax(a1[1], a0[1]) < 1e-12
         for (c1, o1, x1), (c0, o0, x0) in zip(r1, r0):
             assert c1 == c0 and relmax(o1, o0) < 1e-11
+
+
+@pytest.mark.parametrize("case", ["Damping", "TV", "wavelet3D-MS"])
+def test_resident_chain_kernel_streams_columns_that_do_not_fit(G, monkeypatch, case):
+    """Kernels larger than LDS + registers with N <= 1024 (the reference's ratiogrid example class):
+    the resident chain kernel keeps as many columns per workgroup as fit in LDS and reads the rest
+    from L2 / Infinity Cache in both passes of every evaluation (`stream` mode).  700 observations x
+    16000 prisms (90 MB; with the wavelet forward also its dense compressed form; TV: 1024 x 11000):
+    same chain as the
+    sweep-per-launch path, decisions identical, energies and models to 1e-11."""
+    # (the stencil regularisers need <= 44 cells per workgroup in this kernel: 1024 x 11000 there)
+    zmax, nox, noy = (1100, 32, 32) if case == "TV" else (1600, 28, 25)
+    mrange = (0, 4000, 0, 2500, 0, zmax)
+    mesh = G.mesher.PrismMesh(mrange, (100, 100, 100))
+    assert mesh.shape == (zmax // 100, 25, 40)
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 2500, noy), np.linspace(0, 4000, nox))]
+    zp = np.zeros_like(xp)
+    N, M = xp.size, mesh.size
+    assert N * M * 8 > 85e6
+    rng = np.random.default_rng(123)
+    rho = np.zeros(mesh.shape)
+    rho[3:7, 8:15, 12:24] = 0.6
+    wav = "3D" if case.startswith("wavelet") else False
+    reg = "MS" if case.startswith("wavelet") else case
+    trajs = [(int(rng.integers(2, 9)), rng.normal(size=M) * 0.001, float(rng.uniform())) for _ in range(10)]
+    res = {}
+    for mode in ("stream", "sweep"):
+        monkeypatch.setenv("GRAVHMC_RESIDENT", "1" if mode == "stream" else "0")
+        eng0 = G.Engine(N, M)
+        eng0.set_obs(xp, yp, zp)
+        eng0.set_cells(mesh.cell_bounds(), 0)
+        eng0.build_G()
+        d_true = eng0.forward(rho.ravel())
+        eng0.close()
+        dobs = d_true + 0.02 * np.abs(d_true).max() * np.random.default_rng(5).normal(size=N)
+        gm = G.GravMagModule(dobs, mrange, (100, 100, 100), (xp, yp, zp), wavelet=wav, verbose=False)
+        wm = gm.Wm.diagonal()
+        eng = gm._engine
+        eng.set_reg(reg, 1.0, 0.001, mesh.shape, 0.001 * wm)
+        eng.chain_init(0.001 * wm, 0.0 * wm, 1.0 * wm)
+        out = []
+        eng.run_chain(iter(trajs), 0.01, lambda L, acc, o, x: out.append((acc, o.copy(), x)), want_x=True, batch=4)
+        st = eng.chain_stats()
+        assert (st["resident_launches"] > 0) == (mode == "stream")
+        res[mode] = (out, eng.chain_get_x(), eng.chain_get_dsyn())
+        eng.close()
+    (a, ax, ad), (b, bx, bd) = res["stream"], res["sweep"]
+    assert len(a) == len(b) == len(trajs) and sum(t[0] for t in a) > 0
+    for (a1, o1, x1), (a2, o2, x2) in zip(a, b):
+        assert a1 == a2 and relmax(o1, o2) < 1e-11
+        if x1 is not None:
+            assert relmax(x1, x2) < 1e-11
+    assert relmax(ax, bx) < 1e-11 and relmax(ad, bd) < 1e-11
