@@ -287,6 +287,42 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
     return elapsed, naccept, ntraj, prof
 
 
+#: the other BASELINE.json configurations, each measured by a child process of the default run
+#: (same script, its own workload) and summarised under `extra`, so one driver record carries them
+EXTRA_RUNS = [
+    ("c3_segment_wavelet3d_tv", ["--workload", "c3_segment_wavelet3d_tv", "--steps", "20000", "--warmup", "2000"]),
+    ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
+                                         "--warmup", "10"]),
+    ("c4_global_tesseroid_dense", ["--workload", "c4_global_tesseroid", "--steps", "2000", "--warmup", "200"]),
+    ("c5_share_of_one_gpu_of_8", ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "8", "--steps", "40",
+                                  "--warmup", "10"]),
+]
+
+
+def extra_run(device, extra_args):
+    """One of EXTRA_RUNS in a child process (the parent has released its GPU context); returns a
+    compact summary of the child's JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-extra"] + extra_args
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env["LOCAL_RANK"] = str(device)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    if out.returncode != 0:
+        return {"error": out.stderr[-400:]}
+    l = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    r = l["roofline"]
+    keep = ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_ms", "launches", "us_per_evaluation",
+            "near_field_table", "entries_per_s", "flop_model")
+    return {"value": l["value"], "unit": l["unit"], "steps": l["steps"], "warmup": l["warmup"],
+            "ms_per_step": l["ms_per_step"],
+            "config": {k: l["config"].get(k) for k in ("workload", "N_obs", "M_cells", "G_bytes", "regulariser",
+                                                        "matrix_free", "wavelet_nnz", "dt", "traj_len", "accepted",
+                                                        "trajectories")},
+            "roofline": {k: r[k] for k in keep if k in r}}
+
+
 def c1_block(device, want_cpu):
     """BASELINE.json's target configuration (north_star: uniformgrid 20 x 30 x 10, Damping, one chain)
     measured in the same process, for the `extra` field of the line: steps/s, us per potential
@@ -599,6 +635,11 @@ def main():
                 line["extra"] = {"c1_uniform_20x30x10": c1_block(dev, not args.no_cpu_baseline)}
             except Exception as e:
                 line["extra"] = {"c1_uniform_20x30x10": {"error": "%s: %s" % (type(e).__name__, e)}}
+            for tag, xargs in EXTRA_RUNS:
+                try:
+                    line["extra"][tag] = extra_run(dev, xargs)
+                except Exception as e:
+                    line["extra"][tag] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line))
     ranks.close()
 
