@@ -46,7 +46,9 @@ static bool resident_plan(gh_ctx *c)
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess)
         return false;
-    const int cpw = (int)((c->M + c->cus - 1) / c->cus);
+    // (GRAVHMC_RESIDENT_WGS: diagnostic -- fewer, larger workgroups)
+    const int wgs = std::max(1, std::min(c->cus, env_int("GRAVHMC_RESIDENT_WGS", c->cus)));
+    const int cpw = (int)((c->M + wgs - 1) / wgs);
     if (cpw > RES_THREADS) return false;
     r.lds_max = lds_max;
     r.cpw = cpw;
