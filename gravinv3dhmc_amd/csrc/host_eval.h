@@ -82,8 +82,8 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
         src = d_out;
         nseg = 1;
-    } else if (c->grid > 64 && c->slab2 && c->slab2_rows == 1 && c->dsum_live && o.part) {
-        // one reduction stage and the slab rows' sums at hand: the whole epilogue in one launch
+    } else if (c->dsum_live && o.part) {
+        // the slab rows' sums at hand (and N >= 2048): the whole epilogue in one launch
         ReduceFinishArgs fa{};
         fa.slab = c->slab;
         fa.n_rows_slab = c->slab_live > 0 ? c->slab_live : c->grid;
@@ -182,8 +182,7 @@ static int ensure_work(gh_ctx *c)
         TRY(dalloc(c, &c->slab2, (size_t)c->slab2_rows * ld));
     }
     c->n_dpart = (int)((c->ld + 31) / 32);
-    if (c->grid > 64 && c->slab2_rows == 1 && c->TW == 16 && c->n_panels == 1 && !c->mf &&
-        env_int("GRAVHMC_EPILOGUE1", 1) != 0) {
+    if (c->ld >= 2048 && c->TW > 1 && c->n_panels == 1 && !c->mf && env_int("GRAVHMC_EPILOGUE1", 1) != 0) {
         TRY(dalloc(c, &c->dsum, (size_t)c->grid));
         for (int i = 0; i < 4; ++i) TRY(dalloc(c, &c->st[i].part, (size_t)c->n_dpart + (size_t)((c->M + 255) / 256)));
     }

@@ -479,7 +479,7 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
     if (c->n_panels == 1) {
         a.row0 = 0;
         a.rows = c->ld;
-        if ((a.mode & SW_FWD) && c->TW == 16 && c->dsum) {
+        if ((a.mode & SW_FWD) && c->TW > 1 && c->dsum) {
             a.dsum = c->dsum;  // sums of the slab rows: the epilogue then needs one launch
             c->dsum_live = true;
         }

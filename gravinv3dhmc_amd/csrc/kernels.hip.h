@@ -116,7 +116,7 @@ struct SweepArgs {
     double *g_out;        // M (SW_GOUT)
     double *slab;         // gridDim.x x ld (SW_FWD)
     double *pp_part;      // n_teams (SW_PFIN): sum of p_j^2 over the team's columns
-    double *dsum;         // gridDim.x or nullptr (SW_FWD, TW == 16): sum over the rows of the block's slab row
+    double *dsum;         // gridDim.x or nullptr (SW_FWD, TW > 1): sum over the rows of the block's slab row
 };
 
 using d2 = double __attribute__((ext_vector_type(2)));
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
                     ds += dacc[k].y;
                 }
             }
-            if (TW == 16 && a.dsum) {
+            if (a.dsum) {
                 // sum of this slab row (pad rows are zero): lets the epilogue know mean(d) before it
                 // has reduced the slab (reduce_finish_kernel)
                 const double t = block_allreduce_sum(ds, scratch, TW);
@@ -605,8 +605,8 @@ reduce_reg_kernel(const double *slab, int n_rows_slab, int64_t ld, int nseg, int
     }
 }
 
-// The whole per-step epilogue in ONE launch, for d that needs a single reduction stage (ld > 8192)
-// after a sweep that also delivered the sums of its slab rows (dsum).  Because
+// The whole per-step epilogue in ONE launch (N >= 2048: enough 32-observation blocks to fill the
+// chip) after a sweep that also delivered the sums of its slab rows (dsum).  Because
 //     sum_i d_i = sum_t sum_i slab[t][i] = sum_t dsum[t],
 // every block knows mean(d + grav_fix) (potential.py:706) before the slab is reduced, so the blocks
 // that reduce the slab for 32 observations each can form the residual and their share of |r|^2 at
