@@ -174,7 +174,8 @@ static int ensure_work(gh_ctx *c)
     TRY(dalloc(c, &c->pb[1], M));
     TRY(dalloc(c, &c->pn, M));
     if (c->n_panels > 1) TRY(dalloc(c, &c->gbuf, M));
-    TRY(dalloc(c, &c->slab, (size_t)c->grid * ld));
+    // (N > 16384: the team sweep writes one slab row per team, up to 128, whatever the panel grid)
+    TRY(dalloc(c, &c->slab, (size_t)(c->n_panels > 1 ? std::max(c->grid, 128) : c->grid) * ld));
     if (c->grid > 64) {
         // segments left for the single-block finish_kernel: as many as keep its read at ~128 KB
         // (C1: 16 x 608 rows; C2: 1 x 10^4 -- sixteen there made that one block read 1.3 MB, 57 us)

@@ -158,7 +158,8 @@ static int configure_sweep(gh_ctx *c)
     c->grid = (c->n_teams + wg_teams - 1) / wg_teams;
     // (one-wave teams interleave inside their block's column range: every wave of the grid is a team)
     if (tw == 1) c->n_teams = c->n_teams_sweep = c->grid * wg_teams;
-    if (c->n_panels > 1) c->n_teams = std::max(c->n_teams, (int)((c->M + 255) / 256));  // vec_update partials
+    // (row panels: partials of vec_update; the team sweep: one per team, at most 128 teams)
+    if (c->n_panels > 1) c->n_teams = std::max(std::max(c->n_teams, 128), (int)((c->M + 255) / 256));
     return GH_OK;
 }
 
@@ -378,7 +379,6 @@ static bool team_plan(gh_ctx *c)
     if (t.tpx < 1) return false;
     t.grid = 8 * t.tpx * t.Q;
     const int n_teams = 8 * t.tpx;
-    if (n_teams > c->grid) return false;     // the slab was sized for the panel launches
     t.cols_per_team = (c->M + n_teams - 1) / n_teams;
     t.lds = ((size_t)t.panel_rows + 2 * TS_MAXWAVES + TS_RING * 8 + 4) * sizeof(double);
     team_fn f = team_kernel_for(t.threads, t.ept2, t.depth);

@@ -1845,3 +1845,34 @@ def test_resident_chain_kernel_streams_columns_that_do_not_fit(G, monkeypatch, c
         if x1 is not None:
             assert relmax(x1, x2) < 1e-11
     assert relmax(ax, bx) < 1e-11 and relmax(ad, bd) < 1e-11
+
+
+@pytest.mark.parametrize("N,M", [(16400, 7), (20481, 50), (40960, 301)])
+def test_team_sweep_odd_shapes_match_row_panels(G, monkeypatch, N, M):
+    """Teams of 2, 3 and 4 workgroups per column, fewer columns than teams (idle teams), a column
+    count that does not divide: the chain on teams against the chain in row panels (1e-12), with the
+    speculative first steps and a clamping bound in play."""
+    rng = np.random.default_rng(N + M)
+    A = np.asfortranarray(rng.normal(size=(N, M)) * rng.uniform(0.2, 2, size=M))
+    dobs = rng.normal(size=N) * 3
+    trajs = [(int(rng.integers(1, 6)), rng.normal(size=M) * 0.02, float(rng.uniform())) for _ in range(6)]
+    res = {}
+    for team in ("1", "0"):
+        monkeypatch.setenv("GRAVHMC_TEAM", team)
+        eng = G.Engine(N, M)
+        eng.upload_G(A)
+        wm = eng.weight(0.5)
+        eng.set_data(dobs)
+        eng.set_reg("MS", 0.7, 0.01, (1, 1, M), 0.001 * wm)
+        eng.chain_init(0.001 * wm, 0.0 * wm, 0.05 * wm)
+        out = []
+        eng.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: out.append((acc, o.copy(), xs)), want_x=True)
+        st = eng.chain_stats()
+        assert (st["team_launches"] > 0) == (team == "1") and st["team_timeouts"] == 0
+        if team == "1":
+            assert st["team_members"] == (N + 15) // 16 * 16 // 10240 + (1 if (N + 15) // 16 * 16 % 10240 else 0)
+        res[team] = (out, eng.chain_get_x())
+        eng.close()
+    for (a1, o1, x1), (a0, o0, x0) in zip(res["1"][0], res["0"][0]):
+        assert a1 == a0 and relmax(o1, o0) < 1e-12 and (x1 is None or relmax(x1, x0) < 1e-12)
+    assert relmax(res["1"][1], res["0"][1]) < 1e-12
