@@ -171,8 +171,18 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
                     _lib.check(lib.gh_shard_unique_id(idbuf), None)
                 raw = ranks.broadcast_bytes(idbuf.raw)
                 idbuf = C.create_string_buffer(raw, 128)
-                self._chk(lib.gh_shard_init(self._h, idbuf, ranks.rank, ranks.world, self.M_global,
-                                            self.m0))
+                # (RCCL prints a version banner to stdout when it initialises: keep stdout for the
+                # caller's own output -- bench.py's single JSON line -- and send the banner to stderr)
+                import sys
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    rc = lib.gh_shard_init(self._h, idbuf, ranks.rank, ranks.world, self.M_global, self.m0)
+                finally:
+                    os.dup2(saved, 1)
+                    os.close(saved)
+                self._chk(rc)
             else:
                 def _cb(_user, ptr_, count):
                     try:
