@@ -166,11 +166,6 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
             self.M_local = self.M
             lib = self._lib
             if backend == "rccl":
-                idbuf = C.create_string_buffer(128)
-                if ranks.rank == 0:
-                    _lib.check(lib.gh_shard_unique_id(idbuf), None)
-                raw = ranks.broadcast_bytes(idbuf.raw)
-                idbuf = C.create_string_buffer(raw, 128)
                 # (RCCL prints a version banner to stdout when it initialises: keep stdout for the
                 # caller's own output -- bench.py's single JSON line -- and send the banner to stderr)
                 import sys
@@ -178,6 +173,11 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
                 saved = os.dup(1)
                 os.dup2(2, 1)
                 try:
+                    idbuf = C.create_string_buffer(128)
+                    rc = lib.gh_shard_unique_id(idbuf) if ranks.rank == 0 else 0
+                    _lib.check(rc, None)
+                    raw = ranks.broadcast_bytes(idbuf.raw)
+                    idbuf = C.create_string_buffer(raw, 128)
                     rc = lib.gh_shard_init(self._h, idbuf, ranks.rank, ranks.world, self.M_global, self.m0)
                 finally:
                     os.dup2(saved, 1)
