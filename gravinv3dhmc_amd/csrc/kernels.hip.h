@@ -1533,10 +1533,12 @@ ring_stats_kernel(const double *ring, int64_t M, int nvalid, double *mean, doubl
 }
 
 // ------------------------------------------------------------------------- matrix-free path
-// G is never stored: every entry is re-evaluated where it is needed (two evaluations per
-// leapfrog step: once for the adjoint/update pass, once for the forward pass), for problems whose
-// kernel matrix does not fit in HBM.  Wavefront reductions only, no MFMA.  The weighted kernel
-// is Aw_ij = K_ij / wm_j with the column norms wm computed by mf_colnorm_kernel.
+// G is never stored: every entry is re-evaluated where it is needed, for problems whose kernel
+// matrix does not fit in HBM.  N <= 16384: ONE evaluation per entry and leapfrog step
+// (mf_fused_kernel below: the dense sweep's fusion on computed entries); larger N: two
+// (mf_adjoint_kernel for the adjoint / update, mf_forward_kernel for the forward).  Wavefront and
+// block reductions only, no MFMA.  The weighted kernel is Aw_ij = K_ij / wm_j with the column norms
+// wm computed by mf_colnorm_kernel.
 
 struct MfGeom {
     int kind;  // 0 prism, 1 tesseroid
