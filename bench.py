@@ -609,8 +609,8 @@ def main():
                 "bound": "fp64 vector (no stored G: entries re-evaluated, every entry once per step)",
                 "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / FP64_VECTOR_PEAK_TFLOPS if tflops else None, "traffic": None,
-                "kernel": "mf_fused_kernel (entries of a cell's column evaluated once, dot with r, "
-                          "leapfrog update, forward accumulation)",
+                "kernel": "mf_tess_fast_kernel / mf_fused_kernel (entries of a cell's column evaluated once, "
+                          "dot with r, leapfrog update, forward accumulation)",
                 "launches": st["launches"], "avg_ms": sweep_ms,
                 "entries_per_launch": st["entries"] / max(1, st["launches"]),
                 "leaves_per_launch": st["leaves"] / max(1, st["launches"]),

@@ -39,6 +39,7 @@ struct gh_ctx {
     ghk::MfStats *mf_stats = nullptr; // entries / GLQ leaves evaluated while profiling is enabled
     // tesseroids: near-field table (pairs that need the adaptive subdivision: evaluated once, kept)
     bool mf_near_on = false;
+    bool mf_pipe = false;    // mf_tess_fast_kernel (next column's constants fetched ahead; r and the column in LDS)
     bool mf_exact = false;   // GRAVHMC_MF_EXACT=1: the root leaf in the reference's operation order (tess_leaf_cc)
     int64_t *mf_near_ptr = nullptr;
     int *mf_near_row = nullptr;

@@ -204,7 +204,14 @@ static mf_fused_fn mf_fused_for(const gh_ctx *c)
 {
     if (c->cell_kind != GH_CELL_TESSEROID) return mf_fused_for_kind<0>(c->mf_T, c->mf_EPT);
     if (!c->mf_near_on) return mf_fused_for_kind<1>(c->mf_T, c->mf_EPT);
-    return c->mf_exact ? mf_fused_for_kind<2>(c->mf_T, c->mf_EPT) : mf_fused_for_kind<3>(c->mf_T, c->mf_EPT);
+    if (c->mf_exact) return mf_fused_for_kind<2>(c->mf_T, c->mf_EPT);
+    if (!c->mf_pipe) return mf_fused_for_kind<3>(c->mf_T, c->mf_EPT);
+    // the fast pass with the next column's constants and scalars fetched ahead (same bits)
+    if (c->mf_T == 256) return c->mf_EPT <= 4 ? mf_tess_fast_kernel<256, 4> : mf_tess_fast_kernel<256, 8>;
+    if (c->mf_T == 512) return c->mf_EPT <= 8 ? mf_tess_fast_kernel<512, 8> : mf_tess_fast_kernel<512, 16>;
+    if (c->mf_EPT <= 4) return mf_tess_fast_kernel<1024, 4>;
+    if (c->mf_EPT <= 8) return mf_tess_fast_kernel<1024, 8>;
+    return mf_tess_fast_kernel<1024, 16>;
 }
 
 // Tesseroids, fused pass: list of the pairs whose root must be subdivided (or flags an error), with
@@ -266,6 +273,13 @@ static int configure_mf(gh_ctx *c)
         const int e = (int)((ld + c->mf_T - 1) / c->mf_T);
         c->mf_EPT = c->mf_T == 256 ? (e <= 4 ? 4 : 8) : c->mf_T == 512 ? (e <= 8 ? 8 : 16) : (e <= 4 ? 4 : e <= 8 ? 8 : 16);
         c->mf_lds = ((size_t)c->mf_T * c->mf_EPT + 2 * (c->mf_T / 64 + 8)) * sizeof(double);
+        {
+            // the pipelined tesseroid pass also keeps r, the parked constants and scalars in LDS
+            const size_t pipe_lds = (2 * (size_t)c->mf_T * c->mf_EPT + 2 * (c->mf_T / 64 + 8) + 64 + 48) * sizeof(double);
+            c->mf_pipe = c->cell_kind == GH_CELL_TESSEROID && c->mf_near_on && !c->mf_exact &&
+                         env_int("GRAVHMC_MF_PIPE", 1) != 0 && pipe_lds <= 160 * 1024;
+            if (c->mf_pipe) c->mf_lds = pipe_lds;
+        }
         mf_fused_fn f = mf_fused_for(c);
         HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), c->mf_lds));
         int occ = 0;

@@ -2081,4 +2081,192 @@ mf_fused_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const doub
     }
 }
 
+
+// ---- the fast tesseroid pass with its per-column latencies taken out of the way -----------------
+// mf_fused_kernel<.., 3> moves through a column in lock-step phases (28 cell constants by scalar
+// loads -> slots -> barrier -> seven per-cell scalars -> update -> forward) and, with ONE workgroup
+// per CU, nothing overlaps the ~1 us memory round trips at the phase boundaries: the SQ counters
+// showed VALU busy 59 % at 171 instructions per slot.  Here wave 0 requests the NEXT column's cell
+// constants and per-cell scalars while the current column's slots are evaluated and parks them in
+// LDS before the column's barrier; every wave then picks them up from LDS (a broadcast read made
+// uniform with readfirstlane) -- ~100 cycles instead of an L2 round trip.  Same arithmetic, same
+// order of the sums as mf_fused_kernel<.., 3>: identical bits.
+__device__ __forceinline__ double uniform_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+template <int T, int EPT>
+__global__ void __launch_bounds__(T)
+mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const double *__restrict__ cellc,
+                    MfNear near, MfStats *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = T / 64;
+    constexpr int SLOT = NW + 8;
+    constexpr int NSC = 16;                     // per-cell scalars parked per column
+    double *Ks = smem;
+    double *rs = Ks + (size_t)T * EPT;          // r, padded with zeros to T * EPT
+    double *scratch = rs + (size_t)T * EPT;     // 2 x SLOT: ping-pong slots of the dot
+    double *ccs = scratch + 2 * SLOT;           // 2 x 32: cell constants of this / the next column
+    double *cs = ccs + 64;                      // 3 x NSC: x, p, low, high, greg, pn, wm, near.ptr[j], [j+1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mode = a.mode;
+    const int64_t N = g.N;
+    const int ept = (int)((a.ld + T - 1) / T);
+    double dacc[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int64_t i = tid + (int64_t)k * T;
+        dacc[k] = 0.0;
+        rs[(size_t)k * T + tid] = ((mode & SW_ADJ) && i < N) ? a.r[i] : 0.0;
+    }
+    double pp = 0.0;
+    unsigned nent = 0;
+    // what wave 0 fetches for a column: lanes 0..27 the cell constants, lanes 32..40 the scalars
+    auto fetch = [&](int64_t j) -> double {
+        double v = 0.0;
+        if (lane < TESS_NC) {
+            v = cellc[(int64_t)TESS_NC * j + lane];
+        } else if (lane >= 32 && lane < 39) {
+            const int q = lane - 32;
+            const double *src = q == 0 ? a.x_in : q == 1 ? a.p_in : q == 2 ? a.low : q == 3 ? a.high
+                              : q == 4 ? a.greg : q == 5 ? a.pn_in : wm;
+            if (src) v = src[j];
+            if (q == 6 && !wm) v = 1.0;
+        } else if (lane == 39 || lane == 40) {
+            v = (double)near.ptr[j + (lane - 39)];  // (exact: far below 2^53)
+        }
+        return v;
+    };
+    auto park = [&](double v, int itn) {
+        if (lane < TESS_NC) ccs[(itn & 1) * 32 + lane] = v;
+        else if (lane >= 32 && lane < 41) cs[(itn % 3) * NSC + (lane - 32)] = v;
+    };
+    if (wave == 0 && (int64_t)blockIdx.x < g.M) park(fetch(blockIdx.x), 0);
+    // the observation's five numbers for slot 0 never change: kept in registers
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0;
+    if (tid < N) {
+        f0 = g.o4[tid];
+        f1 = g.o5[tid];
+        f2 = g.o1[tid];
+        f3 = g.o2[tid];
+        f4 = g.o3[tid];
+    }
+    __syncthreads();
+    int it = 0;
+    for (int64_t j = blockIdx.x; j < g.M; j += gridDim.x, ++it) {
+        const int64_t jn = j + gridDim.x;
+        double nxt = 0.0;
+        if (wave == 0 && jn < g.M) nxt = fetch(jn);   // in flight while the slots are evaluated
+        // this column's cell constants, uniform
+        double cc[TESS_NC];
+#pragma unroll
+        for (int q = 8; q < TESS_NC; ++q) cc[q] = uniform_d(ccs[(it & 1) * 32 + q]);
+        int64_t i = tid;
+        double c0 = f0, c1 = f1, c2 = f2, c3 = f3, c4 = f4;
+#pragma unroll 1
+        for (int k = 0; k < ept; ++k) {
+            const int64_t in = i + T;
+            double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, n4 = 0.0;
+            if (k + 1 < ept && in < N) {
+                n0 = g.o4[in];
+                n1 = g.o5[in];
+                n2 = g.o1[in];
+                n3 = g.o2[in];
+                n4 = g.o3[in];
+            }
+            double v = 0.0;
+            if (i < N) {
+                v = tess_leaf_fast(c0, c1, c2, c3, c4, cc);
+                nent += 1;
+            }
+            Ks[(size_t)k * T + tid] = v;
+            i = in;
+            c0 = n0;
+            c1 = n1;
+            c2 = n2;
+            c3 = n3;
+            c4 = n4;
+        }
+        const double *sc = cs + (it % 3) * NSC;
+        const int64_t q0 = (int64_t)sc[7], q1 = (int64_t)sc[8];
+        if (q1 > q0) {
+            __syncthreads();
+            for (int64_t q = q0 + tid; q < q1; q += T) Ks[near.row[q]] = near.val[q];
+            __syncthreads();
+        }
+        double s = 0.0;
+        if (mode & SW_ADJ) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (k < ept) s += Ks[(size_t)k * T + tid] * rs[(size_t)k * T + tid];
+            s = wave_sum_dpp(s);
+        }
+        double *slot = scratch + (it & 1) * SLOT;
+        if (lane == 0) slot[wave] = s;
+        if (wave == 0 && jn < g.M) park(nxt, it + 1);
+        __syncthreads();
+        const double w = sc[6];
+        double xj = sc[0];
+        if (mode & SW_ADJ) {
+            double t = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) t += slot[wv];
+            t = (w != 0.0) ? t * (1.0 / w) : t;
+            const double grad = 2.0 * t + sc[4];
+            if ((mode & SW_GOUT) && tid == 0) a.g_out[j] = grad;
+            if (mode & SW_PFIN) {
+                const double pf = sc[1] - a.c_p * grad;
+                pp += pf * pf;
+                if (!(mode & SW_SPEC) && tid == 0) a.p_out[j] = pf;
+            }
+            if (mode & SW_UPD) {
+                const double psrc = (mode & SW_SPEC) ? sc[5] : sc[1];
+                double pj = psrc - a.c_u * grad;
+                xj = xj + a.dt * pj;
+                const double hi = sc[3], lo = sc[2];
+                if (xj > hi) {
+                    xj = hi;
+                    pj = -pj;
+                } else if (xj < lo) {
+                    xj = lo;
+                    pj = -pj;
+                }
+                if (tid == 0) {
+                    a.p_out[j] = pj;
+                    a.x_out[j] = xj;
+                }
+            }
+        }
+        if (mode & SW_FWD) {
+            const double xs = (w != 0.0) ? xj * (1.0 / w) : xj;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (k < ept) dacc[k] += Ks[(size_t)k * T + tid] * xs;
+        }
+    }
+    if ((mode & SW_PFIN) && tid == 0) a.pp_part[blockIdx.x] = pp;
+    if (mode & SW_FWD) {
+        double *out = a.slab + (int64_t)blockIdx.x * a.ld;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int64_t i = tid + (int64_t)k * T;
+            if (i < a.ld) out[i] = dacc[k];
+        }
+    }
+    if (stats) {
+        unsigned long long e = nent;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) e += __shfl_xor(e, off, WAVE);
+        if (lane == 0) {
+            atomicAdd(&stats->entries, e);
+            atomicAdd(&stats->leaves, e);
+        }
+    }
+}
+
 }  // namespace ghk

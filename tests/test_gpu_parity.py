@@ -1876,3 +1876,48 @@ def test_team_sweep_odd_shapes_match_row_panels(G, monkeypatch, N, M):
     for (a1, o1, x1), (a0, o0, x0) in zip(res["1"][0], res["0"][0]):
         assert a1 == a0 and relmax(o1, o0) < 1e-12 and (x1 is None or relmax(x1, x0) < 1e-12)
     assert relmax(res["1"][1], res["0"][1]) < 1e-12
+
+
+def test_matrix_free_tesseroid_fast_pass_variants_agree(G, monkeypatch):
+    """The fast tesseroid pass in its three builds -- pipelined (next column's constants fetched
+    ahead, r in LDS), plain, and the reference's operation order -- on a regional mesh with enough
+    observations (9000: sixteen rows per thread, where the pipelined build does not fit the LDS and
+    the plain one runs) and on a smaller one (2500: the pipelined build): forward, adjoint and a chain
+    agree to 1e-11 (the decisions are the near-field table's in every build)."""
+    mesh = G.mesher.TesseroidMesh((100, 130, 20, 50, 0, -200000), (-50000, 1.5, 1.5))
+    M = mesh.size
+    rng = np.random.default_rng(7)
+    for nlon, nlat in ((50, 50), (100, 90)):
+        lon, lat = [v.ravel() for v in np.meshgrid(np.linspace(100, 130, nlon), np.linspace(20, 50, nlat), indexing="ij")]
+        h = np.full_like(lon, 200000.0)   # (high enough for the near-field pairs to stay below 1/64)
+        N = lon.size
+        x = rng.uniform(0, 1, M)
+        r = rng.normal(size=N)
+        trajs = [(int(rng.integers(2, 6)), rng.normal(size=M) * 0.001, float(rng.uniform())) for _ in range(3)]
+        res = {}
+        for tag, env in (("pipe", {"GRAVHMC_MF_PIPE": "1", "GRAVHMC_MF_EXACT": "0"}),
+                         ("plain", {"GRAVHMC_MF_PIPE": "0", "GRAVHMC_MF_EXACT": "0"}),
+                         ("exact", {"GRAVHMC_MF_PIPE": "0", "GRAVHMC_MF_EXACT": "1"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            eng = G.Engine(N, M)
+            eng.set_matrix_free(True)
+            eng.set_obs(lon, lat, h)
+            eng.set_cells(mesh.cell_bounds(), 1, 1.6)
+            eng.build_G()
+            wm = eng.weight(0.5)
+            st = eng.matrix_free_stats()
+            assert st["near_entries"] > 0                      # the table is in use
+            f, g = eng.forward(x * wm), eng.adjoint(r)
+            eng.set_data(f + 0.01 * np.abs(f).max() * rng.normal(size=N) * 0 + 0.01 * np.abs(f).max())
+            eng.set_reg("Damping", 0.05, 0.01, mesh.shape, 0.001 * wm)
+            eng.chain_init(0.001 * wm, 0.0 * wm, 0.8 * wm)
+            out = []
+            eng.run_chain(iter(trajs), 0.005, lambda L, acc, o, xx: out.append((acc, o.copy())))
+            res[tag] = (f, g, out, eng.chain_get_x())
+            eng.close()
+        for tag in ("pipe", "plain"):
+            a, b = res[tag], res["exact"]
+            assert relmax(a[0], b[0]) < 1e-11 and relmax(a[1], b[1]) < 1e-11 and relmax(a[3], b[3]) < 1e-10
+            for (a1, o1), (a2, o2) in zip(a[2], b[2]):
+                assert a1 == a2 and relmax(o1, o2) < 1e-10
