@@ -42,7 +42,7 @@ class GravMagModule(object):
       ranks' GPUs (each holds N x M/world of G); shard_backend "rccl" or "gloo"; shard_planes=True
       splits in whole z-planes, which the Smoothness/TV regularisers need on a sharded model.
     * matrix_free: never store G; re-evaluate the prism / tesseroid entries in every potential
-      evaluation (for kernels larger than HBM; the global tesseroid example: ~6x slower per step than
+      evaluation (for kernels larger than HBM; the global tesseroid example: ~5x slower per step than
       the dense path).
     """
 
