@@ -1766,12 +1766,18 @@ __device__ __forceinline__ double tess_leaf_cc(double lon, double sinlat, double
 // when the near-field table was built).  cos(lon - lonc) by the addition theorem from sin / cos of
 // the observation's longitude (tabulated per observation) and of the nodes' (per cell): 2 FMAs
 // instead of a ~55-instruction cos; 1 / l^3 as rsq(l^2)^3 with the hardware reciprocal square root
-// refined by two Newton steps (to the last bit or two) instead of an IEEE sqrt and an IEEE divide
+// refined by a Newton step (to ~1e-15) instead of an IEEE sqrt and an IEEE divide
 // (~28 instructions); contraction allowed.  The reference itself writes l_sqr**1.5
 // (_tesseroid_numba.py:218), so no form is bitwise its pow(); this one agrees with tess_leaf_cc to
 // <= 1e-13 of the entry for pairs that are far by the reference's own criterion (the conditioning
 // of l^2 = r^2 + r'^2 - 2 r r' cos psi is the formulation's: an ulp of cos psi moves l^2 by
 // 2 r r' 1e-16 ~ 1e-2 m^2 against l^2 >= 1e10 m^2).  Stated tolerance of the path: 1e-10.
+// Newton steps behind v_rsq_f64 (measured at C4 against the dense engine: one step forward 6.5e-15 /
+// gradient 9.8e-15, two steps 6.2e-15 / 7.3e-15 -- the hardware estimate is good to ~2^-26 and what
+// remains is the conditioning of l^2; one step is 8 % faster)
+#ifndef TESS_FAST_NEWTON
+#define TESS_FAST_NEWTON 1
+#endif
 __device__ __forceinline__ double tess_leaf_fast(double sinlon, double coslon_o, double sinlat, double coslat,
                                                  double radius, const double *__restrict__ cc)
 {
@@ -1791,7 +1797,9 @@ __device__ __forceinline__ double tess_leaf_fast(double sinlon, double coslon_o,
                 double y = __builtin_amdgcn_rsq(l_sqr);
                 const double h = 0.5 * l_sqr;
                 y = fma(y, fma(-h * y, y, 0.5), y);
+#if TESS_FAST_NEWTON > 1
                 y = fma(y, fma(-h * y, y, 0.5), y);
+#endif
                 result = fma(cc[18 + 2 * j + k] * (rck * cospsi - radius), y * y * y, result);
             }
         }
