@@ -55,13 +55,15 @@ def pmc_traffic(workload):
     (None, None) when no profile of this workload exists."""
     import glob
     tag = workload.split("_")[0]
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", tag + "_pmc_summary.json")),
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", tag + "*_pmc_summary.json")),
                     reverse=True):
         try:
             doc = json.load(open(f))
             ks = doc["kernels"]
-            k = [v for n, v in ks.items() if "sweep_kernel" in n][0]
-            b = k["hbm_read_bytes"] + k["hbm_write_bytes"]
+            # the dominant kernel of the workload: the team sweep where it runs, else the sweep
+            k = ([v for n, v in ks.items() if "teamsweep_kernel" in n] or
+                 [v for n, v in ks.items() if "sweep_kernel<" in n])[0]
+            b = k["hbm_read_bytes"] + k.get("hbm_write_bytes", 0.0)
             return b, {"file": os.path.relpath(f, ROOT), "bytes_per_launch": b,
                        "note": "separate rocprofv3 --pmc passes of this command, committed with the "
                                "sources (commit %s); not a counter of this run" % doc.get("commit", "n/a")}
