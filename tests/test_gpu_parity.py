@@ -1921,3 +1921,61 @@ def test_matrix_free_tesseroid_fast_pass_variants_agree(G, monkeypatch):
             assert relmax(a[0], b[0]) < 1e-11 and relmax(a[1], b[1]) < 1e-11 and relmax(a[3], b[3]) < 1e-10
             for (a1, o1), (a2, o2) in zip(a[2], b[2]):
                 assert a1 == a2 and relmax(o1, o2) < 1e-10
+
+
+@pytest.mark.parametrize("path", ["team_sweep", "matrix_free_tesseroid", "resident_stream"])
+def test_round2_paths_are_bitwise_reproducible(G, path):
+    """The inter-workgroup exchanges of the team sweep and of the resident kernel's stream mode, and
+    the matrix-free pass with its near-field table, sum in an order fixed by indices alone: two runs
+    of the same chain give the same bits."""
+    rng = np.random.default_rng(31)
+    runs = []
+    for rep in range(2):
+        if path == "team_sweep":
+            N, M = 20481, 160
+            r0 = np.random.default_rng(5)
+            A = np.asfortranarray(r0.normal(size=(N, M)) * r0.uniform(0.2, 2, size=M))
+            eng = G.Engine(N, M)
+            eng.upload_G(A)
+            wm = eng.weight(0.5)
+            eng.set_data(r0.normal(size=N) * 3)
+            shape, hi, dt, sig = (4, 5, 8), 0.3, 0.002, 0.02
+        elif path == "matrix_free_tesseroid":
+            mesh = G.mesher.TesseroidMesh((100, 130, 20, 50, 0, -200000), (-50000, 1.5, 1.5))
+            lon, lat = [v.ravel() for v in np.meshgrid(np.linspace(100, 130, 50), np.linspace(20, 50, 50), indexing="ij")]
+            N, M = lon.size, mesh.size
+            eng = G.Engine(N, M)
+            eng.set_matrix_free(True)
+            eng.set_obs(lon, lat, np.full_like(lon, 200000.0))
+            eng.set_cells(mesh.cell_bounds(), 1, 1.6)
+            eng.build_G()
+            wm = eng.weight(0.5)
+            eng.set_data(eng.forward(np.random.default_rng(6).uniform(0, 1, M) * wm))
+            shape, hi, dt, sig = mesh.shape, 0.8, 0.005, 0.001
+        else:
+            mesh = G.mesher.PrismMesh((0, 4000, 0, 2500, 0, 1600), (100, 100, 100))
+            yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 2500, 25), np.linspace(0, 4000, 28))]
+            N, M = xp.size, mesh.size
+            eng = G.Engine(N, M)
+            eng.set_obs(xp, yp, np.zeros_like(xp))
+            eng.set_cells(mesh.cell_bounds(), 0)
+            eng.build_G()
+            wm = eng.weight(0.5)
+            eng.set_data(eng.forward(np.random.default_rng(6).uniform(0, 1, M) * wm))
+            shape, hi, dt, sig = mesh.shape, 1.0, 0.01, 0.001
+        eng.set_reg("MS", 0.7, 0.01, shape, 0.001 * wm)
+        eng.chain_init(0.001 * wm, 0.0 * wm, hi * wm)
+        r1 = np.random.default_rng(9)
+        trajs = [(int(r1.integers(2, 7)), r1.normal(size=M) * sig, float(r1.uniform())) for _ in range(6)]
+        out = []
+        eng.run_chain(iter(trajs), dt, lambda L, acc, o, x: out.append((acc, o.copy())), batch=3)
+        st = eng.chain_stats()
+        if path == "team_sweep":
+            assert st["team_launches"] > 0 and st["team_members"] == 3
+        if path == "resident_stream":
+            assert st["resident_launches"] > 0
+        runs.append((out, eng.chain_get_x(), eng.chain_get_dsyn()))
+        eng.close()
+    (a, ax, ad), (b, bx, bd) = runs
+    assert len(a) == 6 and all(a1 == b1 and np.array_equal(o1, o2) for (a1, o1), (b1, o2) in zip(a, b))
+    assert np.array_equal(ax, bx) and np.array_equal(ad, bd)
