@@ -245,21 +245,19 @@ LAST_STATE = {"U": None}
 def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: None):
     """One chain through the sampler's own path (Engine.run_chain), momenta drawn in the reference's
     RNG order (legacy global generator, hmc.py:95,164).  Returns (elapsed_s, accepted, trajectories,
-    profile).  ONE trajectory is drawn before the clock starts; every other draw (the first look-ahead
-    included) happens inside the timed region, overlapped with the GPU where the pipeline manages to."""
-    import itertools
+    profile).  Every draw happens inside the timed region, overlapped with the GPU where the pipeline
+    manages to."""
     np.random.seed(seed)
+    from gravinv3dhmc_amd.inversion.rng import LegacyDraws
 
     def prepare(total_steps):
         plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
-
-        def draws():
-            for n in plan:
-                yield n, np.random.randn(M) * Sigma, np.random.rand()
-
-        gen = draws()
-        head = list(itertools.islice(gen, 1))          # the first trajectory only
-        return plan, itertools.chain(head, gen)
+        if os.environ.get("GRAVHMC_HOST_RNG", "native") == "numpy":
+            def draws():
+                for n in plan:
+                    yield n, np.random.randn(M) * Sigma, np.random.rand()
+            return plan, draws()
+        return plan, LegacyDraws(M, (L, L), Sigma, fixed_L=plan)   # the same stream, drawn by the library
 
     def run(prepared):
         plan, gen = prepared
@@ -270,7 +268,11 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
             stat["traj"] += 1
             LAST_STATE["U"] = [float(v) for v in out5[:3]]
 
-        eng.run_chain(gen, dt, on_result)
+        try:
+            eng.run_chain(gen, dt, on_result)
+        finally:
+            if hasattr(gen, "release"):
+                gen.release()
         return stat["acc"], stat["traj"]
 
     if warmup > 0:

@@ -76,6 +76,13 @@ PROTOTYPES = {
     "gh_shard_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
     "gh_shard_init_callback": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
     "gh_shard_allreduce": (C.c_int, [_ctx, _dp, _i64]),
+    "gh_rng_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
+    "gh_rng_destroy": (None, [C.c_void_p]),
+    "gh_rng_set_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_double]),
+    "gh_rng_get_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_double)]),
+    "gh_rng_draw_trajectories": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _i64, C.c_double,
+                                           C.POINTER(C.c_int), _dp, _dp]),
     "gh_format_row_fixed8": (C.c_int64, [_dp, _i64, C.c_char_p, _i64]),
     "gh_measure_stream_read": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gh_profile_enable": (C.c_int, [_ctx, C.c_int]),

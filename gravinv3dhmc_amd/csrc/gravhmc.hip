@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 using namespace ghk;
@@ -1764,6 +1765,8 @@ int64_t gh_format_row_fixed8(const double *v, int64_t n, char *out, int64_t cap)
     }
     return pos;
 }
+
+#include "host_rng.h"
 
 int gh_profile_enable(gh_ctx *c, int enable)
 {

@@ -245,11 +245,16 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
         def chain_get_x(self):
             return self._full(Engine.chain_get_x(self))
 
-        def _loc_vec(self, v):
-            return self._loc(v)
-
         def _full_vec(self, v):
             return self._full(v)
+
+        def _loc_rows(self, p0s):
+            p0s = np.asarray(p0s, dtype=np.float64)
+            if p0s.shape[1] == self.M_local and self.M_local != self.M_global:
+                return np.ascontiguousarray(p0s)
+            if p0s.shape[1] != self.M_global:
+                raise ValueError("expected momenta of %d entries" % self.M_global)
+            return np.ascontiguousarray(p0s[:, self.m0:self.m1])
 
         def run_chain(self, draws, dt, on_result, **kw):
             # Host-staged (gloo) all-reduce: the library's per-step callback and the all_gather of

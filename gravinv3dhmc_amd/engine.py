@@ -248,24 +248,28 @@ class Engine(object):
                 "resident_launches": la.value, "resident_evaluations": ev.value,
                 "team_members": q.value, "team_launches": tl.value, "team_timeouts": to.value}
 
-    def _prepare_batch(self, batch, lookahead, want_x):
-        """Arguments of one gh_chain_run call over a list of (L, p0, u), marshalled on the calling
-        thread (the 4 MB per momentum of C2 are copied here, not between two batches on the GPU)."""
-        K = len(batch)
-        p0s = np.ascontiguousarray(np.stack([self._vecM(self._loc_vec(b[1]), "p0") for b in batch]))
-        return {"K": K, "Ls": (C.c_int * K)(*[int(b[0]) for b in batch]), "p0s": p0s,
-                "us": np.ascontiguousarray([float(b[2]) for b in batch], dtype=np.float64),
-                "look": self._vecM(self._loc_vec(lookahead[1]), "p0") if lookahead is not None else None,
+    def _prepare_batch(self, blk, look, want_x):
+        """Arguments of one gh_chain_run call over a block (Ls, p0s[K, M], us) of trajectories,
+        marshalled on the calling thread (the 4 MB per momentum of C2 are copied here, not between
+        two batches on the GPU).  `look`: the block whose first row is the next trajectory."""
+        Ls, p0s, us = blk
+        K = len(Ls)
+        p0s = self._loc_rows(p0s)
+        if p0s.shape != (K, self.M):
+            raise ValueError("p0 must have M = %d entries, got shape %r" % (self.M, p0s.shape[1:]))
+        return {"K": K, "Ls": np.ascontiguousarray(Ls, dtype=np.int32), "p0s": p0s,
+                "us": np.ascontiguousarray(us, dtype=np.float64),
+                "look": self._loc_rows(look[1][:1])[0] if look is not None else None,
                 "acc": (C.c_int * K)(), "out5": np.empty((K, 5)),
                 "xs": np.empty((K, self.M)) if want_x else None, "n_run": C.c_int(0)}
 
-    def _run_batch(self, batch, lookahead, dt, stop_at, record_from, want_x, prepared=None, entered=None):
-        """One gh_chain_run call over a list of (L, p0, u); returns per-trajectory results.
+    def _run_batch(self, a, dt, stop_at, record_from, want_x, entered=None):
+        """One gh_chain_run call over a prepared block; returns per-trajectory results.
         `entered` (threading.Event) is set right before the library call (which releases the GIL)."""
-        a = prepared if prepared is not None else self._prepare_batch(batch, lookahead, want_x)
         if entered is not None:
             entered.set()
-        self._chk(self._lib.gh_chain_run(self._h, a["K"], a["Ls"], ptr(a["p0s"]), ptr(a["us"]), float(dt),
+        self._chk(self._lib.gh_chain_run(self._h, a["K"], a["Ls"].ctypes.data_as(C.POINTER(C.c_int)),
+                                         ptr(a["p0s"]), ptr(a["us"]), float(dt),
                                          ptr(a["look"]), int(stop_at), int(record_from), a["acc"],
                                          ptr(a["out5"]), ptr(a["xs"]), C.byref(a["n_run"])))
         acc, out5, xs = a["acc"], a["out5"], a["xs"]
@@ -279,8 +283,16 @@ class Engine(object):
         GPU (C2: 4, C1: 128)."""
         return int(max(4, min(128, (6 << 20) // (8 * max(1, self.M)))))
 
-    def _loc_vec(self, v):
-        return f64(v)
+    def _vec_any(self, v):
+        """One momentum as a caller hands it over (full length; a sharded engine slices it later)."""
+        v = f64(v)
+        if v.ndim != 1:
+            raise ValueError("p0 must be a vector, got shape %r" % (v.shape,))
+        return v
+
+    def _loc_rows(self, p0s):
+        """This engine's columns of a block of momenta, contiguous float64 [K, M]."""
+        return np.ascontiguousarray(p0s, dtype=np.float64)
 
     def _full_vec(self, v):
         return v
@@ -301,25 +313,43 @@ class Engine(object):
         import threading
         if batch is None:
             batch = self.default_batch()
-        it = iter(draws)
+        if hasattr(draws, "take_block"):
+            # a source that fills blocks itself (inversion.rng.LegacyDraws): rows after the lookahead
+            # are drawn straight into the batch's arrays
+            def take(n, head=None):
+                if head is None:
+                    return draws.take_block(n)
+                out = (np.empty(n, dtype=np.int32), np.empty((n, head[1].shape[1])), np.empty(n))
+                out[0][0], out[1][0], out[2][0] = head[0][0], head[1][0], head[2][0]
+                got = len(draws.take_block(n - 1, out=out, at=1)[0]) if n > 1 else 0
+                return tuple(o[:1 + got] for o in out)
+        else:
+            it = iter(draws)
 
-        def take(n):
-            out = []
-            for _ in range(n):
-                d = next(it, None)
-                if d is None:
-                    break
-                out.append(d)
-            return out
+            def take(n, head=None):
+                rows = []
+                for _ in range(n - (0 if head is None else 1)):
+                    d = next(it, None)
+                    if d is None:
+                        break
+                    rows.append(d)
+                Ls = [int(head[0][0])] if head is not None else []
+                ps = [head[1][0]] if head is not None else []
+                us = [float(head[2][0])] if head is not None else []
+                Ls += [int(d[0]) for d in rows]
+                ps += [self._vec_any(d[1]) for d in rows]
+                us += [float(d[2]) for d in rows]
+                if not Ls:
+                    return (np.empty(0, dtype=np.int32), np.empty((0, 0)), np.empty(0))
+                return (np.asarray(Ls, dtype=np.int32), np.stack(ps), np.asarray(us, dtype=np.float64))
 
-        def start(cur, look, prepared):
+        def start(prepared):
             res = {}
             entered = threading.Event()
 
             def work():
                 try:
-                    res["r"] = self._run_batch(cur, look[0] if look else None, dt, stop_at_accepts,
-                                               record_from, want_x, prepared, entered)
+                    res["r"] = self._run_batch(prepared, dt, stop_at_accepts, record_from, want_x, entered)
                 except BaseException as e:  # re-raised in the caller's thread
                     res["e"] = e
                 finally:
@@ -338,31 +368,36 @@ class Engine(object):
                 raise job[1]["e"]
             return job[1]["r"]
 
+        def some(blk):
+            return blk is not None and len(blk[0]) > 0
+
         # a momentum of >= 1 MB takes milliseconds to draw: the first call then carries ONE trajectory,
         # so the device starts after two draws instead of batch + 1
         cur = take(1 if self.M * 8 >= (1 << 20) else batch)
-        look = take(1) if cur else []
-        job = start(cur, look, self._prepare_batch(cur, look[0] if look else None, want_x)) if cur else None
-        while cur:
+        look = take(1) if some(cur) else None
+        look = look if some(look) else None
+        job = start(self._prepare_batch(cur, look, want_x)) if some(cur) else None
+        while some(cur):
             # the lookahead trajectory opens the next batch; the rest is drawn and marshalled
             # while the GPU runs
-            nxt = (look + take(batch - 1)) if look else []
-            nlook = take(1) if nxt else []
-            nprepared = self._prepare_batch(nxt, nlook[0] if nlook else None, want_x) if nxt else None
+            nxt = take(batch, head=look) if look is not None else None
+            nlook = take(1) if some(nxt) else None
+            nlook = nlook if some(nlook) else None
+            nprepared = self._prepare_batch(nxt, nlook, want_x) if some(nxt) else None
             results = finish(job)
-            short = len(results) < len(cur)           # the library stopped at stop_at_accepts
-            job = start(nxt, nlook, nprepared) if (overlap and nxt and not short) else None
+            short = len(results) < len(cur[0])           # the library stopped at stop_at_accepts
+            job = start(nprepared) if (overlap and some(nxt) and not short) else None
             stop = False
-            for (L, _p0, _u), (acc, o, x) in zip(cur, results):
-                if on_result(L, acc, o, self._full_vec(x) if x is not None else None) is False:
+            for L, (acc, o, x) in zip(cur[0], results):
+                if on_result(int(L), acc, o, self._full_vec(x) if x is not None else None) is False:
                     stop = True
                     break
-            if stop or short or not nxt:
+            if stop or short or not some(nxt):
                 if job is not None:
                     finish(job)
                 break
             if job is None:
-                job = start(nxt, nlook, nprepared)
+                job = start(nprepared)
             cur, look = nxt, nlook
 
     def chain_get_x(self):

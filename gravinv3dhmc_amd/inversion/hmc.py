@@ -18,6 +18,7 @@ import numpy as np
 from scipy.sparse import coo_matrix
 
 from ..utils import write_rows_fixed8
+from .rng import LegacyDraws
 
 
 class HamitonianMC(object):
@@ -198,16 +199,26 @@ class HamitonianMC(object):
             eng.chain_init(x, self.low, self.high)
             n = len(x)
 
-            def draws():
-                while True:
-                    L = np.random.randint(self.Lrange[0], self.Lrange[1] + 1)
-                    p0 = np.random.randn(n) * self.Sigma
-                    yield L, p0, np.random.rand()
-
-            eng.run_chain(draws(), self.dt,
-                          lambda L, acc, o, xs: record(o[0], o[1], o[2], acc, lambda: xs),
-                          stop_at_accepts=ndraws + nsamples, record_from=ndraws,
-                          want_x=self.sample_sink != "none", overlap=True)
+            # the reference's draws per trajectory -- randint, randn(n) * Sigma, rand (hmc.py:297,95,164)
+            # -- continue np.random's stream inside the library (inversion/rng.py: same numbers, the
+            # normals scaled on several threads) and are handed back to np.random afterwards
+            if os.environ.get("GRAVHMC_HOST_RNG", "native") == "numpy":
+                def draws():
+                    while True:
+                        L = np.random.randint(self.Lrange[0], self.Lrange[1] + 1)
+                        p0 = np.random.randn(n) * self.Sigma
+                        yield L, p0, np.random.rand()
+                source = draws()
+            else:
+                source = LegacyDraws(n, self.Lrange, self.Sigma)
+            try:
+                eng.run_chain(source, self.dt,
+                              lambda L, acc, o, xs: record(o[0], o[1], o[2], acc, lambda: xs),
+                              stop_at_accepts=ndraws + nsamples, record_from=ndraws,
+                              want_x=self.sample_sink != "none", overlap=True)
+            finally:
+                if hasattr(source, "release"):
+                    source.release()
             self._chain_x = state["x"]
             return state["x"]
         while state["i"] < ndraws + nsamples:

@@ -297,6 +297,23 @@ int gh_shard_allreduce(gh_ctx *ctx, double *host_buf, int64_t count);
  * for |v| < 1e13) is too small. */
 int64_t gh_format_row_fixed8(const double *v, int64_t n, char *out, int64_t cap);
 
+/* ---- the reference's random stream ------------------------------------------------------ */
+
+/* NumPy's legacy RandomState stream on the host, bit for bit (MT19937; doubles from two outputs;
+ * polar Gaussian with its cached second value; masked-rejection integers): what the reference
+ * draws per trajectory in HamitonianMC.sample / _leapfrog -- L = np.random.randint(Lmin, Lmax + 1)
+ * (hmc.py:297), p0 = np.random.randn(M) * Sigma (hmc.py:95), u = np.random.rand() (hmc.py:164) --
+ * K trajectories per call, written straight into the arrays gh_chain_run takes.  Host only, no
+ * context.  gh_rng_create(seed) is np.random.seed(seed); get / set_state exchange the stream with
+ * np.random.get_state() / set_state() (key[624], pos, has_gauss, cached_gaussian). */
+typedef struct gh_rng gh_rng;
+int gh_rng_create(gh_rng **out, uint32_t seed);
+void gh_rng_destroy(gh_rng *rng);
+int gh_rng_set_state(gh_rng *rng, const uint32_t *key624, int pos, int has_gauss, double cached);
+int gh_rng_get_state(const gh_rng *rng, uint32_t *key624, int *pos, int *has_gauss, double *cached);
+int gh_rng_draw_trajectories(gh_rng *rng, int K, int Lmin, int Lmax, int64_t M, double sigma, int *L,
+                             double *p0s /* K x M */, double *us /* K */);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 
 /* HIP-event timing of the G sweeps (the dominant kernel) on the context's stream.

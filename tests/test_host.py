@@ -183,3 +183,60 @@ def test_bench_helpers_cores_and_labelled_traffic():
     assert abs(b - 4.0e10) < 0.01 * 4.0e10            # one read of the 40 GB matrix, nothing re-read
     assert bench.pmc_traffic("no_such_workload") == (None, None)
     assert bench.FP64_VECTOR_PEAK_TFLOPS == 78.6 and bench.FLOPS_PER_TESS_LEAF == 244
+
+
+@pytest.mark.parametrize("seed,K,Lrange,M,sigma,pre", [
+    (100, 40, (5, 20), 6000, 0.001, 0),       # C1's draws (uniformgrid/SetPMTS.txt)
+    (1, 25, (5, 20), 6001, 0.5, 1),           # odd M and a cached normal on entry: pairs straddle momenta
+    (7, 300, (3, 3), 17, 1.0, 0),             # one possible length: randint draws nothing
+    (123456, 30, (1, 1000), 999, 2.0, 3),     # rejection in randint
+    (2 ** 32 - 1, 3, (0, 1), 70001, 1e-3, 0),  # large enough for the threaded scaling pass
+    (5, 4, (2, 9), 0, 1.0, 1),                # no cells: only randint and rand advance the stream
+])
+def test_native_legacy_stream_is_numpys_bit_for_bit(built_lib, seed, K, Lrange, M, sigma, pre):
+    """gh_rng_draw_trajectories against np.random itself: the reference's draws per trajectory
+    (hmc.py:297 randint, :95 randn(M) * Sigma, :164 rand) and the generator state they leave."""
+    from gravinv3dhmc_amd.inversion.rng import LegacyDraws
+    np.random.seed(seed)
+    for _ in range(pre):
+        np.random.randn()
+    start = np.random.get_state()
+    want = [(np.random.randint(Lrange[0], Lrange[1] + 1), np.random.randn(M) * sigma, np.random.rand())
+            for _ in range(K)]
+    after = np.random.get_state()
+    np.random.set_state(start)
+    src = LegacyDraws(M, Lrange, sigma)
+    # blocks of uneven size, one of them written into rows of a larger array, single draws in between
+    got = []
+    Ls, p0s, us = src.take_block(K // 3)
+    got += list(zip(Ls.tolist(), p0s, us.tolist()))
+    got.append(next(src))
+    n = K - len(got)
+    out = (np.zeros(n + 2, dtype=np.int32), np.zeros((n + 2, M)), np.zeros(n + 2))
+    Ls, p0s, us = src.take_block(n, out=out, at=2)
+    assert p0s.base is out[1] or p0s.base is out[1].base or M == 0
+    got += list(zip(Ls.tolist(), p0s, us.tolist()))
+    assert len(got) == K
+    for (L0, p0, u0), (L1, p1, u1) in zip(want, got):
+        assert L0 == L1 and u0 == u1
+        assert np.array_equal(p0, p1)
+    src.release()
+    now = np.random.get_state()
+    assert np.array_equal(now[1], after[1]) and now[2:] == after[2:]
+
+
+def test_native_legacy_stream_vector_sigma_and_fixed_lengths(built_lib):
+    from gravinv3dhmc_amd.inversion.rng import LegacyDraws
+    M = 33
+    sig = np.linspace(0.5, 2.0, M)
+    np.random.seed(3)
+    want = [(n, np.random.randn(M) * sig, np.random.rand()) for n in (10, 10, 4)]
+    np.random.seed(3)
+    src = LegacyDraws(M, (10, 10), sig, fixed_L=[10, 10, 4])
+    got = list(src)
+    src.release()
+    assert [g[0] for g in got] == [10, 10, 4]
+    for w, g_ in zip(want, got):
+        assert np.array_equal(w[1], g_[1]) and w[2] == g_[2]
+    with pytest.raises(RuntimeError):
+        LegacyDraws(M, (9, 3), 1.0).take_block(1)
