@@ -56,7 +56,8 @@ PROTOTYPES = {
     "gh_chain_prefetch_momentum": (C.c_int, [_ctx, _dp]),
     "gh_chain_stats": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64)]),
     "gh_chain_resident_stats": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64)]),
-    "gh_team_sweep_stats": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "gh_team_sweep_stats": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(C.c_int),
+                                      C.POINTER(_i64)]),
     "gh_chain_run": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), _dp, _dp, C.c_double, _dp, _i64, _i64,
                                C.POINTER(C.c_int), _dp, _dp, C.POINTER(C.c_int)]),
     "gh_chain_get_x": (C.c_int, [_ctx, _dp]),

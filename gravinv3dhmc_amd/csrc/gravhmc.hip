@@ -992,9 +992,10 @@ int gh_chain_stats(gh_ctx *c, int64_t *spec_hits, int64_t *spec_misses)
     return GH_OK;
 }
 
-int gh_team_sweep_stats(gh_ctx *c, int *members, int64_t *launches, int *timeouts)
+int gh_team_sweep_stats(gh_ctx *c, int *members, int64_t *launches, int *timeouts, int64_t *late_parts)
 {
     if (!c) return GH_ERR_ARG;
+    if (late_parts) *late_parts = c->tm.late_polls;
     if (members) *members = c->tm.state != 0 ? c->tm.Q : 0;
     if (launches) *launches = c->tm.launches;
     if (timeouts) *timeouts = c->tm.aborts;

@@ -57,6 +57,7 @@ struct gh_ctx {
         int state = 0;        // 0 not planned, 1 usable, -1 not applicable / given up
         int Q = 0, tpx = 0, grid = 0;
         int threads = 0, ept2 = 0, depth = 0;  // instantiation of teamsweep_kernel
+        int lag = 1;                           // columns between a member's dot and its update
         int64_t panel_rows = 0;                // rows per member
         int64_t cols_per_team = 0;
         size_t lds = 0;
@@ -66,6 +67,7 @@ struct gh_ctx {
         bool inflight = false;  // launched since the abort word was last looked at
         int aborts = 0;
         int64_t launches = 0;
+        unsigned late_polls = 0;
     } tm;
     int slab_live = 0;        // rows of the slab the last forward launch wrote
     // one-launch epilogue (reduce_finish_kernel): sums of the slab rows from the sweep, |r|^2 partials

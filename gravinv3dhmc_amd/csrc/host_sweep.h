@@ -367,9 +367,10 @@ typedef void (*team_fn)(TeamArgs);
 // 17.5 + more variance; 512 x 10 x 5 25.8; 512 x 8 x 5 21.4 -- what a column costs beyond its bytes
 // is the per-column hand-off (two workgroup barriers and one L2 round trip), not the depth of the
 // prefetch, so the shape with the fewest, largest members is kept.
-static team_fn team_kernel_for(int threads, int ept2, int depth)
+static team_fn team_kernel_for(int threads, int ept2, int depth, int lag)
 {
-    if (threads == 1024 && ept2 == 5 && depth == 3) return teamsweep_kernel<1024, 5, 3>;
+    if (threads == 1024 && ept2 == 5 && depth == 3)
+        return lag == 2 ? teamsweep_kernel<1024, 5, 3, true> : teamsweep_kernel<1024, 5, 3, false>;
     return nullptr;
 }
 
@@ -384,7 +385,11 @@ static bool team_plan(gh_ctx *c)
     t.threads = 1024;
     t.ept2 = 5;
     t.depth = 3;
-    const int64_t cap = (int64_t)t.threads * t.ept2 * 2;  // rows a member holds of a column
+    t.lag = env_int("GRAVHMC_TEAM_LAG", 2) == 1 ? 1 : 2;
+    const size_t lds_small = (2 * TS_MAXWAVES + 4) * sizeof(double);
+    int64_t cap = (int64_t)t.threads * t.ept2 * 2;  // rows a member holds of a column
+    // lag 2: the member's part of r and the parked column share the 160 KB of LDS
+    if (t.lag == 2) cap = std::min<int64_t>(cap, (int64_t)((160 * 1024 - lds_small) / (2 * sizeof(double))) / 16 * 16);
     t.Q = (int)((c->ld + cap - 1) / cap);
     if (t.Q < 2) t.Q = 2;
     if (t.Q > TS_MAXQ || c->cus < 8 * t.Q) return false;
@@ -394,8 +399,8 @@ static bool team_plan(gh_ctx *c)
     t.grid = 8 * t.tpx * t.Q;
     const int n_teams = 8 * t.tpx;
     t.cols_per_team = (c->M + n_teams - 1) / n_teams;
-    t.lds = ((size_t)t.panel_rows + 2 * TS_MAXWAVES + TS_RING * 8 + 4) * sizeof(double);
-    team_fn f = team_kernel_for(t.threads, t.ept2, t.depth);
+    t.lds = (size_t)t.panel_rows * (size_t)t.lag * sizeof(double) + lds_small;
+    team_fn f = team_kernel_for(t.threads, t.ept2, t.depth, t.lag);
     if (allow_dynamic_lds(reinterpret_cast<const void *>(f), t.lds) != hipSuccess) {
         (void)hipGetLastError();
         return false;
@@ -439,7 +444,7 @@ static int launch_team(gh_ctx *c, const SweepArgs &full)
     a.abort_w = t.abort_w;
     bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-    hipLaunchKernelGGL(team_kernel_for(t.threads, t.ept2, t.depth), dim3(t.grid), dim3(t.threads), t.lds, c->stream, a);
+    hipLaunchKernelGGL(team_kernel_for(t.threads, t.ept2, t.depth, t.lag), dim3(t.grid), dim3(t.threads), t.lds, c->stream, a);
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_bytes[c->ev_used / 2] = c->N * c->M * (int64_t)sizeof(double);
@@ -465,6 +470,7 @@ static int team_failed(gh_ctx *c, bool *failed)
     unsigned w[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(w, t.abort_w, sizeof w, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    t.late_polls = w[1];  // columns whose parts some member had to wait for (all launches so far)
     if (w[0] == 0u) return GH_OK;
     t.aborts += 1;
     const bool for_good = t.aborts >= 3;

@@ -121,12 +121,18 @@ struct SweepArgs {
 
 using d2 = double __attribute__((ext_vector_type(2)));
 
+// read-only inputs of a launch, read through the scalar cache (uniform address: s_load, counted by
+// lgkmcnt -- the vector-memory counter then counts column requests only)
+typedef const double __attribute__((address_space(4))) *kconst_ptr;
+__device__ __forceinline__ kconst_ptr as_kconst(const double *p)
+{
+    return (kconst_ptr)(unsigned long long)p;
+}
+
 template <int EPT2>
 struct ColRegs {
     d2 v[EPT2];
-    double sc;  // lane l < 6 of the team's first wave: the l-th per-column scalar (x, p, low,
-                // high, greg, pn), prefetched with the column -- ONE load instruction per column
-                // and team instead of one per scalar and wave
+    double sc;  // x_j (uniform), requested with the column
 };
 
 // TW = waves per team (1, 4, 8, 16).  TW == 1: four independent wave-teams per 256-thread block.
@@ -184,27 +190,35 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
     for (int k = 0; k < EPT2; ++k) dacc[k] = d2{0.0, 0.0};
     double pp = 0.0;
 
+    // Requests of one column.  They must stay in flight ACROSS the processing of the columns before:
+    // the compiler counts outstanding vector loads per path and waits for the fewest any path may
+    // have issued -- s_waitcnt vmcnt(0), the end of all prefetching, as soon as a younger load is
+    // conditional.  So
+    //   * the column is loaded unconditionally, threads past its end re-read its last double2 (never
+    //     used: the dot and every store are guarded), at 32-bit offsets from a uniform base;
+    //   * the per-column scalars come through the scalar cache (every wave loads them itself, x_j
+    //     with the column, the others while the dot is reduced: no vector load, no LDS broadcast,
+    //     no wave with a longer path than the others).
+    unsigned coff[EPT2];
+#pragma unroll
+    for (int k = 0; k < EPT2; ++k) {
+        const int e = k * TEAM_THREADS + ttid;
+        coff[k] = (unsigned)(e < ld2 ? e : (ld2 > 0 ? ld2 - 1 : 0)) * (unsigned)sizeof(d2);
+    }
+    const kconst_ptr kx = as_kconst(a.x_in), kp = as_kconst(a.p_in), klo = as_kconst(a.low), khi = as_kconst(a.high),
+                     kgr = as_kconst(a.greg), kpn = as_kconst(a.pn_in);
     auto load_col = [&](ColRegs<EPT2> &c, int64_t j) {
-        const d2 *col = reinterpret_cast<const d2 *>(a.G + j * ld + a.row0);
+        c.sc = kx ? kx[j] : 0.0;
+        const char *col = reinterpret_cast<const char *>(a.G + j * ld + a.row0);
 #pragma unroll
         for (int k = 0; k < EPT2; ++k) {
-            const int e = k * TEAM_THREADS + ttid;
-            if (e < ld2)
-                c.v[k] = NT ? __builtin_nontemporal_load(col + e) : col[e];
-            else
-                c.v[k] = d2{0.0, 0.0};
+            // (kept 32-bit next to the uniform base -- global_load v, voff, s[base] -- and in its own
+            // register: as a copy it lands in the destination registers and waits for their last load)
+            asm volatile("" : "+v"(coff[k]));
+            const unsigned o = coff[k];
+            const d2 *src = reinterpret_cast<const d2 *>(col + o);
+            c.v[k] = NT ? __builtin_nontemporal_load(src) : *src;
         }
-        double sc = 0.0;
-        if (mode & SW_ADJ) {
-            if ((TW == 1 || wave == 0) && lane < 6) {
-                const double *src = lane == 0 ? a.x_in : lane == 1 ? a.p_in : lane == 2 ? a.low
-                                  : lane == 3 ? a.high : lane == 4 ? a.greg : a.pn_in;
-                if (src) sc = src[j];
-            }
-        } else if (mode & SW_FWD) {
-            sc = a.x_in[j];  // forward-only sweep: no reduction to piggy-back on
-        }
-        c.sc = sc;
     };
 
     // one column: adjoint dot, leapfrog update, forward accumulation.  `it` = j - j0.
@@ -226,29 +240,17 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
             // trips through the LDS crossbar: the per-column chain dot -> slot -> barrier -> update is
             // what a team's columns are serialised on)
             s = (TW > 1) ? wave_sum_dpp(s) : wave_allreduce_sum(s);
-            double cx, cp, clo, chi, cgr, cpn;
+            const double cx = cur.sc;
+            const double cp = kp ? kp[j] : 0.0, clo = klo ? klo[j] : 0.0, chi = khi ? khi[j] : 0.0,
+                         cgr = kgr ? kgr[j] : 0.0, cpn = kpn ? kpn[j] : 0.0;
             if (TW > 1) {
                 double *slot = scratch + (it & 1) * SLOT;
                 if (lane == 0) slot[wave] = s;
-                if (wave == 0 && lane < 6) slot[TW + lane] = cur.sc;
                 __syncthreads();
                 double t = 0.0;
 #pragma unroll
                 for (int w = 0; w < TW; ++w) t += slot[w];
                 s = t;
-                cx = slot[TW + 0];
-                cp = slot[TW + 1];
-                clo = slot[TW + 2];
-                chi = slot[TW + 3];
-                cgr = slot[TW + 4];
-                cpn = slot[TW + 5];
-            } else {
-                cx = __shfl(cur.sc, 0, WAVE);
-                cp = __shfl(cur.sc, 1, WAVE);
-                clo = __shfl(cur.sc, 2, WAVE);
-                chi = __shfl(cur.sc, 3, WAVE);
-                cgr = __shfl(cur.sc, 4, WAVE);
-                cpn = __shfl(cur.sc, 5, WAVE);
             }
             xj = cx;
             const double g = 2.0 * s + cgr;
@@ -284,34 +286,41 @@ __global__ void __launch_bounds__((TW == 1 ? 4 : TW) * 64) sweep_kernel(SweepArg
         }
     };
 
-    // TW > 1: one team per block, so every wave takes the same trip count (barrier inside)
-    if (PF == 1) {
-        ColRegs<EPT2> b0, b1;
-        if (cnt > 0) load_col(b0, colj(0));
-        int i = 0;
-        while (i < cnt) {
-            if (i + 1 < cnt) load_col(b1, colj(i + 1));
-            process(b0, colj(i), i);
-            if (++i >= cnt) break;
-            if (i + 1 < cnt) load_col(b0, colj(i + 1));
-            process(b1, colj(i), i);
-            ++i;
-        }
-    } else {
-        ColRegs<EPT2> b0, b1, b2;
-        if (cnt > 0) load_col(b0, colj(0));
-        if (cnt > 1) load_col(b1, colj(1));
-        int i = 0;
-        while (i < cnt) {
-            if (i + 2 < cnt) load_col(b2, colj(i + 2));
-            process(b0, colj(i), i);
-            if (++i >= cnt) break;
-            if (i + 2 < cnt) load_col(b0, colj(i + 2));
-            process(b1, colj(i), i);
-            if (++i >= cnt) break;
-            if (i + 2 < cnt) load_col(b1, colj(i + 2));
-            process(b2, colj(i), i);
-            ++i;
+    // TW > 1: one team per block, so every wave takes the same trip count (barrier inside).
+    // Every trip requests a column -- past the end the last one again (a few L2 hits per team): a
+    // request under a condition, even a uniform one, would again turn the waits for the columns in
+    // flight into vmcnt(0).
+    const int lastc = cnt - 1;
+    auto ahead = [&](int i) -> int64_t { return colj(i < lastc ? i : lastc); };
+    if (cnt > 0) {
+        if (PF == 1) {
+            ColRegs<EPT2> b0, b1;
+            load_col(b0, colj(0));
+            int i = 0;
+            for (;;) {
+                load_col(b1, ahead(i + 1));
+                process(b0, colj(i), i);
+                if (++i >= cnt) break;
+                load_col(b0, ahead(i + 1));
+                process(b1, colj(i), i);
+                if (++i >= cnt) break;
+            }
+        } else {
+            ColRegs<EPT2> b0, b1, b2;
+            load_col(b0, colj(0));
+            load_col(b1, ahead(1));
+            int i = 0;
+            for (;;) {
+                load_col(b2, ahead(i + 2));
+                process(b0, colj(i), i);
+                if (++i >= cnt) break;
+                load_col(b0, ahead(i + 2));
+                process(b1, colj(i), i);
+                if (++i >= cnt) break;
+                load_col(b1, ahead(i + 2));
+                process(b2, colj(i), i);
+                if (++i >= cnt) break;
+            }
         }
     }
 

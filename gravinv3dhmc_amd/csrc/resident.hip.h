@@ -152,12 +152,25 @@ __device__ __forceinline__ void st_gran_l2(u64 *g, unsigned tag, double v)
     __hip_atomic_store(g + 1, ((u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ bool ld_gran(u64 *g, unsigned tag, double &v)
+// the two halves of ld_gran: the loads (issue early), and what they brought (look late -- the wait
+// for the loads sits where the words are first used)
+__device__ __forceinline__ void ld_gran_issue(u64 *g, u64 &a, u64 &b)
 {
-    const u64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool gran_value(u64 a, u64 b, unsigned tag, double &v)
+{
     v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
     return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+}
+
+__device__ __forceinline__ bool ld_gran(u64 *g, unsigned tag, double &v)
+{
+    u64 a, b;
+    ld_gran_issue(g, a, b);
+    return gran_value(a, b, tag, v);
 }
 
 // Every lane of the wave re-reads its granules (try_load: true when all of them carry the tag)

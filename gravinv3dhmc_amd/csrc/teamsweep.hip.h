@@ -25,8 +25,15 @@
 //     issued after the dot it would come back behind column i+1 -- a full column later -- and the
 //     team would stream one column at a time (measured 5.2 TB/s; a scalar poll, which is not ordered
 //     with the vector loads but pays its L2 round trip inside the hand-off, 5.3 TB/s).
-// A ring of four granule slots per member suffices (no member is ever more than two columns ahead
-// of another of its team).  Members of a team are blocks with equal blockIdx % 8, i.e. on one XCD
+// One column of lag leaves the parts about half a column (~1.7 us) to arrive before the early poll
+// is served: measured at the C5 share, 17 % of the polls came too early, and each of those pays a
+// second poll that returns behind the column requested meanwhile.  TS_LAG2 therefore finishes column
+// i-2 in iteration i: the column dotted one iteration ago stays in its registers, the one before it
+// waits in LDS (every thread parks and fetches its own elements: no hazard between threads, 2 x 80 KB
+// of LDS traffic per column beside the HBM stream), at the same three register buffers.
+// A ring of eight granule slots per member suffices (a member at column k has the parts of column
+// k-2 of everybody: no member is more than two columns ahead of another, and the slowest still reads
+// column k-4).  Members of a team are blocks with equal blockIdx % 8, i.e. on one XCD
 // under the round-robin dispatch (their exchange then stays in that L2), but nothing depends on it.
 // Every wait is bounded (2 s): on a time-out the abort word is raised, every workgroup leaves, later
 // launches of the stream return at once and the host repeats the work in row panels
@@ -36,7 +43,7 @@
 namespace ghk {
 
 constexpr int TS_MAXQ = 8;
-constexpr int TS_RING = 4;
+constexpr int TS_RING = 8;
 constexpr int TS_MAXWAVES = 16;
 
 struct TeamArgs {
@@ -53,10 +60,12 @@ struct TeamArgs {
 };
 
 // TS_THREADS threads per workgroup, TS_EPT2 double2 per thread and column (rows per member <=
-// TS_THREADS * TS_EPT2 * 2), TS_D column buffers (>= 3): finishing | dotted | TS_D - 2 in flight.
-template <int TS_THREADS, int TS_EPT2, int TS_D>
+// TS_THREADS * TS_EPT2 * 2), TS_D column buffers in registers (>= 3): finishing | dotted | TS_D - 2 in
+// flight; TS_LAG2 (TS_D = 3): waiting | dotted | in flight, and one more waiting column in LDS.
+template <int TS_THREADS, int TS_EPT2, int TS_D, bool TS_LAG2>
 __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
 {
+    static_assert(!TS_LAG2 || TS_D == 3, "the two-column lag rotates three register buffers");
     constexpr int TS_WAVES = TS_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SweepArgs &s = a.s;
@@ -68,11 +77,11 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
     const int64_t row0 = (int64_t)q * a.panel_rows;
     const int64_t rows = (row0 + a.panel_rows <= ld) ? a.panel_rows : (ld > row0 ? ld - row0 : 0);
     const int ld2 = (int)(rows >> 1);
-    // LDS: r of the member's rows | dot partials, 2 x 16 | per-column scalars, ring of 4 x 8 | total, flag
+    // LDS: r of the member's rows | (TS_LAG2: the parked column) | dot partials, 2 x 16 | total, flag
     double *r_s = smem;
-    double *part = smem + a.panel_rows;
-    double *scal = part + 2 * TS_MAXWAVES;
-    double *tot_s = scal + TS_RING * 8;
+    d2 *park2 = reinterpret_cast<d2 *>(smem + a.panel_rows);
+    double *part = smem + (TS_LAG2 ? 2 : 1) * a.panel_rows;
+    double *tot_s = part + 2 * TS_MAXWAVES;
     int *abort_s = reinterpret_cast<int *>(tot_s + 2);
 
     if (tid == 0) *abort_s = (__hip_atomic_load(a.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
@@ -95,21 +104,28 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
     for (int k = 0; k < TS_EPT2; ++k) dacc[k] = d2{0.0, 0.0};
     double pp = 0.0;
 
+    // (unconditional column loads at 32-bit offsets, the scalars through the scalar cache: see
+    // sweep_kernel -- a conditional vector load anywhere behind a column request turns every wait for
+    // that column into vmcnt(0), and nothing is prefetched any more)
+    unsigned coff[TS_EPT2];
+#pragma unroll
+    for (int k = 0; k < TS_EPT2; ++k) {
+        const int e = k * TS_THREADS + tid;
+        coff[k] = (unsigned)(e < ld2 ? e : (ld2 > 0 ? ld2 - 1 : 0)) * (unsigned)sizeof(d2);
+    }
+    const int64_t row0c = rows > 0 ? row0 : 0;
+    const kconst_ptr kx = as_kconst(s.x_in), kp = as_kconst(s.p_in), klo = as_kconst(s.low), khi = as_kconst(s.high),
+                     kgr = as_kconst(s.greg), kpn = as_kconst(s.pn_in);
     auto load_col = [&](ColRegs<TS_EPT2> &c, int i) {
-        const int64_t j = jb + i;
-        const d2 *col = reinterpret_cast<const d2 *>(s.G + j * ld + row0);
+        const char *col = reinterpret_cast<const char *>(s.G + (jb + i) * ld + row0c);
 #pragma unroll
         for (int k = 0; k < TS_EPT2; ++k) {
-            const int e = k * TS_THREADS + tid;
-            c.v[k] = (e < ld2) ? __builtin_nontemporal_load(col + e) : d2{0.0, 0.0};
+            // (kept 32-bit next to the uniform base -- global_load v, voff, s[base] -- and in its own
+            // register: as a copy it lands in the destination registers and waits for their last load)
+            asm volatile("" : "+v"(coff[k]));
+            const unsigned o = coff[k];
+            c.v[k] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(col + o));
         }
-        double sc = 0.0;
-        if (wave == 0 && lane < 6) {
-            const double *src = lane == 0 ? s.x_in : lane == 1 ? s.p_in : lane == 2 ? s.low
-                              : lane == 3 ? s.high : lane == 4 ? s.greg : s.pn_in;
-            if (src) sc = src[j];
-        }
-        c.sc = sc;
     };
 
     // the member's granule pair of column i (ring slot i & 3; the Q pairs of a slot are contiguous)
@@ -132,7 +148,6 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
         sd = wave_sum_dpp(sd);  // on the VALU: the hand-off chain of a column starts here
         double *slot = part + (i & 1) * TS_MAXWAVES;
         if (lane == 0) slot[wave] = sd;
-        if (wave == 0 && lane < 6) scal[(i & (TS_RING - 1)) * 8 + lane] = cur.sc;
         __syncthreads();
         if (wave == 0) {
             // the waves' partials: one LDS read per lane, a row scan, lane 15 publishes
@@ -141,22 +156,37 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
         }
     };
 
-    // issue the poll for column i (wave 0, lane = member): value and "tag matched" come back with the
-    // loads already in flight
-    auto poll_issue = [&](int i, double &pv, bool &pok) {
-        pok = true;
-        if (wave == 0 && lane < a.poll_q) pok = ld_gran(gran_of(lane, i), a.tag0 + (unsigned)i + 1u, pv);
+    // issue the poll for column i (wave 0, lane = member): the two words come back with the loads
+    // already in flight; they are looked at in stage_finish (looking at them here would hold the
+    // wave's column request back until they have arrived)
+    unsigned poff = (unsigned)lane * (unsigned)(2 * sizeof(u64));  // the lane's member in a ring slot
+    auto poll_issue = [&](int i, u64 &pa, u64 &pb) {
+        pa = pb = 0;
+        if (wave == 0 && lane < a.poll_q) {
+            // (uniform base + the lane's offset from its own register: an address built in a scratch
+            // register lands in a column buffer's registers and waits for that buffer's loads)
+            asm volatile("" : "+v"(poff));
+            u64 *g = reinterpret_cast<u64 *>(reinterpret_cast<char *>(gran_of(0, i)) + poff);
+            ld_gran_issue(g, pa, pb);
+        }
         __builtin_amdgcn_sched_barrier(0);  // in front of the column request that follows
     };
 
     // C(i): the Q parts of column i in member order -> gradient, leapfrog update, forward axpy.
-    // pv / pok: what the early poll brought.  false: a wait timed out (or another workgroup gave
+    // pa / pb: what the early poll brought.  false: a wait timed out (or another workgroup gave
     // up): leave.
-    auto stage_finish = [&](const ColRegs<TS_EPT2> &cur, int i, double pv, bool pok) -> bool {
+    auto stage_finish = [&](const ColRegs<TS_EPT2> &cur, int i, u64 pa, u64 pb, bool parked) -> bool {
+        // the column's scalars, through the scalar cache (every wave its own; back by the barrier below)
+        const int64_t j = jb + i;
+        const double cx = kx ? kx[j] : 0.0, cp = kp ? kp[j] : 0.0, clo = klo ? klo[j] : 0.0, chi = khi ? khi[j] : 0.0,
+                     cgr = kgr ? kgr[j] : 0.0, cpn = kpn ? kpn[j] : 0.0;
         if (wave == 0) {
             bool ok = true;
+            double pv = 0.0;
+            const bool pok = lane >= a.poll_q || gran_value(pa, pb, a.tag0 + (unsigned)i + 1u, pv);
             if (!__all(pok)) {
-                // (rare: a member lags by more than a column) poll until every part is there
+                // (a member lags by more than the early poll allows for) poll until every part is there
+                if (lane == 0) __hip_atomic_fetch_add(a.abort_w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = res_poll(a.abort_w, [&]() {
                     return lane >= a.poll_q || ld_gran(gran_of(lane, i), a.tag0 + (unsigned)i + 1u, pv);
                 });
@@ -170,9 +200,6 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
         }
         __syncthreads();
         if (*abort_s) return false;
-        const int64_t j = jb + i;
-        const double *sc = scal + (i & (TS_RING - 1)) * 8;
-        const double cx = sc[0], cp = sc[1], clo = sc[2], chi = sc[3], cgr = sc[4], cpn = sc[5];
         const double g = 2.0 * tot_s[0] + cgr;
         const bool writer = (q == 0 && tid == 0);
         double xj = cx;
@@ -199,47 +226,78 @@ __global__ void __launch_bounds__(TS_THREADS) teamsweep_kernel(TeamArgs a)
             }
         }
         if (mode & SW_FWD) {
+            if (TS_LAG2 && parked) {
+                // the column comes out of the thread's own LDS slots
 #pragma unroll
-            for (int k = 0; k < TS_EPT2; ++k) {
-                dacc[k].x += cur.v[k].x * xj;
-                dacc[k].y += cur.v[k].y * xj;
+                for (int k = 0; k < TS_EPT2; ++k) {
+                    const int e = k * TS_THREADS + tid;
+                    if (e < ld2) {
+                        const d2 v = park2[e];
+                        dacc[k].x += v.x * xj;
+                        dacc[k].y += v.y * xj;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < TS_EPT2; ++k) {
+                    dacc[k].x += cur.v[k].x * xj;
+                    dacc[k].y += cur.v[k].y * xj;
+                }
             }
         }
         return true;
     };
 
+    // the thread's elements of a column into its LDS slots (after it fetched the previous one's)
+    auto park = [&](const ColRegs<TS_EPT2> &c) {
+#pragma unroll
+        for (int k = 0; k < TS_EPT2; ++k) {
+            const int e = k * TS_THREADS + tid;
+            if (e < ld2) park2[e] = c.v[k];
+        }
+    };
+
     // TS_D column buffers rotate: finishing (i-1) | dotted (i) | in flight (i+1 .. i+TS_D-2).
-    // Iteration i: issue the poll for column i-1, request column i+TS_D-2 into the registers column
-    // i-2 left in the last iteration, dot and publish column i, finish column i-1.
+    // Iteration i: issue the poll for column i-LAG, request column i+TS_D-2 into the registers freed
+    // in the last iteration, dot and publish column i, finish column i-LAG (TS_LAG2: from LDS, and
+    // column i-1 takes its place there).
+    constexpr int LAG = TS_LAG2 ? 2 : 1;
     ColRegs<TS_EPT2> B[TS_D];
     bool ok = true;
+    // (every iteration requests a column -- past the end the last one again: a request under a
+    // condition would turn the waits for the columns in flight into vmcnt(0))
+    const int lastc = cnt - 1;
 #pragma unroll
     for (int c0 = 0; c0 < TS_D - 2; ++c0)
-        if (c0 < cnt) load_col(B[c0], c0);
+        if (cnt > 0) load_col(B[c0], c0 < lastc ? c0 : lastc);
     int i = 0;
     while (ok && i < cnt) {
 #pragma unroll
         for (int r = 0; r < TS_D; ++r) {  // r == i % TS_D: every buffer index below is a constant
             if (i >= cnt) break;
-            double pv = 0.0;
-            bool pok = true;
-            if (i > 0) poll_issue(i - 1, pv, pok);
-            if (i + TS_D - 2 < cnt) load_col(B[(r + TS_D - 2) % TS_D], i + TS_D - 2);
+            u64 pa = 0, pb = 0;
+            if (i >= LAG) poll_issue(i - LAG, pa, pb);
+            load_col(B[(r + TS_D - 2) % TS_D], i + TS_D - 2 < lastc ? i + TS_D - 2 : lastc);
             stage_dot(B[r], i);
-            if (i > 0) {
-                if (!(ok = stage_finish(B[(r + TS_D - 1) % TS_D], i - 1, pv, pok))) break;
+            if (i >= LAG) {
+                if (!(ok = stage_finish(B[(r + TS_D - 1) % TS_D], i - LAG, pa, pb, TS_LAG2))) break;
             }
+            if (TS_LAG2 && i >= 1) park(B[(r + TS_D - 1) % TS_D]);
             ++i;
         }
     }
+    if (ok && TS_LAG2 && cnt > 1) {
+        u64 pa = 0, pb = 0;
+        poll_issue(cnt - 2, pa, pb);
+        ok = stage_finish(B[0], cnt - 2, pa, pb, true);
+    }
     if (ok && cnt > 0) {
         const int last = cnt - 1;
-        double pv = 0.0;
-        bool pok = true;
-        poll_issue(last, pv, pok);
+        u64 pa = 0, pb = 0;
+        poll_issue(last, pa, pb);
 #pragma unroll
         for (int r = 0; r < TS_D; ++r)
-            if (last % TS_D == r) ok = stage_finish(B[r], last, pv, pok);
+            if (last % TS_D == r) ok = stage_finish(B[r], last, pa, pb, false);
     }
     if (!ok) return;
 

@@ -242,11 +242,12 @@ class Engine(object):
         self._chk(self._lib.gh_chain_stats(self._h, C.byref(a), C.byref(b)))
         la, ev = C.c_int64(0), C.c_int64(0)
         self._chk(self._lib.gh_chain_resident_stats(self._h, C.byref(la), C.byref(ev)))
-        q, tl, to = C.c_int(0), C.c_int64(0), C.c_int(0)
-        self._chk(self._lib.gh_team_sweep_stats(self._h, C.byref(q), C.byref(tl), C.byref(to)))
+        q, tl, to, late = C.c_int(0), C.c_int64(0), C.c_int(0), C.c_int64(0)
+        self._chk(self._lib.gh_team_sweep_stats(self._h, C.byref(q), C.byref(tl), C.byref(to), C.byref(late)))
         return {"spec_hits": a.value, "spec_misses": b.value,
                 "resident_launches": la.value, "resident_evaluations": ev.value,
-                "team_members": q.value, "team_launches": tl.value, "team_timeouts": to.value}
+                "team_members": q.value, "team_launches": tl.value, "team_timeouts": to.value,
+                "team_late_parts": late.value}
 
     def _prepare_batch(self, blk, look, want_x):
         """Arguments of one gh_chain_run call over a block (Ls, p0s[K, M], us) of trajectories,

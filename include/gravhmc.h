@@ -197,8 +197,10 @@ int gh_chain_resident_stats(gh_ctx *ctx, int64_t *launches, int64_t *evaluations
  * step runs on teams of `members` workgroups that share each column (csrc/teamsweep.hip.h), still
  * ONE read of G per step; adjoint-only / forward-only sweeps and the steps after a team timed out
  * run in row panels.  members: workgroups per team (0: not in use), launches: team sweeps so far,
- * timeouts: launches that gave up (after three the context stays on row panels). */
-int gh_team_sweep_stats(gh_ctx *ctx, int *members, int64_t *launches, int *timeouts);
+ * timeouts: launches that gave up (after three the context stays on row panels), late_parts:
+ * columns for which some member found its team's parts not yet published when it needed them
+ * and had to wait (as of the last synchronisation; columns x members x launches is the total). */
+int gh_team_sweep_stats(gh_ctx *ctx, int *members, int64_t *launches, int *timeouts, int64_t *late_parts);
 int gh_chain_get_x(gh_ctx *ctx, double *x /* M */);
 int gh_chain_get_dsyn(gh_ctx *ctx, double *dsyn /* N, dpre of the current state */);
 /* ---- several chains sharing every sweep of G (fp64 MFMA) ---------------------------------- */

@@ -1847,9 +1847,11 @@ def test_resident_chain_kernel_streams_columns_that_do_not_fit(G, monkeypatch, c
     assert relmax(ax, bx) < 1e-11 and relmax(ad, bd) < 1e-11
 
 
-@pytest.mark.parametrize("N,M", [(16400, 7), (20481, 50), (40960, 301)])
-def test_team_sweep_odd_shapes_match_row_panels(G, monkeypatch, N, M):
-    """Teams of 2, 3 and 4 workgroups per column, fewer columns than teams (idle teams), a column
+@pytest.mark.parametrize("N,M,lag", [(16400, 7, 2), (20481, 50, 2), (40700, 301, 2), (40960, 90, 2), (40960, 301, 1),
+                                     (20481, 1, 2), (16400, 2, 2), (16400, 3, 1)])
+def test_team_sweep_odd_shapes_match_row_panels(G, monkeypatch, N, M, lag):
+    """Teams of 2, 3, 4 and 5 workgroups per column, fewer columns than teams (idle teams; one, two
+    and three columns in all: the pipeline's prologue and epilogue alone), a column
     count that does not divide: the chain on teams against the chain in row panels (1e-12), with the
     speculative first steps and a clamping bound in play."""
     rng = np.random.default_rng(N + M)
@@ -1857,6 +1859,7 @@ def test_team_sweep_odd_shapes_match_row_panels(G, monkeypatch, N, M):
     dobs = rng.normal(size=N) * 3
     trajs = [(int(rng.integers(1, 6)), rng.normal(size=M) * 0.02, float(rng.uniform())) for _ in range(6)]
     res = {}
+    monkeypatch.setenv("GRAVHMC_TEAM_LAG", str(lag))
     for team in ("1", "0"):
         monkeypatch.setenv("GRAVHMC_TEAM", team)
         eng = G.Engine(N, M)
@@ -1870,7 +1873,12 @@ def test_team_sweep_odd_shapes_match_row_panels(G, monkeypatch, N, M):
         st = eng.chain_stats()
         assert (st["team_launches"] > 0) == (team == "1") and st["team_timeouts"] == 0
         if team == "1":
-            assert st["team_members"] == (N + 15) // 16 * 16 // 10240 + (1 if (N + 15) // 16 * 16 % 10240 else 0)
+            # rows a member holds: with a lag of two columns its part of r and the parked column share
+            # the 160 KB of LDS
+            cap = 10240 if lag == 1 else 10208
+            assert st["team_members"] == -(-((N + 15) // 16 * 16) // cap)
+            assert (N, lag, st["team_members"]) in ((16400, 2, 2), (16400, 1, 2), (20481, 2, 3), (40700, 2, 4),
+                                                     (40960, 2, 5), (40960, 1, 4))
         res[team] = (out, eng.chain_get_x())
         eng.close()
     for (a1, o1, x1), (a0, o0, x0) in zip(res["1"][0], res["0"][0]):
