@@ -1814,24 +1814,26 @@ int gh_profile_read(gh_ctx *c, double *sweep_ms, int64_t *sweep_launches, int64_
     if (!c) return GH_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    double ms = c->prof_ms_acc;
+    // The timed launches of the DOMINANT kind only -- those that read the most bytes of G: the
+    // one-read sweeps (one workgroup or a team per column, the whole matrix each) where the path has
+    // them next to row-panel launches (a panel each), so that time and bytes per launch are those of
+    // one kernel and agree with a kernel trace.  (An evaluation inside the resident chain kernel
+    // counts as one sweep of the whole matrix.)
+    const int64_t full = c->N * c->M * (int64_t)sizeof(double);
+    int64_t maxb = c->prof_res_evals > 0 ? full : 0;
+    for (size_t i = 0; i < c->ev_used / 2; ++i) maxb = std::max(maxb, c->ev_bytes[i]);
+    double ms = (c->prof_res_evals > 0 && maxb == full) ? c->prof_ms_acc : 0.0;
+    int64_t timed = (c->prof_res_evals > 0 && maxb == full) ? c->prof_res_evals : 0;
     for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        if (c->ev_bytes[i / 2] != maxb) continue;
         float t = 0.f;
         HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
         ms += t;
+        timed += 1;
     }
-    // launches beyond the event pool are counted but not timed: scale to the timed share
-    // (an evaluation inside the resident chain kernel counts as one sweep)
-    const int64_t timed = (int64_t)(c->ev_used / 2) + c->prof_res_evals;
     if (sweep_ms) *sweep_ms = ms;
     if (sweep_launches) *sweep_launches = timed;
-    // bytes of G an average timed launch read: the whole matrix for the one-read sweeps (one
-    // workgroup or a team per column), one row panel for the launches of the row-panel path
-    if (bytes_per_sweep) {
-        int64_t tot = c->prof_res_evals * c->N * c->M * (int64_t)sizeof(double);
-        for (size_t i = 0; i < c->ev_used / 2; ++i) tot += c->ev_bytes[i];
-        *bytes_per_sweep = timed > 0 ? tot / timed : c->N * c->M * (int64_t)sizeof(double);
-    }
+    if (bytes_per_sweep) *bytes_per_sweep = timed > 0 ? maxb : full;
     return GH_OK;
 }
 

@@ -13,24 +13,29 @@
 //
 // The exchange is the resident chain kernel's (resident.hip.h): the data is the flag -- a double
 // travels as two 8-byte granules {tag, 32 bits}, each written by one write-through store and read
-// with sc1 loads; no counters, no fences; correct under any placement of the workgroups.  Two
-// things keep it off the critical path:
-//   * a lag of one column: a member publishes its part of column i and only then finishes column
-//     i-1 -- whose parts were published a whole column (~3 us of HBM streaming) earlier -- from the
-//     registers it kept it in meanwhile (three column buffers rotate: finishing | dotted | in
-//     flight);
-//   * the poll for column i-1 is ISSUED at the start of iteration i, in front of the request for
-//     column i+1, and looked at only after the dot of column i.  A wave's vector loads return in
-//     order: issued there the poll comes back with column i's data, which the dot waits for anyway;
-//     issued after the dot it would come back behind column i+1 -- a full column later -- and the
-//     team would stream one column at a time (measured 5.2 TB/s; a scalar poll, which is not ordered
-//     with the vector loads but pays its L2 round trip inside the hand-off, 5.3 TB/s).
-// One column of lag leaves the parts about half a column (~1.7 us) to arrive before the early poll
-// is served: measured at the C5 share, 17 % of the polls came too early, and each of those pays a
-// second poll that returns behind the column requested meanwhile.  TS_LAG2 therefore finishes column
-// i-2 in iteration i: the column dotted one iteration ago stays in its registers, the one before it
-// waits in LDS (every thread parks and fetches its own elements: no hazard between threads, 2 x 80 KB
-// of LDS traffic per column beside the HBM stream), at the same three register buffers.
+// with sc1 loads; no counters, no fences; correct under any placement of the workgroups.  What
+// keeps the stream of G going across the hand-off of every column:
+//   * the next column is REALLY in flight while this one is processed.  The compiler counts
+//     outstanding vector loads per path and waits for the fewest any path may have issued, so one
+//     conditional vector load behind a column request (a guarded element, the per-column scalars
+//     of lanes 0..5, a request under `if (i + 1 < cnt)`) turns every wait for a column into
+//     s_waitcnt vmcnt(0): nothing is prefetched, each column pays the full memory latency plus
+//     the hand-off (5.9 TB/s at the C5 share, where sweep_kernel -- same defect, shorter hand-off
+//     -- still reached the plain-read rate).  Hence: unconditional column loads (threads past the
+//     end re-read the last double2; past the last column the last column again), 32-bit offsets
+//     from a uniform base held in their own registers, the scalars through the scalar cache
+//     (s_load, lgkmcnt), the poll address from a persistent offset register.  The waits are then
+//     vmcnt(5): the column just requested stays in flight;
+//   * a lag of two columns: a member publishes its part of column i and then finishes column i-2.
+//     The column dotted one iteration ago stays in its registers, the one before it waits in LDS
+//     (every thread parks and fetches its own elements: no hazard between threads; 2 x 80 KB of
+//     LDS traffic per column beside the HBM stream), at three register buffers.  With one column
+//     of lag 17 % of the polls came before the part (each then pays a second poll that returns
+//     behind the column requested meanwhile); with two, 1.5 %;
+//   * the poll for column i-2 is ISSUED at the start of iteration i, in front of the request for
+//     column i+1, and looked at after the dot of column i.  A wave's vector loads return in order:
+//     issued there the poll comes back before column i+1's data; issued after the dot it would come
+//     back behind it, a full column later.
 // A ring of eight granule slots per member suffices (a member at column k has the parts of column
 // k-2 of everybody: no member is more than two columns ahead of another, and the slowest still reads
 // column k-4).  Members of a team are blocks with equal blockIdx % 8, i.e. on one XCD

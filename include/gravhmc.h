@@ -320,7 +320,9 @@ int gh_rng_draw_trajectories(gh_rng *rng, int K, int Lmin, int Lmax, int64_t M, 
 
 /* HIP-event timing of the G sweeps (the dominant kernel) on the context's stream.
  * enable != 0 starts recording (and clears the counters).  gh_profile_read sums the recorded
- * intervals: total milliseconds, number of sweep launches, bytes of G each launch reads. */
+ * intervals of the launches that read the most bytes of G (where one-read sweeps and row-panel
+ * launches mix, the one-read sweeps alone: one kernel, comparable with a kernel trace): total
+ * milliseconds, number of those launches, bytes of G each of them reads. */
 int gh_profile_enable(gh_ctx *ctx, int enable);
 int gh_profile_read(gh_ctx *ctx, double *sweep_ms, int64_t *sweep_launches,
                     int64_t *bytes_per_sweep);
