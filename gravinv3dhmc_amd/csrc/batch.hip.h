@@ -87,16 +87,22 @@ __global__ void __launch_bounds__(256) batch_adjoint_kernel(BatchAdjArgs a)
         d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
         // software pipeline: two patches are in flight while one is multiplied (ring of three)
         d2 g0[3][2], g1[3][2], r0[3], r1[3];
+        // (every load unconditional -- patches past the end re-read the last one, columns past M the
+        // first, and the residual fragment is zeroed AFTER it arrived: one conditional load here and
+        // the compiler waits with vmcnt(0) in front of every multiply, so nothing is in flight
+        // while a patch is multiplied; see sweep_kernel)
+        const int plast = a.np - 1;
         auto fetch = [&](int slot, int p) {
             const bool ok = p < a.np;
+            const int pc = ok ? p : plast;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const bool gok = ok && col_ok[h];
-                g0[slot][h] = gok ? __builtin_nontemporal_load(gcol[h] + (int64_t)gstep * p) : d2{0.0, 0.0};
-                g1[slot][h] = gok ? __builtin_nontemporal_load(gcol[h] + (int64_t)gstep * p + ghalf) : d2{0.0, 0.0};
+                g0[slot][h] = __builtin_nontemporal_load(gcol[h] + (int64_t)gstep * pc);
+                g1[slot][h] = __builtin_nontemporal_load(gcol[h] + (int64_t)gstep * pc + ghalf);
             }
-            r0[slot] = ok ? rt[128 * p] : d2{0.0, 0.0};
-            r1[slot] = ok ? rt[128 * p + 64] : d2{0.0, 0.0};
+            const d2 ra = rt[128 * pc], rb = rt[128 * pc + 64];
+            r0[slot] = ok ? ra : d2{0.0, 0.0};
+            r1[slot] = ok ? rb : d2{0.0, 0.0};
         };
         auto mult = [&](int slot) {
 #pragma unroll
@@ -225,23 +231,32 @@ __global__ void __launch_bounds__(256) batch_forward_kernel(BatchFwdArgs a)
         acc[rp][1] = d4{0.0, 0.0, 0.0, 0.0};
     }
     // rows this lane loads in patch rp: i0 + 32 rp + 2 lo, +1
-    bool row_ok[4];
-#pragma unroll
-    for (int rp = 0; rp < 4; ++rp) row_ok[rp] = (i0 + 32 * rp + 2 * lo + 1) < a.ld;
     // pipeline unit = two groups of 4 columns (8 loads of 16 B, 16 MFMAs); the next unit is in
     // flight while the current one is multiplied
     double bA[2], bB[2];
     d2 gA[2][4], gB[2][4];
+    // (every load unconditional: columns past the block re-read its last column with a zero
+    // multiplier, rows past the end the column's last double2 -- their sums are never stored; a
+    // conditional load would make every wait in front of the MFMAs a vmcnt(0), see sweep_kernel)
+    const int64_t jlast = (jb1 > jb0 ? jb1 : a.M) - 1;
+    int64_t roff[4];
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp) {
+        const int64_t r = i0 + 32 * rp + 2 * lo;
+        roff[rp] = (r + 1 < a.ld) ? r : a.ld - 2;
+    }
     auto fetch = [&](double (&b)[2], d2 (&g)[2][4], int64_t jbase) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t j = jbase + 4 * u + k;
             const bool ok = j < jb1;
-            b[u] = ok ? a.X[j * CB + lo] : 0.0;
-            const d2 *col = reinterpret_cast<const d2 *>(a.G + (ok ? j : 0) * a.ld + i0) + lo;
+            const int64_t jc = ok ? j : jlast;
+            const double xv = a.X[jc * CB + lo];
+            b[u] = ok ? xv : 0.0;
+            const double *col = a.G + jc * a.ld;
 #pragma unroll
             for (int rp = 0; rp < 4; ++rp)
-                g[u][rp] = (ok && row_ok[rp]) ? __builtin_nontemporal_load(col + 16 * rp) : d2{0.0, 0.0};
+                g[u][rp] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(col + roff[rp]));
         }
     };
     auto mult = [&](const double (&b)[2], const d2 (&g)[2][4]) {

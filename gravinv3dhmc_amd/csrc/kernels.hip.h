@@ -2143,23 +2143,41 @@ mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const 
     }
     double pp = 0.0;
     unsigned nent = 0;
-    // what wave 0 fetches for a column: lanes 0..27 the cell constants, lanes 32..40 the scalars
-    auto fetch = [&](int64_t j) -> double {
-        double v = 0.0;
+    // What wave 0 fetches for a column -- lanes 0..27 the cell constants, lanes 32..38 the scalars,
+    // lanes 39, 40 the bounds of the near-field table -- is ONE 8-byte load from a per-lane base with a
+    // per-lane column stride, looked at a column later.  (Three branches, one of them choosing its
+    // vector among seven kernel arguments -- which the compiler turns into a load of the pointer from
+    // the argument segment -- and each consuming its value at once were three to four serial memory
+    // round trips in front of wave 0's share of every column, the other waves waiting at the
+    // barrier.  Absent vectors read `cellc` and are replaced when parked.)
+    const int sq = lane - 32;
+    const char *fbase = reinterpret_cast<const char *>(cellc);
+    int64_t fstride = 0;
+    bool fabsent = true, fint = false;
+    if (wave == 0) {
         if (lane < TESS_NC) {
-            v = cellc[(int64_t)TESS_NC * j + lane];
-        } else if (lane >= 32 && lane < 39) {
-            const int q = lane - 32;
-            const double *src = q == 0 ? a.x_in : q == 1 ? a.p_in : q == 2 ? a.low : q == 3 ? a.high
-                              : q == 4 ? a.greg : q == 5 ? a.pn_in : wm;
-            if (src) v = src[j];
-            if (q == 6 && !wm) v = 1.0;
-        } else if (lane == 39 || lane == 40) {
-            v = (double)near.ptr[j + (lane - 39)];  // (exact: far below 2^53)
+            fbase = reinterpret_cast<const char *>(cellc + lane);
+            fstride = TESS_NC * (int64_t)sizeof(double);
+            fabsent = false;
+        } else if (sq >= 0 && sq < 7) {
+            const double *v = sq == 0 ? a.x_in : sq == 1 ? a.p_in : sq == 2 ? a.low : sq == 3 ? a.high
+                            : sq == 4 ? a.greg : sq == 5 ? a.pn_in : wm;
+            fabsent = v == nullptr;
+            if (v) fbase = reinterpret_cast<const char *>(v);
+            fstride = v ? (int64_t)sizeof(double) : 0;
+        } else if (sq == 7 || sq == 8) {
+            fbase = reinterpret_cast<const char *>(near.ptr + (sq - 7));
+            fstride = sizeof(int64_t);
+            fabsent = false;
+            fint = true;
         }
-        return v;
+    }
+    auto fetch = [&](int64_t j) -> unsigned long long {
+        return *reinterpret_cast<const unsigned long long *>(fbase + j * fstride);
     };
-    auto park = [&](double v, int itn) {
+    auto park = [&](unsigned long long raw, int itn) {
+        double v = fint ? (double)(long long)raw : __longlong_as_double((long long)raw);  // (exact: far below 2^53)
+        if (fabsent) v = sq == 6 ? 1.0 : 0.0;
         if (lane < TESS_NC) ccs[(itn & 1) * 32 + lane] = v;
         else if (lane >= 32 && lane < 41) cs[(itn % 3) * NSC + (lane - 32)] = v;
     };
@@ -2177,7 +2195,7 @@ mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const 
     int it = 0;
     for (int64_t j = blockIdx.x; j < g.M; j += gridDim.x, ++it) {
         const int64_t jn = j + gridDim.x;
-        double nxt = 0.0;
+        unsigned long long nxt = 0;
         if (wave == 0 && jn < g.M) nxt = fetch(jn);   // in flight while the slots are evaluated
         // this column's cell constants, uniform
         double cc[TESS_NC];
