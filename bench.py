@@ -269,7 +269,7 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
             LAST_STATE["U"] = [float(v) for v in out5[:3]]
 
         try:
-            eng.run_chain(gen, dt, on_result)
+            eng.run_chain(gen, dt, on_result, overlap=True)   # as the sampler calls it (inversion/hmc.py)
         finally:
             if hasattr(gen, "release"):
                 gen.release()

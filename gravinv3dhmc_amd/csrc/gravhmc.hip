@@ -688,6 +688,7 @@ int gh_chain_init(gh_ctx *c, const double *x0, const double *low, const double *
     c->cur = 0;
     c->xcur = 0;
     c->spec_valid = c->pn_valid = false;
+    c->st_stale = false;
     c->accept_count = 0;
     TRY(h2d(c, c->xb[0], x0, (size_t)c->M));
     TRY(h2d(c, c->low, low, (size_t)c->M));
@@ -724,6 +725,20 @@ int gh_chain_prefetch_momentum(gh_ctx *c, const double *p0_next)
     return GH_OK;
 }
 
+// d, r and the scalars of the current sample after launches of the resident chain kernel
+static int chain_state_fresh(gh_ctx *c)
+{
+    if (!c->st_stale) return GH_OK;
+    TRY(eval_forward(c, c->xb[c->xcur], c->st[c->cur]));
+    TRY(scal_ready(c, c->st[c->cur]));
+    TRY(d2h(c, c->h_scal, c->st[c->cur].scal, 4));
+    c->U_cur[0] = c->h_scal[2];
+    c->U_cur[1] = c->h_scal[0];
+    c->U_cur[2] = c->h_scal[1];
+    c->st_stale = false;
+    return GH_OK;
+}
+
 static inline int other_of3(int a, int b)
 {
     for (int i = 0; i < 3; ++i)
@@ -741,6 +756,7 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
     TRY(need(c, c->chain_ready, "gh_chain_trajectory: call gh_chain_init first"));
     if (L < 1) return fail(c, GH_ERR_ARG, "gh_chain_trajectory: L must be >= 1");
     HIPCHK(c, hipSetDevice(c->device));
+    TRY(chain_state_fresh(c));
     const size_t M = (size_t)c->M;
     const int nt = c->n_teams;
     // Was the first step of this trajectory already taken speculatively by the previous call's
@@ -981,6 +997,7 @@ int gh_chain_get_dsyn(gh_ctx *c, double *dsyn)
     if (!c || !dsyn) return fail(c, GH_ERR_ARG, "gh_chain_get_dsyn: null pointer");
     TRY(need(c, c->chain_ready, "gh_chain_get_dsyn: call gh_chain_init first"));
     HIPCHK(c, hipSetDevice(c->device));
+    TRY(chain_state_fresh(c));
     return d2h(c, dsyn, c->st[c->cur].d, (size_t)c->N);
 }
 

@@ -114,6 +114,7 @@ struct gh_ctx {
     size_t h_scal_n = 0;
     bool chain_ready = false;
     double U_cur[3] = {0, 0, 0};
+    bool st_stale = false;  // the resident chain kernel moved x: st[cur] / U_cur are those of an older sample
 
     // column-block sharding of ONE chain over several GPUs: this context holds
     // the cells [m0, m0 + M) of M_global; N-vectors are replicated, the forward partials are

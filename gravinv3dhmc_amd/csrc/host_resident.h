@@ -341,13 +341,10 @@ static int chain_run_resident(gh_ctx *c, int K, const int *L, const double *p0s,
             HIPCHK(c, hipMemcpyAsync(x_out + (size_t)k * M, r.xacc + (size_t)k * M, M * sizeof(double),
                                      hipMemcpyDeviceToHost, c->stream));
     }
-    // bring the per-launch state (d, r, scalars of the current sample) back in step with x
+    // the per-launch state (d, r, scalars of the current sample) is behind x now: whoever reads it
+    // next brings it up to date (chain_state_fresh) -- not every batch, 150 us of launches and a
+    // round trip each
     c->spec_valid = c->pn_valid = false;
-    TRY(eval_forward(c, c->xb[c->xcur], c->st[c->cur]));
-    TRY(scal_ready(c, c->st[c->cur]));
-    TRY(d2h(c, c->h_scal, c->st[c->cur].scal, 4));
-    c->U_cur[0] = c->h_scal[2];
-    c->U_cur[1] = c->h_scal[0];
-    c->U_cur[2] = c->h_scal[1];
+    c->st_stale = true;
     return GH_OK;
 }
