@@ -112,22 +112,24 @@ static int configure_sweep(gh_ctx *c)
     if (e == 7) e = 8;
     c->TW = tw;
     c->EPT2 = e;
-    // two columns in flight per team where the registers allow it (16-wave teams with <= 5 double2
-    // per thread: 122 VGPRs, no spills; measured at 6 and 8 double2: 5.4 / 3.1 TB/s against 6.5 / 6.1
-    // with one column in flight)
-    c->PF = env_int("GRAVHMC_PF", (tw == 16 && e <= 5) ? 2 : 1) == 2 ? 2 : 1;
+    // columns in flight per team beyond the one being reduced.  Re-measured once the requests really
+    // stayed in flight (kernels.hip.h: sweep_kernel, load_col): one is enough wherever it was tried
+    // (7381 rows, 4 double2: 6.6 TB/s against 6.2 with two; 8192 / 12000 / 16000 rows: 6.46 / 6.47 /
+    // 6.45; two at 12000 / 16000: 6.1 / 3.8, spills); at C2's 5 double2 two measure 0.5 % better
+    // (122 VGPRs) and are kept.
+    c->PF = env_int("GRAVHMC_PF", (tw == 16 && e == 5) ? 2 : 1) == 2 ? 2 : 1;
     // G larger than the Infinity Cache is streamed once per sweep: bypass-friendly loads
     c->NT = env_int("GRAVHMC_NT", c->ld * c->M * 8 > (int64_t)(512 << 20) ? 1 : 0) != 0;
     const int wg_teams = (tw == 1) ? 4 : 1;
     // resident workgroups per CU we size the grid for (register/LDS budget of the kernel)
     int wg_per_cu = (tw == 16) ? 1 : (tw == 8) ? 2 : 4;
     if (tw == 4) {
-        // 4-wave teams (1024 < N <= 4096): as many teams as keep ~16 MB of columns in flight, not
+        // 4-wave teams (1024 < N <= 4096): as many teams as keep ~8 MB of columns in flight, not
         // more -- every further team costs a slab row per sweep and shortens the teams' column runs
-        // (measured at 4000 x 30000, 960 MB: 5.6 TB/s with 2 workgroups per CU against 4.8 with 4;
-        // at 2000 x 20000 four are needed: 4.6 against 3.6 TB/s)
+        // (TB/s with 8 / 16 MB at 1500, 2000, 2500, 3000, 4000 rows x 20000 .. 30000 columns:
+        // 5.8 / 5.9, 5.0 / 5.1, 5.4 / 5.0, 6.1 / 5.8, 6.4 / 5.8)
         const int64_t col_bytes = c->panel_rows * (int64_t)sizeof(double);
-        const int64_t need = (((int64_t)env_int("GRAVHMC_INFLIGHT_MB", 16) << 20) + col_bytes - 1) / col_bytes;
+        const int64_t need = (((int64_t)env_int("GRAVHMC_INFLIGHT_MB", 8) << 20) + col_bytes - 1) / col_bytes;
         wg_per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(4, (need + c->cus - 1) / c->cus));
     }
     // never more than the kernel's real residency (registers, LDS): a grid sized for four
