@@ -1669,7 +1669,7 @@ mf_forward_kernel(MfGeom g, const double *x, const double *wm, int64_t cells_per
 // that is 99.9 % of the pairs of the global model) with the same expressions, hence the same bits,
 // as tess_entry; a pair whose root must be subdivided (or flags an error) takes tess_entry itself.
 
-constexpr int TESS_NC = 28;  // doubles per cell in the table of cell constants
+constexpr int TESS_NC = 32;  // doubles per cell in the table of cell constants
 
 // [0] rt [1] rt*rt [2] lont [3] sinlatt [4] coslatt [5] ratio*Llon [6] ratio*Llat [7] ratio*Lr
 // [8,9] lonc [10,11] sinlatc [12,13] coslatc [14,15] rc [16,17] rc*rc
@@ -1723,12 +1723,17 @@ tess_cellconst_kernel(const double *__restrict__ bounds6, int64_t M, double rati
 #pragma unroll
         for (int k = 0; k < 2; ++k) o[18 + 2 * jn + k] = (rc[k] * rc[k]) * coslatc[jn];
     o[22] = dlon * dlat * dr * 0.125;
-    o[23] = 0.0;
+    o[23] = o[22] * (-100000.0 * 0.00000006673);  // (tess_leaf_fast: scale and sign in one factor)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         o[24 + i] = cos(o[8 + i]);
         o[26 + i] = sin(o[8 + i]);
     }
+    // (tess_leaf_fast: weight of node (lat j, r k) times r_k)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) o[28 + 2 * jn + k] = o[18 + 2 * jn + k] * rc[k];
 }
 
 __device__ __noinline__ double tess_entry_slow(double lon, double sinlat, double coslat, double radius,
@@ -1774,46 +1779,56 @@ __device__ __forceinline__ double tess_leaf_cc(double lon, double sinlat, double
 // matrix-free mode; the decisions -- which pairs are NOT a single leaf -- were taken once, exactly,
 // when the near-field table was built).  cos(lon - lonc) by the addition theorem from sin / cos of
 // the observation's longitude (tabulated per observation) and of the nodes' (per cell): 2 FMAs
-// instead of a ~55-instruction cos; 1 / l^3 as rsq(l^2)^3 with the hardware reciprocal square root
-// refined by a Newton step (to ~1e-15) instead of an IEEE sqrt and an IEEE divide
-// (~28 instructions); contraction allowed.  The reference itself writes l_sqr**1.5
+// instead of a ~55-instruction cos; 1 / l^3 from the hardware reciprocal square root and one Newton
+// factor (to ~2e-15) instead of an IEEE sqrt and an IEEE divide (~28 instructions); contraction
+// allowed.  The reference itself writes l_sqr**1.5
 // (_tesseroid_numba.py:218), so no form is bitwise its pow(); this one agrees with tess_leaf_cc to
 // <= 1e-13 of the entry for pairs that are far by the reference's own criterion (the conditioning
 // of l^2 = r^2 + r'^2 - 2 r r' cos psi is the formulation's: an ulp of cos psi moves l^2 by
 // 2 r r' 1e-16 ~ 1e-2 m^2 against l^2 >= 1e10 m^2).  Stated tolerance of the path: 1e-10.
-// Newton steps behind v_rsq_f64 (measured at C4 against the dense engine: one step forward 6.5e-15 /
-// gradient 9.8e-15, two steps 6.2e-15 / 7.3e-15 -- the hardware estimate is good to ~2^-26 and what
-// remains is the conditioning of l^2; one step is 8 % faster)
-#ifndef TESS_FAST_NEWTON
-#define TESS_FAST_NEWTON 1
-#endif
+// (Measured at C4 against the dense engine with y refined by one / two Newton steps and then cubed:
+// forward 6.5e-15 / 6.2e-15, gradient 9.8e-15 / 7.3e-15 -- the hardware estimate is good to ~2^-26
+// and what remains is the conditioning of l^2.)
 __device__ __forceinline__ double tess_leaf_fast(double sinlon, double coslon_o, double sinlat, double coslat,
                                                  double radius, const double *__restrict__ cc)
 {
+    // Per node: l = |r - r_c|^2 by one fma, y = v_rsq_f64(l) (~2^-26), and instead of refining y and
+    // cubing the result, the cube of the raw y times one Newton factor:
+    //     l^(-3/2) = y^3 (2.5 - 1.5 l y^2) (1 + 7.5 d^2 + ...),  d = relative error of y,
+    // i.e. 2*10^-15: eight operations and the rsq per node where the refined form took ten.  The
+    // node's weight and (r_c cos(psi) - r) are one fma of cos(psi) with coefficients that do not
+    // depend on the node's longitude (kappa_jk r_c: tabulated per cell; kappa_jk r: per entry).
     const double r_sqr = radius * radius;
-    const double two_r = 2.0 * radius;
+    const double A0 = r_sqr + cc[16], A1 = r_sqr + cc[17];
+    const double tr = -2.0 * radius;
+    const double m0 = cc[14] * tr, m1 = cc[15] * tr;
+    const double G00 = cc[28], G01 = cc[29], G10 = cc[30], G11 = cc[31];
+    const double H00 = -cc[18] * radius, H01 = -cc[19] * radius, H10 = -cc[20] * radius, H11 = -cc[21] * radius;
+    const double P0 = coslat * cc[12], P1 = coslat * cc[13], Q0 = sinlat * cc[10], Q1 = sinlat * cc[11];
     double result = 0.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const double coslon = coslon_o * cc[24 + i] + sinlon * cc[26 + i];
+        const double coslon = fma(sinlon, cc[26 + i], coslon_o * cc[24 + i]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const double cospsi = sinlat * cc[10 + j] + coslat * cc[12 + j] * coslon;
+            const double cospsi = fma(j ? P1 : P0, coslon, j ? Q1 : Q0);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const double rck = cc[14 + k];
-                const double l_sqr = (r_sqr + cc[16 + k]) - two_r * rck * cospsi;
-                double y = __builtin_amdgcn_rsq(l_sqr);
-                const double h = 0.5 * l_sqr;
-                y = fma(y, fma(-h * y, y, 0.5), y);
-#if TESS_FAST_NEWTON > 1
-                y = fma(y, fma(-h * y, y, 0.5), y);
-#endif
-                result = fma(cc[18 + 2 * j + k] * (rck * cospsi - radius), y * y * y, result);
+                const double l = fma(k ? m1 : m0, cospsi, k ? A1 : A0);
+                const double y = __builtin_amdgcn_rsq(l);
+                const double y2 = y * y;
+                const double y3 = y2 * y;
+                // y^3 (2.5 - 1.5 l y^2) as y^3 + 1.5 (y^3 (1 - l y^2)): one constant that is not an
+                // inline operand instead of two (each costs two moves per use: an instruction reads
+                // one scalar register pair at most)
+                const double w = fma(y3 * fma(-l, y2, 1.0), 1.5, y3);
+                const double fg = fma(j ? (k ? G11 : G10) : (k ? G01 : G00), cospsi,
+                                      j ? (k ? H11 : H10) : (k ? H01 : H00));
+                result = fma(fg, w, result);
             }
         }
     }
-    return (cc[22] * -result) * (100000.0 * 0.00000006673);
+    return result * cc[23];
 }
 
 // Does the pair need more than the root leaf (subdivision, or an error flag)?  The root's
@@ -2178,6 +2193,9 @@ mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const 
     auto park = [&](unsigned long long raw, int itn) {
         double v = fint ? (double)(long long)raw : __longlong_as_double((long long)raw);  // (exact: far below 2^53)
         if (fabsent) v = sq == 6 ? 1.0 : 0.0;
+        // (the column's weight is parked as its reciprocal, rounded as 1.0 / w is: one division per
+        // column instead of two in every wave)
+        if (sq == 6) v = (v != 0.0) ? 1.0 / v : 1.0;
         if (lane < TESS_NC) ccs[(itn & 1) * 32 + lane] = v;
         else if (lane >= 32 && lane < 41) cs[(itn % 3) * NSC + (lane - 32)] = v;
     };
@@ -2192,6 +2210,8 @@ mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const 
         f4 = g.o3[tid];
     }
     __syncthreads();
+    const unsigned toff = (unsigned)tid * (unsigned)sizeof(double);
+    const unsigned olast = (unsigned)(N - 1) * (unsigned)sizeof(double);
     int it = 0;
     for (int64_t j = blockIdx.x; j < g.M; j += gridDim.x, ++it) {
         const int64_t jn = j + gridDim.x;
@@ -2201,32 +2221,43 @@ mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const 
         double cc[TESS_NC];
 #pragma unroll
         for (int q = 8; q < TESS_NC; ++q) cc[q] = uniform_d(ccs[(it & 1) * 32 + q]);
-        int64_t i = tid;
-        double c0 = f0, c1 = f1, c2 = f2, c3 = f3, c4 = f4;
+        // The slots of this column, two per trip: while one is evaluated the observer constants of
+        // the next are in flight, and "next" becomes "current" by taking turns between two register
+        // sets, not by five 64-bit moves per entry.  Their loads are unconditional (rows past the end
+        // re-read the last row; such slots are not evaluated) at a 32-bit byte offset from the five
+        // fixed bases (global_load v, voff, s[base]): no zeroing, no branch, no 64-bit address sums.
+        double a0 = f0, a1 = f1, a2 = f2, a3 = f3, a4 = f4, b0, b1, b2, b3, b4;
+        unsigned off = toff;
+#define GH_OBS_LOAD(n0, n1, n2, n3, n4)                                                                  \
+    {                                                                                                    \
+        off = off + (unsigned)(T * sizeof(double));                                                      \
+        unsigned oc = off < olast ? off : olast;                                                         \
+        asm volatile("" : "+v"(oc));                                                                     \
+        n0 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(g.o4) + oc);               \
+        n1 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(g.o5) + oc);               \
+        n2 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(g.o1) + oc);               \
+        n3 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(g.o2) + oc);               \
+        n4 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(g.o3) + oc);               \
+    }
+#define GH_SLOT_EVAL(c0, c1, c2, c3, c4, kk)                                                             \
+    {                                                                                                    \
+        double v = 0.0;                                                                                  \
+        if (tid + (int64_t)(kk) * T < N) {                                                               \
+            v = tess_leaf_fast(c0, c1, c2, c3, c4, cc);                                                  \
+            nent += 1;                                                                                   \
+        }                                                                                                \
+        Ks[(size_t)(kk) * T + tid] = v;                                                                  \
+    }
 #pragma unroll 1
-        for (int k = 0; k < ept; ++k) {
-            const int64_t in = i + T;
-            double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, n4 = 0.0;
-            if (k + 1 < ept && in < N) {
-                n0 = g.o4[in];
-                n1 = g.o5[in];
-                n2 = g.o1[in];
-                n3 = g.o2[in];
-                n4 = g.o3[in];
-            }
-            double v = 0.0;
-            if (i < N) {
-                v = tess_leaf_fast(c0, c1, c2, c3, c4, cc);
-                nent += 1;
-            }
-            Ks[(size_t)k * T + tid] = v;
-            i = in;
-            c0 = n0;
-            c1 = n1;
-            c2 = n2;
-            c3 = n3;
-            c4 = n4;
+        for (int k = 0; k < ept; k += 2) {
+            GH_OBS_LOAD(b0, b1, b2, b3, b4)
+            GH_SLOT_EVAL(a0, a1, a2, a3, a4, k)
+            if (k + 1 >= ept) break;
+            GH_OBS_LOAD(a0, a1, a2, a3, a4)
+            GH_SLOT_EVAL(b0, b1, b2, b3, b4, k + 1)
         }
+#undef GH_OBS_LOAD
+#undef GH_SLOT_EVAL
         const double *sc = cs + (it % 3) * NSC;
         const int64_t q0 = (int64_t)sc[7], q1 = (int64_t)sc[8];
         if (q1 > q0) {
@@ -2245,13 +2276,13 @@ mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const 
         if (lane == 0) slot[wave] = s;
         if (wave == 0 && jn < g.M) park(nxt, it + 1);
         __syncthreads();
-        const double w = sc[6];
+        const double iw = sc[6];  // 1 / w_j (1 where the column has no weight)
         double xj = sc[0];
         if (mode & SW_ADJ) {
             double t = 0.0;
 #pragma unroll
             for (int wv = 0; wv < NW; ++wv) t += slot[wv];
-            t = (w != 0.0) ? t * (1.0 / w) : t;
+            t = t * iw;
             const double grad = 2.0 * t + sc[4];
             if ((mode & SW_GOUT) && tid == 0) a.g_out[j] = grad;
             if (mode & SW_PFIN) {
@@ -2278,7 +2309,7 @@ mf_tess_fast_kernel(MfGeom g, SweepArgs a, const double *__restrict__ wm, const 
             }
         }
         if (mode & SW_FWD) {
-            const double xs = (w != 0.0) ? xj * (1.0 / w) : xj;
+            const double xs = xj * iw;
 #pragma unroll
             for (int k = 0; k < EPT; ++k)
                 if (k < ept) dacc[k] += Ks[(size_t)k * T + tid] * xs;
