@@ -1987,3 +1987,31 @@ def test_round2_paths_are_bitwise_reproducible(G, path):
     (a, ax, ad), (b, bx, bd) = runs
     assert len(a) == 6 and all(a1 == b1 and np.array_equal(o1, o2) for (a1, o1), (b1, o2) in zip(a, b))
     assert np.array_equal(ax, bx) and np.array_equal(ad, bd)
+
+
+@pytest.mark.gpu
+def test_profile_reports_the_one_read_sweeps_alone_where_panels_mix_in(G, monkeypatch):
+    """N > 16384: a trajectory mixes team sweeps (the whole matrix each) with row-panel launches (a
+    panel each).  gh_profile_read counts the launches that read the most bytes only, so that time and
+    bytes per launch are those of ONE kernel (bench.py's roofline, comparable with a kernel trace);
+    the team statistics say how many of a member's polls came before its team's parts."""
+    N, M = 20481, 600
+    rng = np.random.default_rng(5)
+    A = np.asfortranarray(rng.normal(size=(N, M)))
+    eng = G.Engine(N, M)
+    eng.upload_G(A)
+    wm = eng.weight(0.5)
+    eng.set_data(rng.normal(size=N))
+    eng.set_reg("Damping", 1.0, 0.01, (1, 1, M), 0.001 * wm)
+    eng.chain_init(0.001 * wm, 0.0 * wm, 1.0 * wm)
+    trajs = [(4, rng.normal(size=M) * 0.01, 0.5) for _ in range(3)]
+    eng.profile_enable(True)
+    eng.run_chain(iter(trajs), 0.002, lambda *a: None)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    st = eng.chain_stats()
+    assert st["team_members"] == 3 and st["team_launches"] > 0 and st["team_timeouts"] == 0
+    assert prof["bytes_per_sweep"] == N * M * 8          # a team sweep, not the average with the panels
+    assert 0 < prof["sweeps"] <= st["team_launches"] and prof["sweep_ms"] > 0
+    assert 0 <= st["team_late_parts"] <= st["team_launches"] * 256 * M
+    eng.close()
