@@ -364,11 +364,11 @@ static int launch_sweep_one(gh_ctx *c, SweepArgs &a)
 
 typedef void (*team_fn)(TeamArgs);
 
-// Measured at the C5 share (N = 4*10^4, 3*10^5 cells, 96 GB; ms per team sweep): 1024 threads x 5
-// double2 x 3 buffers (4 members) 18.0; 1024 x 4 x 4 (5 members, 240 of 256 CUs) 19.8; 512 x 10 x 4
-// 17.5 + more variance; 512 x 10 x 5 25.8; 512 x 8 x 5 21.4 -- what a column costs beyond its bytes
-// is the per-column hand-off (two workgroup barriers and one L2 round trip), not the depth of the
-// prefetch, so the shape with the fewest, largest members is kept.
+// Instantiations: 1024 threads x 5 double2 x 3 register buffers, with a lag of one or two columns
+// (teamsweep.hip.h).  C5 share (N = 4*10^4, 3*10^5 cells, 96 GB), ms per team sweep: lag 2 14.2,
+// lag 1 14.7 (a plain read of the matrix: 14.0).  Other shapes were measured only while the kernel's
+// column requests were still drained in front of every dot (18.0 then): 1024 x 4 x 4 (5 members, 240
+// of 256 CUs) 19.8; 512 x 10 x 4 17.5 + more variance; 512 x 10 x 5 25.8; 512 x 8 x 5 21.4.
 static team_fn team_kernel_for(int threads, int ept2, int depth, int lag)
 {
     if (threads == 1024 && ept2 == 5 && depth == 3)
