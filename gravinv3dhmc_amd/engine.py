@@ -265,7 +265,7 @@ class Engine(object):
                 "xs": np.empty((K, self.M)) if want_x else None, "n_run": C.c_int(0)}
 
     def _run_batch(self, a, dt, stop_at, record_from, want_x, entered=None):
-        """One gh_chain_run call over a prepared block; returns per-trajectory results.
+        """One gh_chain_run call over a prepared block; returns the number of trajectories run.
         `entered` (threading.Event) is set right before the library call (which releases the GIL)."""
         if entered is not None:
             entered.set()
@@ -273,9 +273,7 @@ class Engine(object):
                                          ptr(a["p0s"]), ptr(a["us"]), float(dt),
                                          ptr(a["look"]), int(stop_at), int(record_from), a["acc"],
                                          ptr(a["out5"]), ptr(a["xs"]), C.byref(a["n_run"])))
-        acc, out5, xs = a["acc"], a["out5"], a["xs"]
-        return [(bool(acc[k]), out5[k].copy(), xs[k].copy() if (want_x and acc[k]) else None)
-                for k in range(a["n_run"].value)]
+        return a["n_run"].value   # results: a["acc"], a["out5"], a["xs"] (first n_run rows)
 
     def default_batch(self):
         """Trajectories per gh_chain_run call: enough to hide the per-call cost (Python round trip:
@@ -344,62 +342,81 @@ class Engine(object):
                     return (np.empty(0, dtype=np.int32), np.empty((0, 0)), np.empty(0))
                 return (np.asarray(Ls, dtype=np.int32), np.stack(ps), np.asarray(us, dtype=np.float64))
 
-        def start(prepared):
-            res = {}
-            entered = threading.Event()
+        # one worker thread for the whole chain takes the library calls (a thread per call costs
+        # ~0.1 ms of idle device between two batches of a small problem)
+        import queue
+        jobs = queue.Queue()
 
-            def work():
+        def worker():
+            while True:
+                item = jobs.get()
+                if item is None:
+                    return
+                prepared, res, entered, done = item
                 try:
-                    res["r"] = self._run_batch(prepared, dt, stop_at_accepts, record_from, want_x, entered)
+                    res["n"] = self._run_batch(prepared, dt, stop_at_accepts, record_from, want_x, entered)
                 except BaseException as e:  # re-raised in the caller's thread
                     res["e"] = e
                 finally:
                     entered.set()
+                    done.set()
 
-            th = threading.Thread(target=work)
-            th.start()
-            # the GPU has its work before this thread goes back to drawing (the legacy generator
+        th = threading.Thread(target=worker, daemon=True)
+        th.start()
+
+        def start(prepared):
+            res = {"a": prepared}
+            entered, done = threading.Event(), threading.Event()
+            jobs.put((prepared, res, entered, done))
+            # the GPU has its work before this thread goes back to drawing (np.random's generator
             # holds the GIL for the ~10 ms a C2 momentum takes)
             entered.wait()
-            return th, res
+            return done, res
 
         def finish(job):
-            job[0].join()
+            job[0].wait()
             if "e" in job[1]:
                 raise job[1]["e"]
-            return job[1]["r"]
+            return job[1]["n"], job[1]["a"]
 
         def some(blk):
             return blk is not None and len(blk[0]) > 0
 
-        # a momentum of >= 1 MB takes milliseconds to draw: the first call then carries ONE trajectory,
-        # so the device starts after two draws instead of batch + 1
-        cur = take(1 if self.M * 8 >= (1 << 20) else batch)
-        look = take(1) if some(cur) else None
-        look = look if some(look) else None
-        job = start(self._prepare_batch(cur, look, want_x)) if some(cur) else None
-        while some(cur):
-            # the lookahead trajectory opens the next batch; the rest is drawn and marshalled
-            # while the GPU runs
-            nxt = take(batch, head=look) if look is not None else None
-            nlook = take(1) if some(nxt) else None
-            nlook = nlook if some(nlook) else None
-            nprepared = self._prepare_batch(nxt, nlook, want_x) if some(nxt) else None
-            results = finish(job)
-            short = len(results) < len(cur[0])           # the library stopped at stop_at_accepts
-            job = start(nprepared) if (overlap and some(nxt) and not short) else None
-            stop = False
-            for L, (acc, o, x) in zip(cur[0], results):
-                if on_result(int(L), acc, o, self._full_vec(x) if x is not None else None) is False:
-                    stop = True
+        try:
+            # a momentum of >= 1 MB takes milliseconds to draw: the first call then carries ONE
+            # trajectory, so the device starts after two draws instead of batch + 1
+            cur = take(1 if self.M * 8 >= (1 << 20) else batch)
+            look = take(1) if some(cur) else None
+            look = look if some(look) else None
+            job = start(self._prepare_batch(cur, look, want_x)) if some(cur) else None
+            while some(cur):
+                # the lookahead trajectory opens the next batch; the rest is drawn and marshalled
+                # while the GPU runs
+                nxt = take(batch, head=look) if look is not None else None
+                nlook = take(1) if some(nxt) else None
+                nlook = nlook if some(nlook) else None
+                nprepared = self._prepare_batch(nxt, nlook, want_x) if some(nxt) else None
+                n_run, a = finish(job)
+                short = n_run < len(cur[0])               # the library stopped at stop_at_accepts
+                job = start(nprepared) if (overlap and some(nxt) and not short) else None
+                stop = False
+                acc, out5, xs = a["acc"], a["out5"], a["xs"]
+                for k in range(n_run):
+                    x = xs[k].copy() if (want_x and acc[k]) else None
+                    if on_result(int(cur[0][k]), bool(acc[k]), out5[k],
+                                 self._full_vec(x) if x is not None else None) is False:
+                        stop = True
+                        break
+                if stop or short or not some(nxt):
+                    if job is not None:
+                        finish(job)
                     break
-            if stop or short or not some(nxt):
-                if job is not None:
-                    finish(job)
-                break
-            if job is None:
-                job = start(nprepared)
-            cur, look = nxt, nlook
+                if job is None:
+                    job = start(nprepared)
+                cur, look = nxt, nlook
+        finally:
+            jobs.put(None)
+            th.join()
 
     def chain_get_x(self):
         x = np.empty(self.M)
