@@ -2015,3 +2015,31 @@ def test_profile_reports_the_one_read_sweeps_alone_where_panels_mix_in(G, monkey
     assert 0 < prof["sweeps"] <= st["team_launches"] and prof["sweep_ms"] > 0
     assert 0 <= st["team_late_parts"] <= st["team_launches"] * 256 * M
     eng.close()
+
+
+@pytest.mark.gpu
+def test_sampler_draws_from_the_library_are_np_randoms(G, tmp_path, capsys, monkeypatch):
+    """HMCSample with the trajectories' random numbers drawn by the library (the default:
+    inversion/rng.py, gh_rng_draw_trajectories) and by np.random itself (GRAVHMC_HOST_RNG=numpy):
+    the same files byte for byte, the same printed lines, and the same generator state afterwards
+    (the draws of the next np.random call agree)."""
+    g = gold("c1_chain.npz")
+    mesh, xp, yp, zp = c1_inputs()
+    M = 6000
+    out = {}
+    for mode in ("native", "numpy"):
+        monkeypatch.setenv("GRAVHMC_HOST_RNG", mode)
+        gm = G.GravMagModule(g["dobs"], (0, 2000, 0, 3000, 0, 1000), (100, 100, 100), (xp, yp, zp), verbose=False)
+        folder = str(tmp_path / ("chain_" + mode))
+        capsys.readouterr()
+        G.HMCSample(gm, 7, 0, 0.01, [5, 20], np.full(M, 0.001), np.full(M, 0.001),
+                    np.c_[np.zeros(M), np.ones(M)], "mandatory", 1000, g["dobs"], "Fixed", 0.8, 1.0,
+                    "MS", 0.001, 100, 0.001, save_folder=folder)
+        lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain ")]
+        out[mode] = (open(folder + "0/misfit.dat", "rb").read(), open(folder + "0/model.dat", "rb").read(), lines,
+                     np.random.rand(3).tolist())
+        gm._engine.close()
+    assert out["native"][0] == out["numpy"][0] and out["native"][1] == out["numpy"][1]
+    assert out["native"][2] == out["numpy"][2] and len(out["native"][2]) >= 7
+    # both modes drew the same number of trajectories ahead of the last accepted one
+    assert out["native"][3] == out["numpy"][3]
