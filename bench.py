@@ -610,10 +610,14 @@ def main():
                 if near else st["leaves"]
             ref_unit = FLOPS_PER_TESS_LEAF if tess else FLOPS_PER_PRISM_ENTRY
             line["roofline"] = {
-                "bound": "fp64 vector (no stored G: entries re-evaluated, every entry once per step)",
+                "bound": "fp64 vector (no stored G: entries re-evaluated, every entry %s per step)"
+                         % ("twice for all chains together" if CPG > 1 else "once"),
                 "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / FP64_VECTOR_PEAK_TFLOPS if tflops else None, "traffic": None,
-                "kernel": "mf_tess_fast_kernel / mf_fused_kernel (entries of a cell's column evaluated once, "
+                "kernel": ("mfb_adjoint_kernel + mfb_forward_kernel (%d chains share every evaluated entry: "
+                           "16 columns x 512 rows staged in LDS, v_mfma_f64_16x16x4 for the chains; two "
+                           "evaluations per entry and step of the whole batch)" % CPG) if CPG > 1 else
+                          "mf_tess_fast_kernel / mf_fused_kernel (entries of a cell's column evaluated once, "
                           "dot with r, leapfrog update, forward accumulation)",
                 "launches": st["launches"], "avg_ms": sweep_ms,
                 "entries_per_launch": st["entries"] / max(1, st["launches"]),

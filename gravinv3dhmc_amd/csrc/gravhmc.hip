@@ -5,6 +5,7 @@
 #include "batch.hip.h"
 #include "resident.hip.h"
 #include "teamsweep.hip.h"
+#include "mfbatch.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -173,7 +174,7 @@ int gh_build_G(gh_ctx *c)
                 c->tconv + 3 * N, c->tconv + 4 * N, c->tconv + 5 * N);
             HIPCHK(c, hipGetLastError());
             c->mf_exact = env_int("GRAVHMC_MF_EXACT", 0) != 0;
-            if (c->mf_fused) {
+            {
                 // what depends on the cell alone, once per cell instead of once per (obs, cell) pair
                 TRY(dalloc(c, &c->mf_cellc, (size_t)c->M * TESS_NC, false));
                 tess_cellconst_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
@@ -1075,8 +1076,8 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
 {
     if (!c || !x0s || !low || !high) return fail(c, GH_ERR_ARG, "gh_batch_init: null pointer");
     if (C < 1 || C > CB) return fail(c, GH_ERR_ARG, "gh_batch_init: 1..16 chains per batch");
-    TRY(need(c, c->have_G && c->have_data && c->have_reg && !c->mf,
-             "gh_batch_init: needs the stored (dense) kernel matrix, gh_set_data and gh_set_reg"));
+    TRY(need(c, c->have_G && c->have_data && c->have_reg,
+             "gh_batch_init: needs the kernel (gh_build_G / gh_upload_G), gh_set_data and gh_set_reg"));
     if (c->sh.kind != 0)
         return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the unsharded kernel only");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1195,11 +1196,7 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
                 }
             }
         }
-        bool timed;
-        TRY(batch_time_begin(c, timed));
-        batch_adjoint_kernel<<<dim3((unsigned)(b.n_waves / 4)), dim3(256), 0, c->stream>>>(a);
-        TRY(batch_time_end(c, timed));
-        HIPCHK(c, hipGetLastError());
+        TRY(batch_launch_adjoint(c, a));
         if (any_upd) TRY(batch_evaluate(c, b.Xw[xo], b.Dw, b.GREGw, b.Rtw));
         X_in = b.Xw[xo];
         Rt_in = b.Rtw;
@@ -1497,11 +1494,7 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
             scatter_staged(spec, b.Pn);
             batch_sumsq_kernel<<<dim3((unsigned)b.n_pp0), dim3(256), 0, c->stream>>>(b.Pn, c->M, b.pn0_part);
         }
-        bool timed;
-        TRY(batch_time_begin(c, timed));
-        batch_adjoint_kernel<<<dim3((unsigned)(b.n_waves / 4)), dim3(256), 0, c->stream>>>(a);
-        TRY(batch_time_end(c, timed));
-        HIPCHK(c, hipGetLastError());
+        TRY(batch_launch_adjoint(c, a));
         if (any_upd) {
             TRY(batch_evaluate(c, b.Xw[run.xi ^ 1], Ds[wset], GREGs[wset], Rts[wset], scals[wset]));
             run.ws = wset;

@@ -4,6 +4,165 @@
 
 // --------------------------------------------------------------- batched chains (MFMA)
 
+// ------------------------------------------------ batched chains on the matrix-free kernel (mfbatch.hip.h)
+
+static int mfb_kind(const gh_ctx *c)
+{
+    if (c->cell_kind != GH_CELL_TESSEROID) return 0;
+    if (!c->mf_near_on) return 1;
+    return c->mf_exact ? 2 : 3;
+}
+
+typedef void (*mfb_adj_fn)(MfGeom, BatchAdjArgs, const double *, const double *, const double *, MfStats *);
+typedef void (*mfb_fwd_fn)(MfGeom, MfbFwdArgs, const double *, MfStats *);
+
+static mfb_adj_fn mfb_adj_for(const gh_ctx *c)
+{
+    switch (mfb_kind(c)) {
+    case 0: return mfb_adjoint_kernel<0>;
+    case 1: return mfb_adjoint_kernel<1>;
+    case 2: return mfb_adjoint_kernel<2>;
+    default: return mfb_adjoint_kernel<3>;
+    }
+}
+
+static mfb_fwd_fn mfb_fwd_for(const gh_ctx *c)
+{
+    switch (mfb_kind(c)) {
+    case 0: return mfb_forward_kernel<0>;
+    case 1: return mfb_forward_kernel<1>;
+    case 2: return mfb_forward_kernel<2>;
+    default: return mfb_forward_kernel<3>;
+    }
+}
+
+// Partition of the two passes and, for tesseroids with the near-field table, the listed pairs as
+// differences to the root leaf the dense passes stage (column-major for the adjoint, a row-major
+// copy for the forward: both sums then run in a fixed order without atomics).
+static int mfb_plan(gh_ctx *c)
+{
+    gh_ctx::Batch &b = c->bt;
+    const int64_t ntiles = (c->M + 15) / 16;
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_adj_for(c)), MFB_LDS));
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_fwd_for(c)), MFB_LDS));
+    // one workgroup of 16 waves per CU (133 KB of staging): adjoint = column tiles dealt round-robin
+    b.mfb_grid_adj = (int)std::min<int64_t>(ntiles, (int64_t)c->cus * env_int("GRAVHMC_MFB_WG_PER_CU", 1));
+    b.n_waves = b.mfb_grid_adj;  // rows of pp_part: one per workgroup
+    // forward = 512-row chunks x ranges of column tiles, about one workgroup per CU
+    const int nrb = (int)((c->ld + 63) / 64);
+    b.mfb_rchunks = (nrb + MFB_RC - 1) / MFB_RC;
+    int ranges = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.mfb_rchunks));
+    ranges = env_int("GRAVHMC_MFB_RANGES", ranges);
+    b.mfb_tpr = (int)((ntiles + ranges - 1) / ranges);
+    b.mfb_ranges = (int)((ntiles + b.mfb_tpr - 1) / b.mfb_tpr);
+    TRY(dalloc(c, &b.iw, (size_t)c->M));
+    b.mfb_near = false;
+    const int kind = mfb_kind(c);
+    if (kind >= 2 && c->mf_near_n > 0) {
+        const int64_t n = c->mf_near_n;
+        std::vector<int64_t> ptr((size_t)c->M + 1);
+        std::vector<int> row((size_t)n), colof((size_t)n);
+        HIPCHK(c, hipMemcpyAsync(ptr.data(), c->mf_near_ptr, sizeof(int64_t) * ptr.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(row.data(), c->mf_near_row, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int64_t j = 0; j < c->M; ++j)
+            for (int64_t q = ptr[(size_t)j]; q < ptr[(size_t)j + 1]; ++q) colof[(size_t)q] = (int)j;
+        int *d_colof = nullptr;
+        TRY(dalloc(c, &d_colof, (size_t)n, false));
+        HIPCHK(c, hipMemcpyAsync(d_colof, colof.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        TRY(dalloc(c, &b.ndelta, (size_t)n, false));
+        const MfGeom g = mf_geom(c);
+        MfNear near{c->mf_near_ptr, c->mf_near_row, c->mf_near_val};
+        if (kind == 3)
+            mfb_near_delta_kernel<3><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(g, c->mf_cellc, near, n, d_colof, b.ndelta);
+        else
+            mfb_near_delta_kernel<2><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(g, c->mf_cellc, near, n, d_colof, b.ndelta);
+        HIPCHK(c, hipGetLastError());
+        std::vector<double> delta((size_t)n);
+        TRY(d2h(c, delta.data(), b.ndelta, (size_t)n));
+        // row-major copy (columns ascending inside a row: a stable counting sort by row)
+        std::vector<int64_t> rptr((size_t)c->N + 1, 0);
+        for (int64_t q = 0; q < n; ++q) rptr[(size_t)row[(size_t)q] + 1] += 1;
+        for (int64_t i = 0; i < c->N; ++i) rptr[(size_t)i + 1] += rptr[(size_t)i];
+        std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+        std::vector<int> rcol((size_t)n);
+        std::vector<double> rdelta((size_t)n);
+        for (int64_t q = 0; q < n; ++q) {
+            const int64_t at = fill[(size_t)row[(size_t)q]]++;
+            rcol[(size_t)at] = colof[(size_t)q];
+            rdelta[(size_t)at] = delta[(size_t)q];
+        }
+        TRY(dalloc(c, &b.rptr, (size_t)c->N + 1, false));
+        TRY(dalloc(c, &b.rcol, (size_t)n, false));
+        TRY(dalloc(c, &b.rdelta, (size_t)n, false));
+        HIPCHK(c, hipMemcpyAsync(b.rptr, rptr.data(), sizeof(int64_t) * rptr.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b.rcol, rcol.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b.rdelta, rdelta.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host vectors go out of scope)
+        TRY(dalloc(c, &b.Snear, (size_t)c->M * CB));
+        b.mfb_near = true;
+    }
+    b.n_colblocks = b.mfb_ranges + (b.mfb_near ? 1 : 0);
+    b.cols_per_block = (int64_t)b.mfb_tpr * 16;
+    return GH_OK;
+}
+
+static int batch_time_begin(gh_ctx *c, bool &timed);
+static int batch_time_end(gh_ctx *c, bool timed);
+
+// forward of all chains at X into the slab (ranges of column tiles, plus the near-field block)
+static int mfb_forward(gh_ctx *c, const double *X)
+{
+    gh_ctx::Batch &b = c->bt;
+    MfbFwdArgs f;
+    f.ld = c->ld;
+    f.M = c->M;
+    f.X = X;
+    f.iw = b.iw;
+    f.tiles_per_range = b.mfb_tpr;
+    f.slab = b.slab;
+    bool timed;
+    TRY(batch_time_begin(c, timed));
+    hipLaunchKernelGGL(mfb_fwd_for(c), dim3((unsigned)b.mfb_rchunks, (unsigned)b.mfb_ranges), dim3(1024), MFB_LDS,
+                       c->stream, mf_geom(c), f, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,
+                       c->prof ? c->mf_stats : nullptr);
+    TRY(batch_time_end(c, timed));
+    if (c->prof) c->mf_launches += 1;
+    if (b.mfb_near) {
+        const int64_t l16 = c->ld * CB;
+        mfb_near_forward_kernel<<<dim3((unsigned)((l16 + 255) / 256)), dim3(256), 0, c->stream>>>(
+            b.rptr, b.rcol, b.rdelta, c->N, c->ld, X, b.iw, b.slab + (size_t)b.mfb_ranges * (size_t)l16);
+    }
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+// adjoint of all chains + leapfrog update: the dense batch's MFMA kernel or the matrix-free one
+static int batch_launch_adjoint(gh_ctx *c, BatchAdjArgs &a)
+{
+    gh_ctx::Batch &b = c->bt;
+    bool timed;
+    if (c->mf) {
+        if (b.mfb_near) {
+            const int64_t n16 = c->M * CB;
+            mfb_near_adjoint_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(
+                c->mf_near_ptr, c->mf_near_row, b.ndelta, c->M, a.Rt, b.Snear);
+        }
+        TRY(batch_time_begin(c, timed));
+        hipLaunchKernelGGL(mfb_adj_for(c), dim3((unsigned)b.mfb_grid_adj), dim3(1024), MFB_LDS, c->stream, mf_geom(c),
+                           a, b.iw, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,
+                           b.mfb_near ? b.Snear : nullptr, c->prof ? c->mf_stats : nullptr);
+        TRY(batch_time_end(c, timed));
+        if (c->prof) c->mf_launches += 1;
+    } else {
+        TRY(batch_time_begin(c, timed));
+        batch_adjoint_kernel<<<dim3((unsigned)(b.n_waves / 4)), dim3(256), 0, c->stream>>>(a);
+        TRY(batch_time_end(c, timed));
+    }
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
 static int batch_alloc(gh_ctx *c)
 {
     gh_ctx::Batch &b = c->bt;
@@ -22,27 +181,31 @@ static int batch_alloc(gh_ctx *c)
     TRY(dalloc(c, &b.Dw, L16));
     TRY(dalloc(c, &b.scal, CB * 4));
     TRY(dalloc(c, &b.stage, M16));
-    // forward: 512-row blocks x column blocks, about 4 workgroups per CU in total
-    const int rowblocks = (int)((c->ld + 511) / 512);
-    int colblocks = std::max(1, (c->cus * 4 + rowblocks - 1) / rowblocks);
-    int64_t cpb = (c->M + colblocks - 1) / colblocks;
-    cpb = (cpb + 15) / 16 * 16;
-    b.cols_per_block = cpb;
-    b.n_colblocks = (int)((c->M + cpb - 1) / cpb);
+    const int64_t ntiles = (c->M + 15) / 16;
+    if (c->mf) {
+        TRY(mfb_plan(c));
+    } else {
+        // forward: 512-row blocks x column blocks, about 4 workgroups per CU in total
+        const int rowblocks = (int)((c->ld + 511) / 512);
+        int colblocks = std::max(1, (c->cus * 4 + rowblocks - 1) / rowblocks);
+        int64_t cpb = (c->M + colblocks - 1) / colblocks;
+        cpb = (cpb + 15) / 16 * 16;
+        b.cols_per_block = cpb;
+        b.n_colblocks = (int)((c->M + cpb - 1) / cpb);
+        const int64_t npairs = (ntiles + 1) / 2;  // a wave owns two adjacent column tiles
+        const int wgs = (int)std::min<int64_t>((npairs + 3) / 4, (int64_t)c->cus * 4);
+        b.n_waves = wgs * 4;
+    }
     TRY(dalloc(c, &b.slab, (size_t)b.n_colblocks * L16));
     b.n_regblocks = (int)((c->M + 15) / 16);
     TRY(dalloc(c, &b.regpart, (size_t)b.n_regblocks * CB));
-    const int64_t ntiles = (c->M + 15) / 16;
-    const int64_t npairs = (ntiles + 1) / 2;  // a wave owns two adjacent column tiles
-    const int wgs = (int)std::min<int64_t>((npairs + 3) / 4, (int64_t)c->cus * 4);
-    b.n_waves = wgs * 4;
     TRY(dalloc(c, &b.pp_part, (size_t)b.n_waves * CB));
     b.n_pp0 = (int)std::min<int64_t>(512, (c->M + 15) / 16);
     TRY(dalloc(c, &b.pp0_part, (size_t)b.n_pp0 * CB));
     HIPCHK(c, hipHostMalloc((void **)&b.h, sizeof(double) * (size_t)(CB * 4 + (b.n_waves + 2 * b.n_pp0) * CB)));
     // the adjoint GEMM wants G in MFMA operand order; 288 GB of HBM usually has room for the
     // second copy (C2: 40 GB + 40 GB).  Without it the kernel reads the column-major matrix.
-    if (env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
+    if (!c->mf && env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
         size_t free_b = 0, total_b = 0;
         const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)2 << 30)) {
@@ -88,19 +251,23 @@ static int batch_time_end(gh_ctx *c, bool timed)
 static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, double *Rt, double *scal = nullptr)
 {
     gh_ctx::Batch &b = c->bt;
-    BatchFwdArgs f;
-    f.G = c->G;
-    f.ld = c->ld;
-    f.M = c->M;
-    f.N = c->N;
-    f.X = X;
-    f.cols_per_block = b.cols_per_block;
-    f.slab = b.slab;
     bool timed;
-    TRY(batch_time_begin(c, timed));
-    batch_forward_kernel<<<dim3((unsigned)((c->ld + 511) / 512), (unsigned)b.n_colblocks), dim3(256), 0,
-                           c->stream>>>(f);
-    TRY(batch_time_end(c, timed));
+    if (c->mf) {
+        TRY(mfb_forward(c, X));
+    } else {
+        BatchFwdArgs f;
+        f.G = c->G;
+        f.ld = c->ld;
+        f.M = c->M;
+        f.N = c->N;
+        f.X = X;
+        f.cols_per_block = b.cols_per_block;
+        f.slab = b.slab;
+        TRY(batch_time_begin(c, timed));
+        batch_forward_kernel<<<dim3((unsigned)((c->ld + 511) / 512), (unsigned)b.n_colblocks), dim3(256), 0,
+                               c->stream>>>(f);
+        TRY(batch_time_end(c, timed));
+    }
     const int64_t n16 = c->ld * CB;
     batch_reduce_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.slab, b.n_colblocks,
                                                                                         n16, D);
@@ -151,6 +318,12 @@ static int batch_init_mfma(gh_ctx *c, int C, const double *x0s)
     TRY(batch_alloc(c));
     gh_ctx::Batch &b = c->bt;
     b.C = C;
+    if (c->mf) {
+        // 1 / wm as the single-chain passes round it (x * (1.0 / w); 1 where w == 0 or not weighted)
+        mfb_invw_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
+            c->weighted ? c->wm : nullptr, c->M, b.iw);
+        HIPCHK(c, hipGetLastError());
+    }
     TRY(batch_upload_rows(c, x0s, C, b.Xc));
     TRY(batch_evaluate(c, b.Xc, b.Dc, b.GREGc, b.Rtc));
     TRY(d2h(c, b.h, b.scal, CB * 4));

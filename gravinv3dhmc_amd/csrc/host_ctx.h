@@ -172,6 +172,13 @@ struct gh_ctx {
         // proposal's values survive a speculative first step) and the next trajectories' momenta
         double *GREGw2 = nullptr, *Dw2 = nullptr, *Rtw2 = nullptr, *scal2 = nullptr, *Pn = nullptr, *pn0_part = nullptr;
         double *Gb = nullptr;     // second copy of G in MFMA operand order (adjoint), if HBM allows
+        // matrix-free batch (mfbatch.hip.h): 1 / wm, the near-field pairs as differences to the staged
+        // root leaf (column-major: mf_near_ptr / mf_near_row / ndelta; row-major copy: rptr / rcol / rdelta)
+        double *iw = nullptr, *Snear = nullptr, *ndelta = nullptr, *rdelta = nullptr;
+        int64_t *rptr = nullptr;
+        int *rcol = nullptr;
+        bool mfb_near = false;
+        int mfb_grid_adj = 0, mfb_rchunks = 0, mfb_ranges = 0, mfb_tpr = 0;
         double *h = nullptr;      // pinned
         int n_colblocks = 0, n_regblocks = 0, n_waves = 0, n_pp0 = 0;
         int64_t cols_per_block = 0;

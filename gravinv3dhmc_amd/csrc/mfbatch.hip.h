@@ -1,0 +1,422 @@
+// Several HMC chains on the matrix-free kernel: every evaluated entry serves all chains (gfx950).
+//
+// BASELINE configs[3] is "matrix-free, 8 chains per node x 8 GPUs" (example/global/run_main.sh:16,
+// inversion/hmc.py:367-369: the reference runs its chains as separate MPI ranks, each re-evaluating
+// the whole tesseroid kernel, gravmag/_tesseroid_numba.py:32-71).  The single-chain matrix-free
+// pass (mf_tess_fast_kernel / mf_fused_kernel) is bound by evaluating the entries (~127 VALU
+// instructions each), not by using them (2 FMAs).  With C <= 16 chains in lock step the two
+// products of a potential evaluation are skinny GEMMs whose G operand is computed on the fly,
+//     S (M x 16) = K^T (M x N) . R (N x 16)       adjoint of all chains + leapfrog update
+//     D (N x 16) = K   (N x M) . XS (M x 16)      forward of all chains, XS = X / wm
+// and v_mfma_f64_16x16x4 does the per-chain work: a pass costs the same for 1 or 16 chains.
+//
+// The one-evaluation fusion of the single-chain pass (a workgroup keeps a column between the dot
+// and the axpy) does not carry over: between the dot and the axpy sits the update, which needs the
+// dot over ALL rows, and the per-workgroup state (C x N residuals + C x N forward partials) no
+// longer fits one CU.  So the batch evaluates every entry twice per step -- for ALL chains.
+//
+// Both passes share the evaluation phase: a workgroup of 16 waves stages a tile of 16 columns x 512
+// rows in LDS, wave w evaluating column w of the tile with the lane = row layout and the column's
+// constants in scalar registers (the single-chain pass's arithmetic: tess_leaf_fast / tess_leaf_cc
+// / tess_entry_cc / prism_entry, unchanged).  Two staging buffers: the next chunk is evaluated
+// while the MFMAs consume this one, one barrier per chunk.
+//   adjoint: workgroup = column tile, all rows in chunks; lane (lo, k) feeds A[col lo][row group k]
+//            from the staged tile (16-byte LDS reads), B from the patch-transposed residuals Rt of
+//            batch.hip.h; the 16 waves' accumulators are summed through LDS in wave order, then
+//            256 threads apply the leapfrog update of the 16 x 16 (cell, chain) pairs.
+//   forward: workgroup = 512-row chunk x range of column tiles; wave w owns row patches 2w, 2w+1
+//            of the chunk (two accumulator tiles), A[row lo][col k] from the staged tile, B = XS.
+// Every sum has a fixed order: results are reproducible bit for bit.
+//
+// Tesseroids with the near-field table (KIND 2, 3): the staged value of EVERY pair is its root
+// leaf; the listed pairs contribute their difference delta = entry - root leaf through two small
+// sparse kernels (column-major list for the adjoint, row-major copy for the forward), so the
+// dense passes have no test, no branch and no scattered LDS writes.
+#pragma once
+
+namespace ghk {
+
+constexpr int MFB_WAVES = 16;             // waves per workgroup = columns of a tile
+constexpr int MFB_RC = 8;                 // row blocks of 64 per staged chunk
+constexpr int MFB_ROWS = MFB_RC * 64;     // 512 rows
+constexpr int MFB_PATCHES = MFB_ROWS / 16;
+// column stride of the staged tile (doubles): +8 shifts consecutive columns by 64 B, so the
+// adjoint's 16-byte reads (16 columns x 4 row groups) and the forward's 8-byte reads (4 columns x
+// 16 rows) both spread over all LDS banks
+constexpr int MFB_S = MFB_ROWS + 8;
+constexpr size_t MFB_LDS = 2 * (size_t)MFB_WAVES * MFB_S * sizeof(double);  // 133120 B
+
+// the column's constants in (scalar) registers
+template <int KIND>
+struct MfbCol {
+    double cc[KIND == 0 ? 1 : TESS_NC];
+    double b[KIND == 0 ? 6 : 1];
+    const double *ccp, *bp;  // KIND 1: the generic engine takes pointers
+};
+
+template <int KIND>
+__device__ __forceinline__ void mfb_col_load(MfbCol<KIND> &c, const MfGeom &g, const double *cellc, int64_t j)
+{
+    if constexpr (KIND == 0) {
+        const kconst_ptr bk = as_kconst(g.bounds6) + 6 * j;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) c.b[q] = bk[q];
+        c.ccp = c.bp = nullptr;
+    } else {
+        const kconst_ptr ck = as_kconst(cellc) + (int64_t)TESS_NC * j;
+        constexpr int Q0 = KIND == 3 ? 10 : (KIND == 2 ? 8 : 0);
+        constexpr int Q1 = KIND == 3 ? TESS_NC : 23;
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) c.cc[q] = ck[q];
+        c.ccp = cellc + (int64_t)TESS_NC * j;
+        c.bp = g.bounds6 + 6 * j;
+    }
+}
+
+// observation constants of one row: KIND 0: x, y, z; 1, 2: lon, sin lat, cos lat, radius;
+// 3: sin lon, cos lon, sin lat, cos lat, radius.  Unconditional loads at a clamped 32-bit byte
+// offset from the uniform bases (rows past the end re-read the last row).
+template <int KIND>
+__device__ __forceinline__ void mfb_obs_load(double (&o)[5], const MfGeom &g, unsigned oc)
+{
+    auto at = [&](const double *base) { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + oc); };
+    if constexpr (KIND == 0) {
+        o[0] = at(g.o0);
+        o[1] = at(g.o1);
+        o[2] = at(g.o2);
+        o[3] = o[4] = 0.0;
+    } else if constexpr (KIND == 3) {
+        o[0] = at(g.o4);
+        o[1] = at(g.o5);
+        o[2] = at(g.o1);
+        o[3] = at(g.o2);
+        o[4] = at(g.o3);
+    } else {
+        o[0] = at(g.o0);
+        o[1] = at(g.o1);
+        o[2] = at(g.o2);
+        o[3] = at(g.o3);
+        o[4] = 0.0;
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ double mfb_eval(const MfbCol<KIND> &c, const MfGeom &g, const double (&o)[5], unsigned &nleaf)
+{
+    if constexpr (KIND == 0) {
+        nleaf += 1;
+        return prism_entry(o[0], o[1], o[2], c.b);
+    } else if constexpr (KIND == 1) {
+        return tess_entry_cc(o[0], o[1], o[2], o[3], c.ccp, c.bp, g.ratio, nleaf);
+    } else if constexpr (KIND == 2) {
+        nleaf += 1;
+        return tess_leaf_cc(o[0], o[1], o[2], o[3], c.cc);
+    } else {
+        nleaf += 1;
+        return tess_leaf_fast(o[0], o[1], o[2], o[3], o[4], c.cc);
+    }
+}
+
+// One wave stages its column for `nb` row blocks starting at row block rb0: st[e * 64 + lane].
+// The observation constants of the next block are in flight while this one is evaluated.
+template <int KIND>
+__device__ __forceinline__ void mfb_stage(const MfbCol<KIND> &col, const MfGeom &g, int rb0, int nb, int lane,
+                                          double *st, unsigned &nleaf, unsigned &nent)
+{
+    const unsigned olast = (unsigned)(g.N - 1) * (unsigned)sizeof(double);
+    unsigned off = ((unsigned)rb0 * 64u + (unsigned)lane) * (unsigned)sizeof(double);
+    double oa[5], ob[5];
+    {
+        unsigned oc = off < olast ? off : olast;
+        mfb_obs_load<KIND>(oa, g, oc);
+    }
+#pragma unroll 1
+    for (int e = 0; e < nb; e += 2) {
+        {
+            off += 64u * (unsigned)sizeof(double);
+            unsigned oc = off < olast ? off : olast;
+            asm volatile("" : "+v"(oc));
+            mfb_obs_load<KIND>(ob, g, oc);
+        }
+        st[e * 64 + lane] = mfb_eval<KIND>(col, g, oa, nleaf);
+        nent += 1;
+        if (e + 1 >= nb) break;
+        {
+            off += 64u * (unsigned)sizeof(double);
+            unsigned oc = off < olast ? off : olast;
+            asm volatile("" : "+v"(oc));
+            mfb_obs_load<KIND>(oa, g, oc);
+        }
+        st[(e + 1) * 64 + lane] = mfb_eval<KIND>(col, g, ob, nleaf);
+        nent += 1;
+    }
+}
+
+__device__ __forceinline__ void mfb_count(MfStats *stats, unsigned nent, unsigned nleaf, int lane)
+{
+    if (!stats) return;
+    unsigned long long e = nent, l = nleaf;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        e += __shfl_xor(e, off, WAVE);
+        l += __shfl_xor(l, off, WAVE);
+    }
+    if (lane == 0) {
+        atomicAdd(&stats->entries, e);
+        atomicAdd(&stats->leaves, l);
+    }
+}
+
+// ---- adjoint of all chains + leapfrog update (hmc.py:114-152) ------------------------------------
+// BatchAdjArgs as batch_adjoint_kernel (G / Gb unused); iw = 1 / wm (1 where wm == 0), Snear =
+// near-field part of S (M x 16) or nullptr; pp_part has gridDim.x x 16 entries.
+template <int KIND>
+__global__ void __launch_bounds__(1024)
+mfb_adjoint_kernel(MfGeom g, BatchAdjArgs a, const double *__restrict__ iw, const double *__restrict__ cellc,
+                   const double *__restrict__ Snear, MfStats *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double ppred[16][17];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, k = lane >> 4;
+    const int64_t ntiles = (a.M + 15) / 16;
+    const int nrb = (int)((a.ld + 63) / 64);
+    const int nch = (nrb + MFB_RC - 1) / MFB_RC;
+    const d2 *rt = reinterpret_cast<const d2 *>(a.Rt) + (k * 16 + lo);
+    double pp = 0.0;
+    unsigned nent = 0, nleaf = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t j = tile * 16 + wave;
+        if (j >= a.M) j = a.M - 1;
+        MfbCol<KIND> col;
+        mfb_col_load<KIND>(col, g, cellc, j);
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        for (int ch = 0; ch < nch; ++ch) {
+            double *buf = smem + (size_t)(ch & 1) * (MFB_WAVES * MFB_S);
+            const int rb0 = ch * MFB_RC;
+            const int nb = nrb - rb0 < MFB_RC ? nrb - rb0 : MFB_RC;
+            mfb_stage<KIND>(col, g, rb0, nb, lane, buf + wave * MFB_S, nleaf, nent);
+            __syncthreads();
+            const double *sr = buf + lo * MFB_S;
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+                const int p = 2 * wave + pq;
+                const int gp = ch * MFB_PATCHES + p;
+                if (gp < a.np) {
+                    const d2 a0 = *reinterpret_cast<const d2 *>(sr + 16 * p + 2 * k);
+                    const d2 a1 = *reinterpret_cast<const d2 *>(sr + 16 * p + 8 + 2 * k);
+                    const d2 r0 = rt[128 * gp], r1 = rt[128 * gp + 64];
+                    acc = mfma_f64(a0.x, r0.x, acc);
+                    acc = mfma_f64(a0.y, r0.y, acc);
+                    acc = mfma_f64(a1.x, r1.x, acc);
+                    acc = mfma_f64(a1.y, r1.y, acc);
+                }
+            }
+        }
+        // the waves' accumulators through the staging buffer nobody reads any more, in wave order
+        double *red = smem + (size_t)(nch & 1) * (MFB_WAVES * MFB_S);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave * 256 + q * 64 + lane] = acc[q];
+        __syncthreads();
+        if (tid < 256) {
+            // acc[q] of lane (lo, k): column k + 4 q of the tile, chain lo
+            const int cl = tid >> 4, c = tid & 15;
+            const int ridx = (cl >> 2) * 64 + (cl & 3) * 16 + c;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < MFB_WAVES; ++w) s += red[w * 256 + ridx];
+            const int64_t jc = tile * 16 + cl;
+            if (jc < a.M) {
+                const int64_t idx = jc * CB + c;
+                if (Snear) s += Snear[idx];
+                s = s * iw[jc];
+                const int ph = a.phase[c];
+                const double gr = 2.0 * s + (a.GREG ? a.GREG[idx] : 0.0);
+                if (ph == PH_GOUT) {
+                    a.G_out[idx] = gr;
+                } else if (ph == PH_UPD) {
+                    double pj = a.P_in[idx] - a.cu[c] * gr;
+                    double xj = a.X_in[idx] + a.dt * pj;
+                    const double hi = a.high[jc], lw = a.low[jc];
+                    if (xj > hi) {
+                        xj = hi;
+                        pj = -pj;
+                    } else if (xj < lw) {
+                        xj = lw;
+                        pj = -pj;
+                    }
+                    a.P_out[idx] = pj;
+                    a.X_out[idx] = xj;
+                } else if (ph == PH_PFIN) {
+                    const double pf = a.P_in[idx] - a.cp[c] * gr;
+                    pp += pf * pf;
+                    a.P_out[idx] = pf;
+                    a.X_out[idx] = a.X_in[idx];
+                } else if (ph == PH_PFIN_SPEC) {
+                    const double pf = a.P_in[idx] - a.cp[c] * gr;
+                    pp += pf * pf;
+                    double pj = a.Pn[idx] - a.cu[c] * gr;
+                    double xj = a.X_in[idx] + a.dt * pj;
+                    const double hi = a.high[jc], lw = a.low[jc];
+                    if (xj > hi) {
+                        xj = hi;
+                        pj = -pj;
+                    } else if (xj < lw) {
+                        xj = lw;
+                        pj = -pj;
+                    }
+                    a.P_out[idx] = pj;
+                    a.X_out[idx] = xj;
+                } else {
+                    a.P_out[idx] = a.P_in[idx];
+                    a.X_out[idx] = a.X_in[idx];
+                }
+            }
+        }
+        __syncthreads();  // (the reduction buffer is the next tile's first staging buffer when nch is even)
+    }
+    if (tid < 256) ppred[tid >> 4][tid & 15] = pp;
+    __syncthreads();
+    if (a.pp_part && tid < 16 && (a.phase[tid] == PH_PFIN || a.phase[tid] == PH_PFIN_SPEC)) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += ppred[r][tid];
+        a.pp_part[(int64_t)blockIdx.x * CB + tid] = t;
+    }
+    mfb_count(stats, nent, nleaf, lane);
+}
+
+// ---- forward of all chains --------------------------------------------------------------------
+struct MfbFwdArgs {
+    int64_t ld, M;
+    const double *X;   // M x 16
+    const double *iw;  // M: 1 / wm (1 where wm == 0 or the kernel is not weighted)
+    int tiles_per_range;
+    double *slab;      // gridDim.y x (ld x 16)
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(1024)
+mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfStats *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, k = lane >> 4;
+    const int64_t ntiles = (a.M + 15) / 16;
+    const int nrb = (int)((a.ld + 63) / 64);
+    const int rb0 = blockIdx.x * MFB_RC;
+    const int nb = nrb - rb0 < MFB_RC ? nrb - rb0 : MFB_RC;
+    const int64_t t0 = (int64_t)blockIdx.y * a.tiles_per_range;
+    int64_t t1 = t0 + a.tiles_per_range;
+    if (t1 > ntiles) t1 = ntiles;
+    d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    unsigned nent = 0, nleaf = 0;
+    int it = 0;
+    for (int64_t tile = t0; tile < t1; ++tile, ++it) {
+        int64_t j = tile * 16 + wave;
+        if (j >= a.M) j = a.M - 1;
+        MfbCol<KIND> col;
+        mfb_col_load<KIND>(col, g, cellc, j);
+        double *buf = smem + (size_t)(it & 1) * (MFB_WAVES * MFB_S);
+        // this tile's XS fragments: lane (lo, k) feeds column 4 u + k, chain lo
+        double xs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t jj = tile * 16 + 4 * u + k;
+            const bool ok = jj < a.M;
+            const int64_t jc = ok ? jj : a.M - 1;
+            const double v = a.X[jc * CB + lo] * a.iw[jc];
+            xs[u] = ok ? v : 0.0;
+        }
+        mfb_stage<KIND>(col, g, rb0, nb, lane, buf + wave * MFB_S, nleaf, nent);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *sa = buf + (4 * u + k) * MFB_S + lo;
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) acc[pq] = mfma_f64(sa[16 * (2 * wave + pq)], xs[u], acc[pq]);
+        }
+    }
+    // acc[pq][q] of lane (lo, k): row 16 (2 wave + pq) + k + 4 q of the chunk, chain lo
+    double *out = a.slab + (int64_t)blockIdx.y * a.ld * CB;
+#pragma unroll
+    for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = (int64_t)rb0 * 64 + 16 * (2 * wave + pq) + k + 4 * q;
+            if (row < a.ld) out[row * CB + lo] = acc[pq][q];
+        }
+    mfb_count(stats, nent, nleaf, lane);
+}
+
+// ---- near-field list as differences ---------------------------------------------------------------
+// delta[q] = val[q] - (the root leaf the dense passes stage for that pair), column-major order
+template <int KIND>
+__global__ void __launch_bounds__(256)
+mfb_near_delta_kernel(MfGeom g, const double *__restrict__ cellc, MfNear near, int64_t n, const int *__restrict__ colof,
+                      double *__restrict__ delta)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const int64_t i = near.row[q], j = colof[q];
+    const double *cc = cellc + (int64_t)TESS_NC * j;
+    double leaf;
+    if constexpr (KIND == 3)
+        leaf = tess_leaf_fast(g.o4[i], g.o5[i], g.o1[i], g.o2[i], g.o3[i], cc);
+    else
+        leaf = tess_leaf_cc(g.o0[i], g.o1[i], g.o2[i], g.o3[i], cc);
+    delta[q] = near.val[q] - leaf;
+}
+
+// offset of residual (row i, chain c) in the patch-transposed layout of batch.hip.h
+__device__ __forceinline__ int64_t rt_offset(int64_t i, int c)
+{
+    const int64_t p = i >> 4, q = i & 15;
+    return (((p * 2 + (q >> 3)) * 4 + ((q & 7) >> 1)) * CB + c) * 2 + (q & 1);
+}
+
+// Snear[j][c] = sum over the listed rows of column j of delta * r_c[row] (rows ascending)
+__global__ void __launch_bounds__(256)
+mfb_near_adjoint_kernel(const int64_t *__restrict__ ptr, const int *__restrict__ row, const double *__restrict__ delta,
+                        int64_t M, const double *__restrict__ Rt, double *__restrict__ Snear)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * CB) return;
+    const int c = (int)(t & 15);
+    const int64_t j = t >> 4;
+    double s = 0.0;
+    for (int64_t q = ptr[j]; q < ptr[j + 1]; ++q) s += delta[q] * Rt[rt_offset(row[q], c)];
+    Snear[t] = s;
+}
+
+// out[i][c] = sum over the listed columns of row i of delta * XS[col][c] (columns ascending); one
+// more block of the forward slab
+__global__ void __launch_bounds__(256)
+mfb_near_forward_kernel(const int64_t *__restrict__ rptr, const int *__restrict__ rcol, const double *__restrict__ rdelta,
+                        int64_t N, int64_t ld, const double *__restrict__ X, const double *__restrict__ iw,
+                        double *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ld * CB) return;
+    const int c = (int)(t & 15);
+    const int64_t i = t >> 4;
+    double s = 0.0;
+    if (i < N)
+        for (int64_t q = rptr[i]; q < rptr[i + 1]; ++q) {
+            const int64_t j = rcol[q];
+            s += rdelta[q] * (X[j * CB + c] * iw[j]);
+        }
+    out[t] = s;
+}
+
+__global__ void __launch_bounds__(256) mfb_invw_kernel(const double *wm, int64_t M, double *iw)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    const double w = wm ? wm[j] : 1.0;
+    iw[j] = (w != 0.0) ? 1.0 / w : 1.0;
+}
+
+}  // namespace ghk

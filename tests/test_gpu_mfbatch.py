@@ -1,0 +1,188 @@
+"""Several chains per GPU on the MATRIX-FREE kernel (csrc/mfbatch.hip.h): every entry evaluated by a
+pass serves all chains (BASELINE configs[3]: "matrix-free ... 8 chains"; the reference runs its chains
+as separate MPI ranks, example/global/run_main.sh:16, inversion/hmc.py:367-369, each re-evaluating
+gravmag/_tesseroid_numba.py:32-71 by itself).  Every chain of the batch must reproduce a single-chain
+matrix-free context fed the same momenta / lengths / variates, with identical Metropolis decisions."""
+import numpy as np
+import pytest
+
+from helpers import relmax
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(built_lib):
+    import gravinv3dhmc_amd as g
+    return g
+
+
+def _tess_problem(G):
+    """A coarse global tesseroid model with more rows than one staged chunk (512) and neither N a
+    multiple of 64 nor M a multiple of 16; big cells under low observations: a rich near field."""
+    mesh = G.mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-600000, 10, 10))
+    lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 6.0), np.arange(-87, 88, 6.0), indexing="ij")]
+    h = np.full_like(lon, 20000.0)
+    b = mesh.cell_bounds()[:-7]             # M = 3233: the last column tile is partial
+    return (lon, lat, h), b, 1, (1, 1, b.shape[0])
+
+
+def _prism_problem(G):
+    rng = np.random.default_rng(3)
+    N = 1100
+    xp, yp = rng.uniform(0, 2000, N), rng.uniform(0, 3000, N)
+    mesh = G.mesher.PrismMesh((0, 2000, 0, 3000, 0, 1000), (100, 250, 250))
+    b = mesh.cell_bounds()[:-5]
+    return (xp, yp, np.zeros(N)), b, 0, (1, 1, b.shape[0])
+
+
+CASES = {
+    # name: (problem, GRAVHMC_MF_EXACT, GRAVHMC_MF_NEAR, regulariser)
+    "tess_fast_leaf_near_table": (_tess_problem, "0", "1", "Damping"),
+    "tess_reference_order_near_table": (_tess_problem, "1", "1", "MS"),
+    "tess_subdivision_inside_the_pass": (_tess_problem, "0", "0", "Damping"),
+    "prisms": (_prism_problem, "0", "1", "MS"),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case):
+    problem, exact, near, reg = CASES[case]
+    monkeypatch.setenv("GRAVHMC_MF_EXACT", exact)
+    monkeypatch.setenv("GRAVHMC_MF_NEAR", near)
+    obs, bounds, kind, shape = problem(G)
+    N, M = obs[0].size, bounds.shape[0]
+    rng = np.random.default_rng(5)
+    rho = rng.uniform(0.0, 0.5, M)
+
+    def make(matrix_free=True):
+        e = G.Engine(N, M)
+        e.set_matrix_free(matrix_free)
+        e.set_obs(*obs)
+        e.set_cells(bounds, kind, 1.6)
+        e.build_G()
+        return e
+
+    eb = make()
+    d_true = eb.forward(rho)
+    wm = eb.weight(0.5)
+    dobs = d_true + 0.02 * np.abs(d_true).max() * rng.normal(size=N)
+
+    def finish(e, weighted=True):
+        if not weighted:
+            e.weight(0.5)
+        e.set_data(dobs)
+        e.set_reg(reg, 0.05, 0.01, shape, 0.001 * wm)
+        return e
+
+    finish(eb)
+    st = eb.matrix_free_stats()
+    if kind == 1:
+        assert (st["near_entries"] > 0) == (near == "1"), st
+    C, dt, sig = 5, 0.005, 0.002
+    low, high = 0.0 * wm, 0.8 * wm
+    x0s = np.stack([(0.001 + 0.05 * c) * wm for c in range(C)])
+    eb.batch_init(x0s, low, high)
+    # the dense engine's potential at the chains' starting points: the batch's own evaluation
+    ed = finish(make(False), weighted=False)
+    singles = []
+    for c in range(C):
+        e = finish(make(), weighted=False)
+        e.chain_init(x0s[c], low, high)
+        singles.append(e)
+    n_acc = n_rej = 0
+    worst = 0.0
+    for it in range(3):
+        Ls = rng.integers(1, 6, size=C)
+        p0s = rng.normal(size=(C, M)) * sig
+        us = rng.uniform(size=C) * (0.05 if it == 1 else 1.0)
+        acc, out5 = eb.batch_trajectory(p0s, dt, Ls, us)
+        for c in range(C):
+            a1, o1 = singles[c].chain_trajectory(p0s[c], dt, int(Ls[c]), float(us[c]))
+            assert a1 == acc[c], (case, it, c, o1, out5[c])
+            worst = max(worst, relmax(out5[c], o1), relmax(eb.batch_get_x(c), singles[c].chain_get_x()))
+            n_acc += a1
+            n_rej += not a1
+    print("matrix-free batch [%s]: N %d M %d, %d chains, accepted %d rejected %d, worst deviation from the "
+          "single-chain matrix-free engine %.2e; near field %r" % (case, N, M, C, n_acc, n_rej, worst, st))
+    assert worst < 1e-10 and n_acc > 0
+    # against the DENSE single-chain engine as well (stored G: the reference's formulation)
+    a = ed.misfit_and_grad(eb.batch_get_x(2))
+    b = singles[2].misfit_and_grad(singles[2].chain_get_x())
+    assert abs(a[0] - b[0]) < 1e-10 * abs(b[0]) and relmax(a[1], b[1]) < 1e-10
+    # desynchronised scheduling (gh_batch_run: a chain starts its next trajectory in the sweep after it
+    # finished the previous one; speculative first steps) computes what lock-step rounds compute
+    T = 3
+    Ls = rng.integers(1, 6, size=(C, T))
+    p0s = rng.normal(size=(C, T, M)) * sig
+    us = rng.uniform(size=(C, T))
+    acc_a, out_a, xs_a = eb.batch_run(p0s, dt, Ls, us, want_x=True)
+    for t in range(T):
+        for c in range(C):
+            a1, o1 = singles[c].chain_trajectory(p0s[c, t], dt, int(Ls[c, t]), float(us[c, t]))
+            assert bool(a1) == bool(acc_a[c, t]), (case, c, t)
+            assert relmax(out_a[c, t], o1) < 1e-10
+            if a1:
+                assert relmax(xs_a[c, t], singles[c].chain_get_x()) < 1e-10
+    for c in range(C):
+        assert relmax(eb.batch_get_x(c), singles[c].chain_get_x()) < 1e-10
+    for e in singles + [eb, ed]:
+        e.close()
+
+
+def test_c4_matrix_free_eight_chains_full_size(G):
+    """BASELINE configs[3] at full size on one GPU: the 7381 x 72000 global tesseroid model, matrix-free,
+    EIGHT chains sharing every evaluated entry, against the single-chain matrix-free engine (chains 0, 3
+    and 7 re-run one by one) and -- potential and gradient at the final states -- the dense engine."""
+    mesh = G.mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))
+    lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 3.0), np.arange(-90, 91, 3.0), indexing="ij")]
+    h = np.full_like(lon, 5000.0)
+    N, M = lon.size, mesh.size
+    rho = np.zeros(mesh.shape)
+    rho[1:4, 20:30, 40:60] = 0.3
+    rho = rho.ravel()
+    rng = np.random.default_rng(45)
+
+    def make(matrix_free):
+        e = G.Engine(N, M)
+        e.set_matrix_free(matrix_free)
+        e.set_obs(lon, lat, h)
+        e.set_cells(mesh.cell_bounds(), 1, 1.6)
+        e.build_G()
+        return e
+
+    eb, es, ed = make(True), make(True), make(False)
+    dtrue = ed.forward(rho)
+    wm = ed.weight(0.5)
+    assert relmax(eb.weight(0.5), wm) < 1e-12 and relmax(es.weight(0.5), wm) < 1e-12
+    dobs = dtrue + 0.02 * np.abs(dtrue).max() * rng.normal(size=N)
+    for e in (eb, es, ed):
+        e.set_data(dobs)
+        e.set_reg("Damping", 0.05, 0.01, mesh.shape, 0.001 * wm)
+    C, dt = 8, 0.005
+    low, high = 0.0 * wm, 0.8 * wm
+    x0s = np.stack([(0.001 + 0.01 * c) * wm for c in range(C)])
+    eb.batch_init(x0s, low, high)
+    rounds = []
+    for it in range(2):
+        Ls = rng.integers(2, 6, size=C)
+        p0s = rng.normal(size=(C, M)) * 0.001
+        us = rng.uniform(size=C)
+        acc, out5 = eb.batch_trajectory(p0s, dt, Ls, us)
+        rounds.append((Ls, p0s, us, acc.copy(), out5.copy()))
+    worst = 0.0
+    for c in (0, 3, 7):
+        es.chain_init(x0s[c], low, high)
+        for (Ls, p0s, us, acc, out5) in rounds:
+            a1, o1 = es.chain_trajectory(p0s[c], dt, int(Ls[c]), float(us[c]))
+            assert a1 == acc[c], (c, o1, out5[c])
+            worst = max(worst, relmax(out5[c], o1))
+        xb = eb.batch_get_x(c)
+        worst = max(worst, relmax(xb, es.chain_get_x()))
+        a, b = es.misfit_and_grad(xb), ed.misfit_and_grad(xb)
+        assert abs(a[0] - b[0]) < 1e-10 * abs(b[0]) and relmax(a[1], b[1]) < 1e-10
+    print("C4 matrix-free, 8 chains per GPU vs the single-chain matrix-free engine: worst %.2e, accepted %d of %d"
+          % (worst, sum(int(r[3].sum()) for r in rounds), 2 * C))
+    assert worst < 1e-10
+    for e in (eb, es, ed):
+        e.close()
