@@ -364,6 +364,21 @@ def c1_block(device, want_cpu):
     return out
 
 
+def launch_ranks(n, argv):
+    """One process per GPU through torch.distributed.run on 127.0.0.1 (a free port), the command the
+    driver itself uses for N > 1; stdout / stderr pass through, the return code is the launcher's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +395,8 @@ def main():
     ap.add_argument("--matrix-free", action="store_true",
                     help="never store G: re-evaluate the kernel entries in every pass")
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
+    ap.add_argument("--seed", type=int, default=100,
+                    help="np.random.seed of the chain of rank 0; rank r takes seed + r (hmc.py:369)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra block (C1, north_star's target configuration) of the default line")
@@ -392,15 +409,21 @@ def main():
                     help="all ranks share GPU 0 (rehearsal of the N>1 launch path on a 1-GPU box)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver types it for N = 1: start the N ranks ourselves, as
+        # CHILD processes of a parent that has not touched the GPU (no HIP call, no library load so
+        # far; never an exec of a process that has), relay rank 0's JSON line, exit with their status.
+        # The reference's counterpart is `mpiexec -n K python main_*.py` (example/uniformgrid/run_main.sh:17).
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     # control plane only (barrier + max of the elapsed time): the chains are independent, so
     # no tensor of the data path ever crosses ranks.  gloo on CPU tensors keeps torch's own HIP
     # runtime out of the process (gravinv3dhmc_amd/dist.py, covered by tests/test_dist_gloo.py).
     from gravinv3dhmc_amd.dist import Ranks
     ranks = Ranks()
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                 "--nproc-per-node %d" % (args.gpus, args.gpus))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d runs under a launcher with WORLD_SIZE = %d" % (args.gpus, world))
 
     import gravinv3dhmc_amd as g
     extra = EXTRA.get(args.workload)
@@ -450,7 +473,7 @@ def main():
         # ---- several chains per GPU: one RandomState per chain (seed 100 + global chain index,
         # the stream np.random.seed gives the reference's rank), lock-step rounds of L steps
         from concurrent.futures import ThreadPoolExecutor
-        rs = [np.random.RandomState(100 + rank * CPG + k) for k in range(CPG)]
+        rs = [np.random.RandomState(args.seed + rank * CPG + k) for k in range(CPG)]
         pool = ThreadPoolExecutor(max_workers=CPG)
         x0s = np.stack([0.001 * wm for _ in range(CPG)])
         eng.batch_init(x0s, low, high)
@@ -516,7 +539,7 @@ def main():
         # the reference's RNG stream (legacy global generator), one chain per rank (a sharded chain
         # shares one stream)
         elapsed, naccept, ntraj, prof = run_single_chain(eng, M, Sigma, dt, L, args.steps, args.warmup,
-                                                         100 if args.shard else 100 + rank, barrier)
+                                                         args.seed if args.shard else args.seed + rank, barrier)
     if CPG > 1:
         prof = eng.profile_read()
         eng.profile_enable(False)
@@ -525,6 +548,7 @@ def main():
     if not args.matrix_free and int(N) * int(M) * 8 >= (1 << 30):
         stream_gbps = eng.stream_read_gbps(nt=True, reps=3)
     elapsed = ranks.max(elapsed)
+    final_U_ranks = ranks.gather(LAST_STATE["U"])      # rank 0: every rank's chain state, in rank order
 
     if rank == 0:
         traffic, traffic_src = pmc_traffic(args.workload)
@@ -545,6 +569,8 @@ def main():
                        "matrix_free": bool(args.matrix_free), "wavelet_nnz": nnz,
                        "chains_per_gpu": CPG, "dt": dt, "traj_len": L, "trajectories": ntraj,
                        "accepted": naccept, "final_U": LAST_STATE["U"] if CPG == 1 else None,
+                       "final_U_per_rank": final_U_ranks if CPG == 1 and world > 1 else None,
+                       "seed": args.seed,
                        "speculative_first_steps": eng.chain_stats() if CPG == 1 else None, "parallelism": ("1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step"
                                        % (world, args.shard_backend)) if args.shard
                        else "chain-parallel x%d (no collective)" % world,
@@ -563,6 +589,10 @@ def main():
                          "vs_stream_read_microbench": achieved / stream_gbps if stream_gbps else None},
         }
         cstat = eng.chain_stats()
+        if cstat.get("team_launches", 0) > 0:
+            # N > 16384: the timed launches were team sweeps (csrc/teamsweep.hip.h)
+            line["roofline"]["kernel"] = ("teamsweep_kernel (teams of %d workgroups share each column: fused "
+                                          "adjoint+update+forward, one read of G)" % cstat["team_members"])
         if cstat.get("resident_evaluations", 0) > 0:
             # G never left the chip: the figure below is what the reference formulation would have
             # had to read per second, not HBM traffic

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "gh_set_obs": (C.c_int, [_ctx, _dp, _dp, _dp]),
     "gh_set_cells": (C.c_int, [_ctx, _dp, C.c_int, C.c_double]),
     "gh_set_matrix_free": (C.c_int, [_ctx, C.c_int]),
+    "gh_set_matrix_free_exact": (C.c_int, [_ctx, C.c_int]),
     "gh_matrix_free_stats": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
                                        C.POINTER(_i64), C.POINTER(_i64)]),
     "gh_build_G": (C.c_int, [_ctx]),

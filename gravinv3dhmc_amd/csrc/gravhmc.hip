@@ -156,6 +156,14 @@ int gh_set_matrix_free(gh_ctx *c, int enable)
     return GH_OK;
 }
 
+int gh_set_matrix_free_exact(gh_ctx *c, int exact)
+{
+    if (!c) return GH_ERR_ARG;
+    if (c->have_G || c->slab) return fail(c, GH_ERR_ARG, "gh_set_matrix_free_exact: call before gh_build_G");
+    c->mf_exact_req = exact != 0 ? 1 : 0;
+    return GH_OK;
+}
+
 int gh_build_G(gh_ctx *c)
 {
     if (!c) return GH_ERR_ARG;
@@ -173,7 +181,7 @@ int gh_build_G(gh_ctx *c)
                 c->obs[0], c->obs[1], c->obs[2], N, c->tconv, c->tconv + N, c->tconv + 2 * N,
                 c->tconv + 3 * N, c->tconv + 4 * N, c->tconv + 5 * N);
             HIPCHK(c, hipGetLastError());
-            c->mf_exact = env_int("GRAVHMC_MF_EXACT", 0) != 0;
+            c->mf_exact = c->mf_exact_req >= 0 ? c->mf_exact_req != 0 : env_int("GRAVHMC_MF_EXACT", 0) != 0;
             {
                 // what depends on the cell alone, once per cell instead of once per (obs, cell) pair
                 TRY(dalloc(c, &c->mf_cellc, (size_t)c->M * TESS_NC, false));
@@ -629,9 +637,15 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     hipFree(count);
     if (rc != GH_OK) return rc;
     if (e != hipSuccess) return fail(c, GH_ERR_HIP, "gh_compress_wavelet: %s", hipGetErrorString(e));
+    // (a second compression of the same context -- other dims / levels / shape, other Mp -- gets fresh,
+    // zeroed scratch: the one-launch transform never writes the gaps of the packed layout and relies
+    // on their being zero; the old blocks stay in the allocation list until gh_destroy)
+    if (w.coeff_n != Mp) w.coeff = w.s1 = w.s2 = nullptr;
     TRY(dalloc(c, &w.coeff, (size_t)Mp));
     TRY(dalloc(c, &w.s1, (size_t)Mp));
     TRY(dalloc(c, &w.s2, (size_t)Mp));
+    w.coeff_n = Mp;
+    HIPCHK(c, hipMemsetAsync(w.coeff, 0, sizeof(double) * (size_t)Mp, c->stream));
     wavelet_plan_lds(c);
     w.on = true;
     w.F_valid = false;
@@ -870,18 +884,18 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
         HIPCHK(c, hipMemcpyAsync(h + 16 + 2 * nt + c->n_pp0, c->pn0_part, (size_t)c->n_pp0 * sizeof(double),
                                  hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    {
-        // a team sweep of this trajectory gave up (its workgroups were not all resident): nothing of
-        // the chain's current state was touched -- run the trajectory again, in row panels
-        bool failed = false;
-        TRY(team_failed(c, &failed));
-        if (failed) {
-            c->spec_valid = c->pn_valid = false;
-            const int rc = chain_trajectory_impl(c, p0, dt, L, u, p0_next, accepted, out5);
-            team_resume(c);
-            return rc;
-        }
-    }
+    // a team sweep of this trajectory gave up (its workgroups were not all resident): nothing of
+    // the chain's current state was touched -- run the trajectory again, in row panels.  Sharded
+    // chain: decided by all ranks together, below (the flag rides on the scalar all-reduce)
+    bool failed = false;
+    TRY(team_failed(c, &failed));
+    auto redo = [&]() -> int {
+        c->spec_valid = c->pn_valid = false;
+        const int rc = chain_trajectory_impl(c, p0, dt, L, u, p0_next, accepted, out5);
+        team_resume(c);
+        return rc;
+    };
+    if (failed && c->sh.kind == 0) return redo();
     if (pn_deferred) {
         double s = 0.0;
         for (int t = 0; t < c->n_pp0; ++t) s += h[16 + 2 * nt + c->n_pp0 + t];
@@ -896,8 +910,15 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
     double pn_pp0_g = pn_pp0;
     if (c->sh.kind != 0) {
         // kinetic energies are sums over cells: combine the ranks' parts (same bits everywhere)
-        double v[3] = {pp1, use_spec ? 0.0 : pp0, spec ? pn_pp0 : 0.0};
-        TRY(comm_allreduce_host(c, v, 3));
+        double v[4] = {pp1, use_spec ? 0.0 : pp0, spec ? pn_pp0 : 0.0, failed ? 1.0 : 0.0};
+        if (failed) v[0] = v[1] = v[2] = 0.0;  // (whatever the aborted sweeps left: not worth a NaN in the sum)
+        TRY(comm_allreduce_host(c, v, 4));
+        if (v[3] != 0.0) {
+            // some rank's team sweep gave up: its slab went into everybody's d and r through the
+            // all-reduces of this trajectory -- every rank repeats it, in row panels, together
+            if (!failed) TRY(team_mark_failed(c, "another rank's"));
+            return redo();
+        }
         pp1 = v[0];
         if (!use_spec) pp0 = v[1];
         pn_pp0_g = v[2];

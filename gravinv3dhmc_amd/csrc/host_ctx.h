@@ -40,7 +40,8 @@ struct gh_ctx {
     // tesseroids: near-field table (pairs that need the adaptive subdivision: evaluated once, kept)
     bool mf_near_on = false;
     bool mf_pipe = false;    // mf_tess_fast_kernel (next column's constants fetched ahead; r and the column in LDS)
-    bool mf_exact = false;   // GRAVHMC_MF_EXACT=1: the root leaf in the reference's operation order (tess_leaf_cc)
+    bool mf_exact = false;   // the root leaf in the reference's operation order (tess_leaf_cc) instead of tess_leaf_fast
+    int mf_exact_req = -1;   // gh_set_matrix_free_exact: 0 / 1; -1: not called, the environment (GRAVHMC_MF_EXACT) decides
     int64_t *mf_near_ptr = nullptr;
     int *mf_near_row = nullptr;
     double *mf_near_val = nullptr;
@@ -153,6 +154,7 @@ struct gh_ctx {
         int *indices = nullptr;
         double *data = nullptr;
         double *coeff = nullptr, *s1 = nullptr, *s2 = nullptr;  // model-sized scratch
+        int64_t coeff_n = 0;                                    // doubles each of them holds
         ghk::DwtLdsPlan lds_plan;  // one-launch transform of one model vector (dwt_lds_kernel)
         size_t lds_bytes = 0;      // 0: the working block does not fit the LDS -> one launch per pass
         double *F = nullptr;  // dense model-space form Awcp W (ld x M, column-major), built on demand

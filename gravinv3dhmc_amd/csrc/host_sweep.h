@@ -460,6 +460,25 @@ static int launch_team(gh_ctx *c, const SweepArgs &full)
     return GH_OK;
 }
 
+// Bookkeeping of a team sweep that gave up.  On a sharded chain EVERY rank calls this when ANY rank's
+// sweep gave up (the decision travels with the trajectory's scalar all-reduce): the garbage of the
+// failed rank's slab has been summed into everybody's d and r, and the ranks must repeat the
+// trajectory together, with the same number of collectives and the same count of time-outs.
+static int team_mark_failed(gh_ctx *c, const char *whose)
+{
+    gh_ctx::Team &t = c->tm;
+    if (t.state == -1 || !t.gran) return GH_OK;  // (teams not in use on this rank)
+    t.aborts += 1;
+    const bool for_good = t.aborts >= 3;
+    fprintf(stderr, "libgravhmc: %s team sweep timed out waiting for its workgroups (%d of 3); repeating %s in row panels\n",
+            whose, t.aborts, for_good ? "this and everything after it" : "the step");
+    HIPCHK(c, hipMemsetAsync(t.abort_w, 0, 4 * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(t.gran, 0, (size_t)8 * t.tpx * TS_MAXQ * TS_RING * 2 * sizeof(u64), c->stream));
+    t.tag = 0;
+    t.state = for_good ? -1 : 2;  // 2: skip the teams until the repeated work is done (team_resume)
+    return GH_OK;
+}
+
 // After a synchronisation point: did a team sweep since the last look give up (its workgroups were
 // not all resident)?  Then everything it fed is void: the caller repeats its work, which now runs in
 // row panels (again on teams after a transient stall; for good after three).
@@ -474,16 +493,8 @@ static int team_failed(gh_ctx *c, bool *failed)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     t.late_polls = w[1];  // columns whose parts some member had to wait for (all launches so far)
     if (w[0] == 0u) return GH_OK;
-    t.aborts += 1;
-    const bool for_good = t.aborts >= 3;
-    fprintf(stderr, "libgravhmc: team sweep timed out waiting for its workgroups (%d of 3); repeating %s in row panels\n",
-            t.aborts, for_good ? "this and everything after it" : "the step");
-    HIPCHK(c, hipMemsetAsync(t.abort_w, 0, 4 * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemsetAsync(t.gran, 0, (size_t)8 * t.tpx * TS_MAXQ * TS_RING * 2 * sizeof(u64), c->stream));
-    t.tag = 0;
-    t.state = for_good ? -1 : 2;  // 2: skip the teams until the repeated work is done (team_resume)
     *failed = true;
-    return GH_OK;
+    return team_mark_failed(c, "this rank's");
 }
 
 static void team_resume(gh_ctx *c)

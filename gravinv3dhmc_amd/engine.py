@@ -96,8 +96,13 @@ class Engine(object):
             raise ValueError("bounds table must be (M, 6)")
         self._chk(self._lib.gh_set_cells(self._h, ptr(b), int(kind), float(ratio)))
 
-    def set_matrix_free(self, on=True):
+    def set_matrix_free(self, on=True, exact=None):
+        """Never store G.  exact (tesseroids): True = a far pair's GLQ leaf in the reference's operation
+        order (_tesseroid_numba.py:207-222), False = the throughput form (~1e-14 from it); None leaves
+        the choice to the environment (GRAVHMC_MF_EXACT, default the throughput form)."""
         self._chk(self._lib.gh_set_matrix_free(self._h, 1 if on else 0))
+        if exact is not None:
+            self._chk(self._lib.gh_set_matrix_free_exact(self._h, 1 if exact else 0))
 
     def matrix_free_stats(self):
         """Entries / GLQ leaves evaluated and launches of the fused matrix-free pass since

@@ -70,6 +70,15 @@ int gh_set_cells(gh_ctx *ctx, const double *bounds6, int kind, double ratio);
  * the dot with r, the leapfrog update and the forward accumulation, like the dense sweep); beyond
  * that an adjoint pass and a forward pass evaluate it twice.  For problems whose G exceeds HBM. */
 int gh_set_matrix_free(gh_ctx *ctx, int enable);
+/* Arithmetic of the matrix-free tesseroid passes (call before gh_build_G; prisms: no effect).
+ * exact = 0 (default): a far pair's 2x2x2 Gauss-Legendre leaf re-arranged for throughput --
+ * cos(lon - lon') by the addition theorem, 1 / l^3 from the hardware reciprocal square root and one
+ * Newton factor; agrees with the reference's values to ~1e-14 (stated tolerance of the path 1e-10).
+ * exact = 1: the leaf in the operation order of gravmag/_tesseroid_numba.py:207-222 (same bits as the
+ * dense assembly, ~3x the time).  Which pairs are far is decided by the reference's own distance /
+ * size test with the same bits either way (_tesseroid_numba.py:135-157).  Without this call the
+ * environment variable GRAVHMC_MF_EXACT (0 / 1) chooses, default 0. */
+int gh_set_matrix_free_exact(gh_ctx *ctx, int exact);
 /* Work of the matrix-free passes since gh_profile_enable(ctx, 1) (fused form only): entries
  * evaluated, 2x2x2 Gauss-Legendre leaves evaluated (tesseroids; = entries for prisms), launches.
  * Tesseroids: the pairs that need the reference's adaptive subdivision (_tesseroid_numba.py:135-157)

@@ -67,6 +67,25 @@ def main():
 
     run(sh, got["sharded"])
     info = {"M_local": ranks.gather(sh.M_local)}
+    # ONE rank's team sweep gives up (test hook on rank 1 only: its members wait for a part that never
+    # comes and time out).  Its slab has been all-reduced into every rank's d and r by then, so the
+    # ranks must repeat the trajectory TOGETHER, in row panels, with matching collectives; three
+    # time-outs later every rank is on row panels for good.  Same chain as before.
+    before = sh.chain_stats()
+    if ranks.rank == 1:
+        os.environ["GRAVHMC_TEAM_TEST_ABORT"] = "1"
+    sh.chain_init(0.001 * wm, low, high)
+    res2 = []
+    sh.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res2.append((acc, o.copy(), xs)), want_x=True, batch=2)
+    os.environ.pop("GRAVHMC_TEAM_TEST_ABORT", None)
+    after = sh.chain_stats()
+    res1 = got["sharded"]["chain"]
+    info["abort"] = {
+        "timeouts": ranks.gather(after["team_timeouts"] - before["team_timeouts"]),
+        "teams_in_use": before["team_members"],
+        "decisions_equal": [r[0] for r in res2] == [r[0] for r in res1],
+        "out5": max(relmax(a[1], b[1]) for a, b in zip(res2, res1)),
+        "x": max([relmax(a[2], b[2]) for a, b in zip(res2, res1) if a[0]] or [0.0])}
     ranks.barrier()
     if ranks.rank == 0:
         from oracle import oracle as orc
@@ -82,6 +101,7 @@ def main():
         del K
         out["wm"] = relmax(wm, wmo)
         out["n_panels"] = 2 if N > 16384 else 1
+        out["abort"] = info["abort"]
         ref = {}
         for reg in ("MS", "TV"):
             Pr = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.7, 0.001, wm=wm, shape=mesh.shape)

