@@ -53,11 +53,14 @@ def pmc(out, note, dirs):
         if "SQ_BUSY_CYCLES_avg" in e and "SQ_ACTIVE_INST_VALU_avg" in e and e.get("SQ_WAVE_CYCLES_avg"):
             e["valu_active_share_of_wave_cycles"] = e["SQ_ACTIVE_INST_VALU_avg"] / e["SQ_WAVE_CYCLES_avg"]
         kernels[name] = e
-    try:
-        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True,
-                                         cwd=os.path.dirname(os.path.abspath(__file__))).strip()
-    except Exception:
-        commit = "n/a"
+    # the build that was profiled: handed over by the recipe (the GPU box has no .git), else HEAD here
+    commit = os.environ.get("GRAVHMC_PROFILED_COMMIT")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True,
+                                             cwd=os.path.dirname(os.path.abspath(__file__))).strip()
+        except Exception:
+            commit = "n/a"
     json.dump({"note": note, "commit": commit, "kernels": kernels}, open(out, "w"), indent=1)
 
 

@@ -169,7 +169,7 @@ def test_c4_matrix_free_eight_chains_full_size(G):
         p0s = rng.normal(size=(C, M)) * 0.001
         us = rng.uniform(size=C)
         acc, out5 = eb.batch_trajectory(p0s, dt, Ls, us)
-        rounds.append((Ls, p0s, us, acc.copy(), out5.copy()))
+        rounds.append((Ls, p0s, us, np.array(acc), np.array(out5)))
     worst = 0.0
     for c in (0, 3, 7):
         es.chain_init(x0s[c], low, high)
@@ -182,7 +182,7 @@ def test_c4_matrix_free_eight_chains_full_size(G):
         a, b = es.misfit_and_grad(xb), ed.misfit_and_grad(xb)
         assert abs(a[0] - b[0]) < 1e-10 * abs(b[0]) and relmax(a[1], b[1]) < 1e-10
     print("C4 matrix-free, 8 chains per GPU vs the single-chain matrix-free engine: worst %.2e, accepted %d of %d"
-          % (worst, sum(int(r[3].sum()) for r in rounds), 2 * C))
+          % (worst, sum(int(np.sum(r[3])) for r in rounds), 2 * C))
     assert worst < 1e-10
     for e in (eb, es, ed):
         e.close()
