@@ -298,6 +298,10 @@ EXTRA_RUNS = [
     ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
                                          "--warmup", "10"]),
     ("c4_global_tesseroid_dense", ["--workload", "c4_global_tesseroid", "--steps", "2000", "--warmup", "200"]),
+    ("c4_global_tesseroid_shift_invariant", ["--workload", "c4_global_tesseroid", "--shift-invariant", "--steps", "4000",
+                                             "--warmup", "400"]),
+    ("c4_global_tesseroid_matrix_free_8_chains", ["--workload", "c4_global_tesseroid", "--matrix-free",
+                                                  "--chains-per-gpu", "8", "--steps", "100", "--warmup", "20"]),
     ("c5_share_of_one_gpu_of_8", ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "8", "--steps", "40",
                                   "--warmup", "10"]),
 ]
@@ -318,11 +322,12 @@ def extra_run(device, extra_args):
     l = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
     r = l["roofline"]
     keep = ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_ms", "launches", "us_per_evaluation",
-            "near_field_table", "entries_per_s", "flop_model")
+            "near_field_table", "entries_per_s", "flop_model", "table", "table_read_GBps", "dense_G_equiv_GBps")
     return {"value": l["value"], "unit": l["unit"], "steps": l["steps"], "warmup": l["warmup"],
             "ms_per_step": l["ms_per_step"],
             "config": {k: l["config"].get(k) for k in ("workload", "N_obs", "M_cells", "G_bytes", "regulariser",
-                                                        "matrix_free", "wavelet_nnz", "dt", "traj_len", "accepted",
+                                                        "matrix_free", "shift_invariant", "chains_per_gpu",
+                                                        "wavelet_nnz", "dt", "traj_len", "accepted",
                                                         "trajectories")},
             "roofline": {k: r[k] for k in keep if k in r}}
 
@@ -394,6 +399,9 @@ def main():
                          "the chain is sharded (single-GPU rehearsal of a model that exceeds one HBM)")
     ap.add_argument("--matrix-free", action="store_true",
                     help="never store G: re-evaluate the kernel entries in every pass")
+    ap.add_argument("--shift-invariant", action="store_true",
+                    help="regular spherical grids (C4): keep the longitude-shift-invariant table instead of G "
+                         "(gh_set_shift_invariant: 35 MB instead of 4.25 GB)")
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
     ap.add_argument("--seed", type=int, default=100,
                     help="np.random.seed of the chain of rank 0; rank r takes seed + r (hmc.py:369)")
@@ -447,6 +455,8 @@ def main():
     info = eng.device_info()
     if args.matrix_free:
         eng.set_matrix_free(True)
+    if args.shift_invariant:
+        eng.set_shift_invariant(True)
     t0 = time.time()
     eng.set_obs(xp, yp, zp)
     eng.set_cells(bounds, extra["kind"], 1.6)
@@ -545,7 +555,7 @@ def main():
         eng.profile_enable(False)
     # what a pure read of the same matrix reaches on this device (outside the timed region)
     stream_gbps = None
-    if not args.matrix_free and int(N) * int(M) * 8 >= (1 << 30):
+    if not args.matrix_free and not args.shift_invariant and int(N) * int(M) * 8 >= (1 << 30):
         stream_gbps = eng.stream_read_gbps(nt=True, reps=3)
     elapsed = ranks.max(elapsed)
     final_U_ranks = ranks.gather(LAST_STATE["U"])      # rank 0: every rank's chain state, in rank order
@@ -566,7 +576,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "N_obs": int(N), "M_cells": int(M),
                        "G_bytes": int(N) * int(M) * 8, "regulariser": extra["reg"],
-                       "matrix_free": bool(args.matrix_free), "wavelet_nnz": nnz,
+                       "matrix_free": bool(args.matrix_free), "shift_invariant": bool(args.shift_invariant),
+                       "wavelet_nnz": nnz,
                        "chains_per_gpu": CPG, "dt": dt, "traj_len": L, "trajectories": ntraj,
                        "accepted": naccept, "final_U": LAST_STATE["U"] if CPG == 1 else None,
                        "final_U_per_rank": final_U_ranks if CPG == 1 and world > 1 else None,
@@ -616,7 +627,26 @@ def main():
                           "share each read of G; two sweeps per leapfrog step of the batch)" % CPG,
                 "fp64_matrix_TFLOPs": 4.0 * N * M * 16 * prof["sweeps"] / 2 / (prof["sweep_ms"] * 1e-3) / 1e12,
                 "reference_formulation_equiv_GBps": 2 * bytes_sweep * CPG * args.steps / elapsed / 1e9})
-        if args.matrix_free:
+        if args.shift_invariant:
+            # K[i, (c, k)] = T[c][class_i][(m_i - k) mod n]: the pass reads the table once (L2 / Infinity
+            # Cache resident) and does the N*M multiply-adds of adjoint and forward out of LDS
+            si = eng.shift_invariant_info()
+            secs = prof["sweep_ms"] * 1e-3
+            flops = 4.0 * N * M * prof["sweeps"]
+            line["roofline"] = {
+                "bound": "fp64 vector out of LDS (shift-invariant table, %.1f MB, cache resident; the N*M "
+                         "multiply-adds of adjoint and forward remain)" % (si["table_bytes"] / 1e6),
+                "achieved": flops / secs / 1e12 if secs > 0 else None, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": flops / secs / 1e12 / FP64_VECTOR_PEAK_TFLOPS if secs > 0 else None,
+                "traffic": None,
+                "kernel": "lonsym_sweep_kernel (workgroup = cell row of %d longitudes: %d observation classes in "
+                          "the lanes, 8-shift register window, fused adjoint+update+forward)"
+                          % (si["n_lon"], si["n_classes"]),
+                "launches": prof["sweeps"], "avg_ms": sweep_ms, "table": si,
+                "table_read_GBps": si["table_bytes"] / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None,
+                "flop_model": "2 N M multiply-adds per pass (adjoint + forward) = 4 N M flop",
+                "dense_G_equiv_GBps": N * M * 8 / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None}
+        elif args.matrix_free:
             # no stored G: the pass is bound by fp64 vector arithmetic.  FLOP model: the
             # operations of the reference's formulas as written, every +, -, *, /, sqrt and
             # trigonometric / logarithm call counted as ONE flop, times the work the kernel counted

@@ -6,6 +6,7 @@
 #include "resident.hip.h"
 #include "teamsweep.hip.h"
 #include "mfbatch.hip.h"
+#include "lonsym.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -27,6 +28,7 @@ using namespace ghk;
 
 #include "host_ctx.h"
 #include "host_sweep.h"
+#include "host_lonsym.h"
 #include "host_comm.h"
 #include "host_wavelet.h"
 #include "host_eval.h"
@@ -94,6 +96,7 @@ void gh_destroy(gh_ctx *c)
     if (c->rs.ev0) hipEventDestroy(c->rs.ev0);
     if (c->rs.ev1) hipEventDestroy(c->rs.ev1);
     if (c->stream) hipStreamDestroy(c->stream);
+    delete c->ls;
     delete c;
 }
 
@@ -156,6 +159,30 @@ int gh_set_matrix_free(gh_ctx *c, int enable)
     return GH_OK;
 }
 
+int gh_set_shift_invariant(gh_ctx *c, int enable)
+{
+    if (!c) return GH_ERR_ARG;
+    if (c->have_G || c->slab) return fail(c, GH_ERR_ARG, "gh_set_shift_invariant: call before gh_build_G");
+    delete c->ls;
+    c->ls = nullptr;
+    if (enable) {
+        c->ls = new LonSymHost();
+        c->mf = true;  // a flavour of the matrix-free mode: G is never stored
+    }
+    return GH_OK;
+}
+
+int gh_shift_invariant_info(const gh_ctx *c, int *n_lon, int *n_classes, int *n_rows, int64_t *table_bytes)
+{
+    if (!c) return GH_ERR_ARG;
+    const bool on = lonsym_on(c);
+    if (n_lon) *n_lon = on ? c->ls->n : 0;
+    if (n_classes) *n_classes = on ? c->ls->na : 0;
+    if (n_rows) *n_rows = on ? c->ls->nc : 0;
+    if (table_bytes) *table_bytes = on ? lonsym_table_bytes(c) : 0;
+    return GH_OK;
+}
+
 int gh_set_matrix_free_exact(gh_ctx *c, int exact)
 {
     if (!c) return GH_ERR_ARG;
@@ -191,6 +218,7 @@ int gh_build_G(gh_ctx *c)
                 TRY(build_near_table(c));
             }
         }
+        if (c->ls) TRY(lonsym_build(c));
         TRY(configure_mf(c));
         TRY(dalloc(c, &c->mf_stats, 1));
         c->have_G = true;
@@ -313,7 +341,10 @@ int gh_weight(gh_ctx *c, double weightfactor, double *wm_out)
     HIPCHK(c, hipSetDevice(c->device));
     TRY(dalloc(c, &c->wm, (size_t)c->M));
     TRY(dalloc(c, &c->wm2, (size_t)c->M));
-    if (c->mf) {
+    if (lonsym_on(c)) {
+        lonsym_colnorm_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
+            lonsym_geom(c), c->ls->a_of, c->ls->m_of, weightfactor, c->wm);
+    } else if (c->mf) {
         mf_colnorm_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(mf_geom(c), weightfactor,
                                                                                         c->wm);
     } else if (c->n_panels > 1) {

@@ -43,14 +43,14 @@ static int mfb_plan(gh_ctx *c)
 {
     gh_ctx::Batch &b = c->bt;
     const int64_t ntiles = (c->M + 15) / 16;
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_adj_for(c)), MFB_LDS));
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_fwd_for(c)), MFB_LDS));
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_adj_for(c)), MFB_LDS_ADJ));
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_fwd_for(c)), MFB_LDS_FWD));
     // one workgroup of 16 waves per CU (133 KB of staging): adjoint = column tiles dealt round-robin
     b.mfb_grid_adj = (int)std::min<int64_t>(ntiles, (int64_t)c->cus * env_int("GRAVHMC_MFB_WG_PER_CU", 1));
     b.n_waves = b.mfb_grid_adj;  // rows of pp_part: one per workgroup
     // forward = 512-row chunks x ranges of column tiles, about one workgroup per CU
     const int nrb = (int)((c->ld + 63) / 64);
-    b.mfb_rchunks = (nrb + MFB_RC - 1) / MFB_RC;
+    b.mfb_rchunks = (nrb + MFB_RC_FWD - 1) / MFB_RC_FWD;
     int ranges = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.mfb_rchunks));
     ranges = env_int("GRAVHMC_MFB_RANGES", ranges);
     b.mfb_tpr = (int)((ntiles + ranges - 1) / ranges);
@@ -123,14 +123,14 @@ static int mfb_forward(gh_ctx *c, const double *X)
     f.slab = b.slab;
     bool timed;
     TRY(batch_time_begin(c, timed));
-    hipLaunchKernelGGL(mfb_fwd_for(c), dim3((unsigned)b.mfb_rchunks, (unsigned)b.mfb_ranges), dim3(1024), MFB_LDS,
+    hipLaunchKernelGGL(mfb_fwd_for(c), dim3((unsigned)b.mfb_rchunks, (unsigned)b.mfb_ranges), dim3(1024), MFB_LDS_FWD,
                        c->stream, mf_geom(c), f, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,
                        c->prof ? c->mf_stats : nullptr);
     TRY(batch_time_end(c, timed));
     if (c->prof) c->mf_launches += 1;
     if (b.mfb_near) {
         const int64_t l16 = c->ld * CB;
-        mfb_near_forward_kernel<<<dim3((unsigned)((l16 + 255) / 256)), dim3(256), 0, c->stream>>>(
+        mfb_near_forward_kernel<<<dim3((unsigned)c->ld), dim3(256), 0, c->stream>>>(
             b.rptr, b.rcol, b.rdelta, c->N, c->ld, X, b.iw, b.slab + (size_t)b.mfb_ranges * (size_t)l16);
     }
     HIPCHK(c, hipGetLastError());
@@ -144,12 +144,11 @@ static int batch_launch_adjoint(gh_ctx *c, BatchAdjArgs &a)
     bool timed;
     if (c->mf) {
         if (b.mfb_near) {
-            const int64_t n16 = c->M * CB;
-            mfb_near_adjoint_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(
+            mfb_near_adjoint_kernel<<<dim3((unsigned)c->M), dim3(256), 0, c->stream>>>(
                 c->mf_near_ptr, c->mf_near_row, b.ndelta, c->M, a.Rt, b.Snear);
         }
         TRY(batch_time_begin(c, timed));
-        hipLaunchKernelGGL(mfb_adj_for(c), dim3((unsigned)b.mfb_grid_adj), dim3(1024), MFB_LDS, c->stream, mf_geom(c),
+        hipLaunchKernelGGL(mfb_adj_for(c), dim3((unsigned)b.mfb_grid_adj), dim3(1024), MFB_LDS_ADJ, c->stream, mf_geom(c),
                            a, b.iw, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,
                            b.mfb_near ? b.Snear : nullptr, c->prof ? c->mf_stats : nullptr);
         TRY(batch_time_end(c, timed));

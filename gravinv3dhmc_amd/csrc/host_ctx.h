@@ -4,6 +4,8 @@
 
 static thread_local std::string g_create_error;
 
+struct LonSymHost;  // host_lonsym.h
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -47,6 +49,9 @@ struct gh_ctx {
     double *mf_near_val = nullptr;
     int64_t mf_near_n = 0, mf_near_leaves = 0;
     int64_t mf_launches = 0;
+    // shift-invariant store of a regular spherical grid (lonsym.hip.h): a table instead of G or of
+    // per-step evaluations; a flavour of the matrix-free mode (gh_set_shift_invariant)
+    LonSymHost *ls = nullptr;
 
     // sweep configuration
     int TW = 0, EPT2 = 0, PF = 1;

@@ -1,0 +1,190 @@
+// libgravhmc host side: detection and construction of the shift-invariant store for regular
+// spherical grids (lonsym.hip.h).  Included once by gravhmc.hip.
+#pragma once
+
+struct LonSymHost {
+    bool on = false;
+    int n = 0, na = 0, nc = 0, SW = 0, AG = 0, KB = 0;
+    int64_t ldT = 0;
+    double *T = nullptr;
+    int *slot_ptr = nullptr, *slot_obs = nullptr, *lds_of = nullptr, *a_of = nullptr, *m_of = nullptr;
+    size_t lds = 0;
+    int grid = 0, items = 1;  // items: work items per wave (instantiation of the kernel)
+    std::string why;  // why the geometry does not qualify (gh_last_error text)
+};
+
+typedef void (*lonsym_fn_t)(LonSymGeom, SweepArgs, const double *);
+static lonsym_fn_t lonsym_fn(int items)
+{
+    return items <= 1 ? lonsym_sweep_kernel<1> : items <= 2 ? lonsym_sweep_kernel<2> : lonsym_sweep_kernel<4>;
+}
+
+static LonSymGeom lonsym_geom(const gh_ctx *c)
+{
+    const LonSymHost &h = *c->ls;
+    LonSymGeom g;
+    g.n = h.n;
+    g.na = h.na;
+    g.nc = h.nc;
+    g.SW = h.SW;
+    g.AG = h.AG;
+    g.KB = h.KB;
+    g.ldT = h.ldT;
+    g.T = h.T;
+    g.slot_ptr = h.slot_ptr;
+    g.slot_obs = h.slot_obs;
+    g.lds_of = h.lds_of;
+    g.N = c->N;
+    return g;
+}
+
+// Does the geometry have the structure (header of lonsym.hip.h)?  Fills the host description and
+// builds the table with the reference's adaptive engine; GH_ERR_UNSUPPORTED with the reason otherwise.
+static int lonsym_build(gh_ctx *c)
+{
+    LonSymHost &h = *c->ls;
+    h.on = false;
+    auto no = [&](const char *why) {
+        h.why = why;
+        return fail(c, GH_ERR_UNSUPPORTED, "shift-invariant store: %s", why);
+    };
+    if (c->cell_kind != GH_CELL_TESSEROID) return no("tesseroid cells only");
+    const int64_t M = c->M, N = c->N;
+    std::vector<double> b((size_t)M * 6), lon((size_t)N), lat((size_t)N), hh((size_t)N);
+    HIPCHK(c, hipMemcpyAsync(b.data(), c->bounds, sizeof(double) * b.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(lon.data(), c->obs[0], sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(lat.data(), c->obs[1], sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hh.data(), c->obs[2], sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto same_row = [&](int64_t j0, int64_t j1) {
+        return memcmp(&b[(size_t)j0 * 6 + 2], &b[(size_t)j1 * 6 + 2], 4 * sizeof(double)) == 0;
+    };
+    // cells: rows of n cells that differ in their longitudes only, w = w0 + k dlon, n dlon = 360
+    int64_t n = 1;
+    while (n < M && same_row(0, n)) ++n;
+    if (M % n != 0) return no("the cells do not form rows of equal length along the longitude");
+    const double w0 = b[0], dlon = b[1] - b[0];
+    if (!(dlon > 0) || std::fabs((double)n * dlon - 360.0) > 1e-9 * 360.0)
+        return no("a row of cells does not cover the full circle of longitudes");
+    const double tol = 1e-9 * dlon;
+    for (int64_t j = 0; j < M; ++j) {
+        const int64_t k = j % n;
+        if (!same_row(j - k, j) || std::fabs(b[(size_t)j * 6] - (w0 + (double)k * dlon)) > tol ||
+            std::fabs(b[(size_t)j * 6 + 1] - (w0 + (double)(k + 1) * dlon)) > tol)
+            return no("the cell rows are not regular in longitude (same origin, same spacing)");
+    }
+    // observations: longitudes on the cells' spacing, classes of equal (latitude, height)
+    std::vector<int> a_of((size_t)N), m_of((size_t)N);
+    std::map<std::pair<uint64_t, uint64_t>, int> cls;
+    std::vector<double> cl_lat, cl_h;
+    const double lon_ref = lon[0];
+    for (int64_t i = 0; i < N; ++i) {
+        const long long m = std::llround((lon[(size_t)i] - lon_ref) / dlon);
+        if (std::fabs(lon[(size_t)i] - lon_ref - (double)m * dlon) > tol)
+            return no("the observation longitudes are not on the cells' longitude spacing");
+        m_of[(size_t)i] = (int)(((m % n) + n) % n);
+        uint64_t kb[2];
+        memcpy(&kb[0], &lat[(size_t)i], 8);
+        memcpy(&kb[1], &hh[(size_t)i], 8);
+        auto it = cls.find({kb[0], kb[1]});
+        if (it == cls.end()) {
+            it = cls.emplace(std::make_pair(kb[0], kb[1]), (int)cl_lat.size()).first;
+            cl_lat.push_back(lat[(size_t)i]);
+            cl_h.push_back(hh[(size_t)i]);
+        }
+        a_of[(size_t)i] = it->second;
+    }
+    const int64_t na = (int64_t)cl_lat.size(), nc = M / n;
+    h.n = (int)n;
+    h.na = (int)na;
+    h.nc = (int)nc;
+    h.SW = (int)((n + 15) / 16 * 16 + 1);
+    h.AG = (int)((na + 63) / 64);
+    h.KB = (int)((n + 7) / 8);
+    const int steps = (int)((n + 7) / 8 * 8);
+    h.lds = sizeof(double) * ((size_t)(2 * na + 1) * h.SW + steps + 8 + (size_t)h.AG * h.KB * 8 + 32);
+    if (n > LS_THREADS) return no("more than 1024 longitudes per cell row");
+    if (h.AG * h.KB > LS_WAVES * LS_MAXITEMS) return no("too many (class, longitude block) work items for one workgroup");
+    if (h.lds > 160 * 1024 - 512) return no("a cell row's table and the residual grid do not fit the LDS");
+    if (na * n > (int64_t)1 << 24) return no("table too wide");
+    // the table: every class at every shift against the cells of longitude index 0 (reference engine)
+    const int64_t Np = na * n;
+    h.ldT = (Np + 15) / 16 * 16;
+    std::vector<double> so((size_t)Np * 3), sb((size_t)nc * 6);
+    for (int64_t a = 0; a < na; ++a)
+        for (int64_t d = 0; d < n; ++d) {
+            so[(size_t)(a * n + d)] = lon_ref + (double)d * dlon;
+            so[(size_t)(Np + a * n + d)] = cl_lat[(size_t)a];
+            so[(size_t)(2 * Np + a * n + d)] = cl_h[(size_t)a];
+        }
+    for (int64_t cc = 0; cc < nc; ++cc) memcpy(&sb[(size_t)cc * 6], &b[(size_t)(cc * n) * 6], 6 * sizeof(double));
+    double *d_so = nullptr, *d_sb = nullptr, *conv = nullptr;
+    int *err_cell = nullptr;
+    TessStats *stats = nullptr;
+    TRY(dalloc(c, &h.T, (size_t)h.ldT * (size_t)nc, false));
+    HIPCHK(c, hipMalloc((void **)&d_so, sizeof(double) * so.size()));
+    HIPCHK(c, hipMalloc((void **)&d_sb, sizeof(double) * sb.size()));
+    HIPCHK(c, hipMalloc((void **)&conv, sizeof(double) * 4 * (size_t)Np));
+    HIPCHK(c, hipMalloc((void **)&err_cell, sizeof(int) * (size_t)nc));
+    HIPCHK(c, hipMalloc((void **)&stats, sizeof(TessStats)));
+    HIPCHK(c, hipMemcpyAsync(d_so, so.data(), sizeof(double) * so.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_sb, sb.data(), sizeof(double) * sb.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(err_cell, 0, sizeof(int) * (size_t)nc, c->stream));
+    HIPCHK(c, hipMemsetAsync(stats, 0, sizeof(TessStats), c->stream));
+    tess_convert_kernel<<<dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, c->stream>>>(
+        d_so, d_so + Np, d_so + 2 * Np, Np, conv, conv + Np, conv + 2 * Np, conv + 3 * Np);
+    const int64_t total = h.ldT * nc;
+    tess_gz_kernel<<<dim3((unsigned)std::min<int64_t>((total + 63) / 64, 1 << 24)), dim3(64), 0, c->stream>>>(
+        conv, conv + Np, conv + 2 * Np, conv + 3 * Np, d_sb, Np, nc, h.ldT, c->ratio, h.T, err_cell, stats);
+    TessStats hs;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&hs, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_so);
+    hipFree(d_sb);
+    hipFree(conv);
+    hipFree(err_cell);
+    hipFree(stats);
+    if (e != hipSuccess) return fail(c, GH_ERR_HIP, "shift-invariant table: %s", hipGetErrorString(e));
+    if (hs.overflow) return fail(c, GH_ERR_OVERFLOW, "tesseroid stack overflow (> %d entries)", TESS_STACK);
+    c->leaves = (int64_t)hs.leaves;
+    // slots (a, m) -> observations, ascending; LDS offset of every observation's slot
+    std::vector<int> sptr((size_t)Np + 1, 0), sobs((size_t)N), ldsof((size_t)N);
+    for (int64_t i = 0; i < N; ++i) sptr[(size_t)(a_of[(size_t)i] * n + m_of[(size_t)i]) + 1] += 1;
+    for (int64_t s = 0; s < Np; ++s) sptr[(size_t)s + 1] += sptr[(size_t)s];
+    {
+        std::vector<int> fill(sptr.begin(), sptr.end() - 1);
+        for (int64_t i = 0; i < N; ++i) sobs[(size_t)fill[(size_t)(a_of[(size_t)i] * n + m_of[(size_t)i])]++] = (int)i;
+    }
+    for (int64_t i = 0; i < N; ++i) ldsof[(size_t)i] = a_of[(size_t)i] * h.SW + m_of[(size_t)i];
+    auto up = [&](int **dst, const std::vector<int> &src) -> int {
+        TRY(dalloc(c, dst, src.size(), false));
+        HIPCHK(c, hipMemcpyAsync(*dst, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice, c->stream));
+        return GH_OK;
+    };
+    TRY(up(&h.slot_ptr, sptr));
+    TRY(up(&h.slot_obs, sobs));
+    TRY(up(&h.lds_of, ldsof));
+    TRY(up(&h.a_of, a_of));
+    TRY(up(&h.m_of, m_of));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    h.items = (h.AG * h.KB + LS_WAVES - 1) / LS_WAVES;
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsym_fn(h.items)), h.lds));
+    h.grid = (int)std::min<int64_t>(nc, c->cus);
+    h.on = true;
+    return GH_OK;
+}
+
+static bool lonsym_on(const gh_ctx *c) { return c->ls && c->ls->on; }
+static int lonsym_grid(const gh_ctx *c) { return c->ls->grid; }
+static int64_t lonsym_table_bytes(const gh_ctx *c) { return c->ls->ldT * c->ls->nc * (int64_t)sizeof(double); }
+
+static int launch_lonsym(gh_ctx *c, SweepArgs &a)
+{
+    const LonSymHost &h = *c->ls;
+    a.ld = c->ld;
+    a.M = c->M;
+    hipLaunchKernelGGL(lonsym_fn(h.items), dim3((unsigned)h.grid), dim3(LS_THREADS), h.lds, c->stream, lonsym_geom(c), a,
+                       c->weighted ? c->wm : nullptr);
+    return GH_OK;
+}

@@ -259,11 +259,21 @@ static int build_near_table(gh_ctx *c)
     return GH_OK;
 }
 
+static int launch_lonsym(gh_ctx *c, SweepArgs &a);  // host_lonsym.h
+static bool lonsym_on(const gh_ctx *c);
+static int lonsym_grid(const gh_ctx *c);
+static int64_t lonsym_table_bytes(const gh_ctx *c);
+
 // Partition of the matrix-free passes.  N <= 16384: the fused pass (one workgroup per column at a
 // time, columns dealt round-robin); else the two-pass form (one wave per cell for the adjoint,
 // chunks of cells per forward partial).
 static int configure_mf(gh_ctx *c)
 {
+    if (lonsym_on(c)) {
+        c->grid = lonsym_grid(c);  // one workgroup per cell row at a time, rows dealt round-robin
+        c->n_teams = c->grid;
+        return GH_OK;
+    }
     if (c->mf_fused) {
         const int64_t ld = c->ld;
         c->mf_T = ld <= 2048 ? 256 : 1024;
@@ -310,7 +320,9 @@ static int launch_mf(gh_ctx *c, SweepArgs &a)
     bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
     if ((a.mode & SW_ADJ) && !wm) return fail(c, GH_ERR_ARG, "matrix-free adjoint needs gh_weight first");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-    if (c->mf_fused) {
+    if (lonsym_on(c)) {
+        TRY(launch_lonsym(c, a));
+    } else if (c->mf_fused) {
         a.ld = c->ld;
         a.M = c->M;
         MfNear near{c->mf_near_ptr, c->mf_near_row, c->mf_near_val};
@@ -328,7 +340,7 @@ static int launch_mf(gh_ctx *c, SweepArgs &a)
     }
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_bytes[c->ev_used / 2] = 0;
+        c->ev_bytes[c->ev_used / 2] = lonsym_on(c) ? lonsym_table_bytes(c) : 0;  // (the table is read once per pass)
         c->ev_used += 2;
     }
     if (c->prof) c->mf_launches += 1;

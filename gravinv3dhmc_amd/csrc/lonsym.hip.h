@@ -1,0 +1,237 @@
+// Shift-invariant store for regular spherical grids (gfx950): the kernel matrix of a global model is
+// never assembled -- and never re-evaluated either.
+//
+// BASELINE configs[3] (example/global/main_global.py:25-28, SetPMTS.txt) puts a 3-degree tesseroid
+// mesh under a 3-degree observation grid.  The gz entry of (observation, tesseroid) depends on the
+// two longitudes only through their difference (gravmag/tesseroid.py:189-232,
+// _tesseroid_numba.py:207-222: cos(lon - lon')), so with
+//     cells       j = c * n + k        c = (layer, latitude band) "cell row", k = 0..n-1 the longitude index,
+//                                      w_k = w_0 + k * dlon, n * dlon = 360
+//     observations i -> (a_i, m_i)     a = class of equal (latitude, height), lon_i = lon_ref + m_i * dlon
+// the whole matrix is  K[i, (c, k)] = T[c][a_i][(m_i - k) mod n]:  n_c x n_a x n numbers (C4: 600 x 61 x
+// 120 doubles = 35 MB, L2 / Infinity-Cache resident) instead of N x M (4.25 GB) or 5.3e8 evaluations
+// per step.  The table is built once with the reference's own adaptive engine (tess_gz_kernel on the
+// synthetic problem "every class at every shift against the cells of longitude index 0": near-field
+// pairs included, same subdivision decisions).  Forward and adjoint become circular correlations
+// along the longitude, per (class, cell row):
+//     S[c][k]  = sum_a sum_m T[c][a][(m - k) mod n] * R[a][m]        R[a][m] = sum of r_i over the slot
+//     D[a][m] += sum_k     T[c][a][(m - k) mod n] * xs[c][k]         d_i = D[a_i][m_i]
+// The fused leapfrog pass of the dense sweep carries over unchanged: a workgroup owns cell row c,
+// holds T[c] (58 KB) and R in LDS, forms the 120 dots, updates the 120 cells (hmc.py:114-152) and adds
+// their forward contribution to its D accumulators (registers) -- one read of the 35 MB table per step.
+//
+// Inner loop (both products): lane = class a, a wave owns 8 consecutive k (adjoint) or m (forward);
+// the 8 table values it needs at a step are 8 consecutive shifts, and the next step needs the same
+// window moved by one: a circular buffer of 8 registers, ONE new LDS read per 8 FMAs.  Row stride of the
+// LDS copies = 1 mod 16 doubles: the lanes' rows fall into different banks.
+// Sums run in a fixed order: reproducible bit for bit.  The values differ from the dense engine's by
+// the rounding of cos(lon - lon') at a shifted pair of longitudes (~1e-16 of an entry) and by the
+// association of the sums; stated tolerance 1e-10, gated by the tests at full size.
+#pragma once
+
+namespace ghk {
+
+struct LonSymGeom {
+    int n, na, nc;         // longitudes per cell row, observation classes, cell rows
+    int SW;                // row stride of the LDS copies (doubles)
+    int AG, KB;            // lane groups of 64 classes, blocks of 8 longitudes: AG * KB work items
+    int64_t ldT;           // doubles per cell row of the table
+    const double *T;       // [nc][ldT], T[c][a * n + delta]
+    const int *slot_ptr;   // na * n + 1: observations of slot (a, m), ascending
+    const int *slot_obs;   // N
+    const int *lds_of;     // N: a_i * SW + m_i
+    int64_t N;
+};
+
+constexpr int LS_THREADS = 1024;
+constexpr int LS_WAVES = 16;
+constexpr int LS_MAXITEMS = 4;  // work items per wave at most (8 forward accumulators each)
+
+// acc[u] += sum over t of window(t)[u] * v(t): see the header.  ADJ: u = 7 - j and v = Rrow[t] (this
+// lane's row of R); forward: u = j and v = xsr[t] (uniform).  Trow = this lane's row of T[c]; b0 = first
+// shift of the window at t = 0; steps = multiple of 8 (v is zero beyond n).
+template <bool ADJ>
+__device__ __forceinline__ void ls_correlate(double (&acc)[8], const double *Trow, const double *v, int b0, int n, int steps)
+{
+    double w[8];
+    int ti = b0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        w[x] = Trow[ti];
+        ti = ti + 1 == n ? 0 : ti + 1;
+    }
+    for (int t0 = 0; t0 < steps; t0 += 8) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double vv = v[t0 + t];
+            const double nx = Trow[ti];  // the element that joins the window at the next step
+            ti = ti + 1 == n ? 0 : ti + 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[ADJ ? 7 - j : j] = fma(w[(t + j) & 7], vv, acc[ADJ ? 7 - j : j]);
+            w[t] = nx;
+        }
+    }
+}
+
+// The fused pass (modes of SweepArgs as sweep_kernel / mf_fused_kernel).  ITEMS = work items per wave
+// (AG * KB <= 16 ITEMS): the forward accumulators are registers.
+template <int ITEMS>
+__global__ void __launch_bounds__(LS_THREADS)
+lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = g.n, na = g.na, SW = g.SW;
+    const int mode = a.mode;
+    const int steps = (n + 7) & ~7;
+    double *Tc = smem;                                   // na x SW
+    double *Rg = Tc + (size_t)na * SW;                   // (na + 1) x SW: row na is zero
+    double *xsr = Rg + (size_t)(na + 1) * SW;            // steps + 8: xs reversed, zero beyond n
+    double *Sp = xsr + steps + 8;                        // AG x (KB * 8)
+    double *red = Sp + (size_t)g.AG * g.KB * 8;          // 32
+    const int nitems = g.AG * g.KB;
+
+    // R[a][m] = sum of r over the slot's observations; zero elsewhere (padding, the extra row)
+    for (int e = tid; e < (na + 1) * SW; e += LS_THREADS) Rg[e] = 0.0;
+    for (int e = tid; e < steps + 8; e += LS_THREADS) xsr[e] = 0.0;
+    __syncthreads();
+    if (mode & SW_ADJ) {
+        for (int aa = wave; aa < na; aa += LS_WAVES)
+            for (int m = lane; m < n; m += 64) {
+                const int s = aa * n + m;
+                double t = 0.0;
+                for (int q = g.slot_ptr[s]; q < g.slot_ptr[s + 1]; ++q) t += a.r[g.slot_obs[q]];
+                Rg[aa * SW + m] = t;
+            }
+    }
+    double dacc[ITEMS][8];
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dacc[q][u] = 0.0;
+    double pp = 0.0;
+    for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
+        __syncthreads();  // (the previous row's forward has finished with Tc and xsr; first trip: Rg is complete)
+        {
+            const double *Tg = g.T + (int64_t)c * g.ldT;
+            for (int aa = wave; aa < na; aa += LS_WAVES)
+                for (int m = lane; m < n; m += 64) Tc[aa * SW + m] = Tg[aa * n + m];
+        }
+        __syncthreads();
+        const int64_t j = (int64_t)c * n + tid;  // thread tid < n: cell (c, tid)
+        double xj = 0.0, iwj = 1.0;
+        if (tid < n) {
+            const double w = wm ? wm[j] : 1.0;
+            iwj = (w != 0.0) ? 1.0 / w : 1.0;
+            xj = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+        }
+        if (mode & SW_ADJ) {
+#pragma unroll 1
+            for (int it = wave; it < nitems; it += LS_WAVES) {
+                const int ag = it / g.KB, kb = it - ag * g.KB;
+                const int aa = ag * 64 + lane;
+                const double *Trow = Tc + (aa < na ? aa : na - 1) * SW;
+                const double *Rrow = Rg + (aa < na ? aa : na) * SW;  // row na: zeros
+                int b0 = (-(kb * 8 + 7)) % n;
+                if (b0 < 0) b0 += n;
+                double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                ls_correlate<true>(acc, Trow, Rrow, b0, n, steps);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double s = wave_sum_dpp(acc[u]);
+                    if (lane == 0) Sp[ag * g.KB * 8 + kb * 8 + u] = s;
+                }
+            }
+            __syncthreads();
+            if (tid < n) {
+                double t = 0.0;
+                for (int ag = 0; ag < g.AG; ++ag) t += Sp[ag * g.KB * 8 + tid];
+                t = t * iwj;
+                const double gr = a.greg ? a.greg[j] : 0.0;
+                const double grad = 2.0 * t + gr;
+                if (mode & SW_GOUT) a.g_out[j] = grad;
+                if (mode & SW_PFIN) {
+                    const double pf = a.p_in[j] - a.c_p * grad;
+                    pp += pf * pf;
+                    if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+                }
+                if (mode & SW_UPD) {
+                    const double psrc = (mode & SW_SPEC) ? a.pn_in[j] : a.p_in[j];
+                    double pj = psrc - a.c_u * grad;
+                    xj = xj + a.dt * pj;
+                    const double hi = a.high[j], lo = a.low[j];
+                    if (xj > hi) {
+                        xj = hi;
+                        pj = -pj;
+                    } else if (xj < lo) {
+                        xj = lo;
+                        pj = -pj;
+                    }
+                    a.p_out[j] = pj;
+                    a.x_out[j] = xj;
+                }
+            }
+        }
+        if (mode & SW_FWD) {
+            if (tid < n) xsr[n - 1 - tid] = xj * iwj;
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < ITEMS; ++qq) {
+                const int it = wave + qq * LS_WAVES;
+                if (it < nitems) {
+                    const int ag = it / g.KB, mb = it - ag * g.KB;
+                    const int aa = ag * 64 + lane;
+                    const double *Trow = Tc + (aa < na ? aa : na - 1) * SW;
+                    const int b0 = (mb * 8 + 1) % n;
+                    ls_correlate<false>(dacc[qq], Trow, xsr, b0, n, steps);
+                }
+            }
+        }
+    }
+    if ((mode & SW_PFIN)) {
+        // sum of p^2 over this workgroup's cells: threads tid < n hold parts
+        const double t = block_allreduce_sum(tid < n ? pp : 0.0, red, LS_WAVES);
+        if (tid == 0) a.pp_part[blockIdx.x] = t;
+    }
+    if (mode & SW_FWD) {
+        __syncthreads();  // everybody is done with Tc: it takes D[a][m]
+#pragma unroll
+        for (int qq = 0; qq < ITEMS; ++qq) {
+            const int it = wave + qq * LS_WAVES;
+            if (it < nitems) {
+                const int ag = it / g.KB, mb = it - ag * g.KB;
+                const int aa = ag * 64 + lane;
+                if (aa < na) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (mb * 8 + u < n) Tc[aa * SW + mb * 8 + u] = dacc[qq][u];
+                }
+            }
+        }
+        __syncthreads();
+        double *out = a.slab + (int64_t)blockIdx.x * a.ld;
+        for (int64_t i = tid; i < a.ld; i += LS_THREADS) out[i] = i < g.N ? Tc[g.lds_of[i]] : 0.0;
+    }
+}
+
+// wm_j = (sum_i K_ij^2)^wf for j = (c, k): thread per cell, observations in order (serial, fixed order)
+__global__ void __launch_bounds__(256)
+lonsym_colnorm_kernel(LonSymGeom g, const int *__restrict__ a_of, const int *__restrict__ m_of, double wf,
+                      double *__restrict__ wm)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= (int64_t)g.nc * g.n) return;
+    const int c = (int)(j / g.n), k = (int)(j - (int64_t)c * g.n);
+    const double *Tg = g.T + (int64_t)c * g.ldT;
+    double s = 0.0;
+    for (int64_t i = 0; i < g.N; ++i) {
+        int d = m_of[i] - k;
+        if (d < 0) d += g.n;
+        const double v = Tg[a_of[i] * g.n + d];
+        s += v * v;
+    }
+    wm[j] = (wf == 0.5) ? sqrt(s) : pow(s, wf);
+}
+
+}  // namespace ghk

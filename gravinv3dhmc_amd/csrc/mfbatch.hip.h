@@ -19,7 +19,10 @@
 // rows in LDS, wave w evaluating column w of the tile with the lane = row layout and the column's
 // constants in scalar registers (the single-chain pass's arithmetic: tess_leaf_fast / tess_leaf_cc
 // / tess_entry_cc / prism_entry, unchanged).  Two staging buffers: the next chunk is evaluated
-// while the MFMAs consume this one, one barrier per chunk.
+// while the MFMAs consume this one, one barrier per chunk.  The rows' observation constants come
+// from LDS as well (fetched by the whole workgroup one chunk ahead): as per-lane global loads in
+// front of every evaluation -- 16 waves x the same rows -- the compiler's software pipeline ended up
+// waiting for half of them right after issuing them (VALU busy 72 %, profiles/r03).
 //   adjoint: workgroup = column tile, all rows in chunks; lane (lo, k) feeds A[col lo][row group k]
 //            from the staged tile (16-byte LDS reads), B from the patch-transposed residuals Rt of
 //            batch.hip.h; the 16 waves' accumulators are summed through LDS in wave order, then
@@ -37,14 +40,22 @@
 namespace ghk {
 
 constexpr int MFB_WAVES = 16;             // waves per workgroup = columns of a tile
-constexpr int MFB_RC = 8;                 // row blocks of 64 per staged chunk
-constexpr int MFB_ROWS = MFB_RC * 64;     // 512 rows
-constexpr int MFB_PATCHES = MFB_ROWS / 16;
+// Row blocks of 64 per staged chunk.  Forward: 8 (512 rows; the workgroup's rows never change: their
+// observation constants sit in LDS once).  Adjoint: 7 (448 rows), which leaves room for two buffers of
+// observation constants: the next chunk's are fetched while this one is evaluated.
+constexpr int MFB_RC_FWD = 8, MFB_RC_ADJ = 7;
+constexpr int MFB_NOBS = 5;               // observation constants per row (tess_leaf_fast: 5)
 // column stride of the staged tile (doubles): +8 shifts consecutive columns by 64 B, so the
 // adjoint's 16-byte reads (16 columns x 4 row groups) and the forward's 8-byte reads (4 columns x
 // 16 rows) both spread over all LDS banks
-constexpr int MFB_S = MFB_ROWS + 8;
-constexpr size_t MFB_LDS = 2 * (size_t)MFB_WAVES * MFB_S * sizeof(double);  // 133120 B
+template <int RC> struct MfbTile {
+    static constexpr int ROWS = RC * 64;
+    static constexpr int PATCHES = ROWS / 16;
+    static constexpr int S = ROWS + 8;
+    static constexpr int BUF = MFB_WAVES * S;   // doubles per staging buffer
+};
+constexpr size_t MFB_LDS_FWD = (2 * (size_t)MfbTile<MFB_RC_FWD>::BUF + (size_t)MFB_NOBS * MfbTile<MFB_RC_FWD>::ROWS) * sizeof(double);      // 153600 B
+constexpr size_t MFB_LDS_ADJ = (2 * (size_t)MfbTile<MFB_RC_ADJ>::BUF + 2 * (size_t)MFB_NOBS * MfbTile<MFB_RC_ADJ>::ROWS) * sizeof(double);  // 152576 B
 
 // the column's constants in (scalar) registers
 template <int KIND>
@@ -73,32 +84,43 @@ __device__ __forceinline__ void mfb_col_load(MfbCol<KIND> &c, const MfGeom &g, c
     }
 }
 
-// observation constants of one row: KIND 0: x, y, z; 1, 2: lon, sin lat, cos lat, radius;
-// 3: sin lon, cos lon, sin lat, cos lat, radius.  Unconditional loads at a clamped 32-bit byte
-// offset from the uniform bases (rows past the end re-read the last row).
+// observation constants of a row: KIND 0: x, y, z; 1, 2: lon, sin lat, cos lat, radius; 3: sin lon,
+// cos lon, sin lat, cos lat, radius.  The q-th array they come from:
 template <int KIND>
-__device__ __forceinline__ void mfb_obs_load(double (&o)[5], const MfGeom &g, unsigned oc)
+__device__ __forceinline__ const double *mfb_obs_array(const MfGeom &g, int q)
 {
-    auto at = [&](const double *base) { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + oc); };
-    if constexpr (KIND == 0) {
-        o[0] = at(g.o0);
-        o[1] = at(g.o1);
-        o[2] = at(g.o2);
-        o[3] = o[4] = 0.0;
-    } else if constexpr (KIND == 3) {
-        o[0] = at(g.o4);
-        o[1] = at(g.o5);
-        o[2] = at(g.o1);
-        o[3] = at(g.o2);
-        o[4] = at(g.o3);
-    } else {
-        o[0] = at(g.o0);
-        o[1] = at(g.o1);
-        o[2] = at(g.o2);
-        o[3] = at(g.o3);
-        o[4] = 0.0;
-    }
+    if constexpr (KIND == 3) return q == 0 ? g.o4 : q == 1 ? g.o5 : q == 2 ? g.o1 : q == 3 ? g.o2 : g.o3;
+    return q == 0 ? g.o0 : q == 1 ? g.o1 : q == 2 ? g.o2 : g.o3;
 }
+template <int KIND> constexpr int mfb_nobs() { return KIND == 0 ? 3 : KIND == 3 ? 5 : 4; }
+
+// The constants of `rows` rows starting at row0, fetched by the whole workgroup (rows past the end
+// re-read the last row: finite values whose products meet zero residuals / are never stored): each
+// thread requests its elements (fetch) and parks them in LDS later (park), SoA: ob[q * rows + i].
+template <int KIND, int ROWS>
+struct MfbObsFetch {
+    static constexpr int PER = (mfb_nobs<KIND>() * ROWS + 1023) / 1024;
+    double v[PER];
+    __device__ __forceinline__ void fetch(const MfGeom &g, int64_t row0, int tid)
+    {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + k * 1024;
+            const int q = e / ROWS, i = e - q * ROWS;
+            int64_t row = row0 + i;
+            if (row >= g.N) row = g.N - 1;
+            v[k] = q < mfb_nobs<KIND>() ? mfb_obs_array<KIND>(g, q)[row] : 0.0;
+        }
+    }
+    __device__ __forceinline__ void park(double *ob, int tid) const
+    {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid + k * 1024;
+            if (e < mfb_nobs<KIND>() * ROWS) ob[e] = v[k];
+        }
+    }
+};
 
 template <int KIND>
 __device__ __forceinline__ double mfb_eval(const MfbCol<KIND> &c, const MfGeom &g, const double (&o)[5], unsigned &nleaf)
@@ -117,37 +139,18 @@ __device__ __forceinline__ double mfb_eval(const MfbCol<KIND> &c, const MfGeom &
     }
 }
 
-// One wave stages its column for `nb` row blocks starting at row block rb0: st[e * 64 + lane].
-// The observation constants of the next block are in flight while this one is evaluated.
-template <int KIND>
-__device__ __forceinline__ void mfb_stage(const MfbCol<KIND> &col, const MfGeom &g, int rb0, int nb, int lane,
+// One wave stages its column for `nb` row blocks of a chunk: st[e * 64 + lane]; the rows' constants
+// come from the chunk's LDS copy ob[q * ROWS + e * 64 + lane].
+template <int KIND, int ROWS>
+__device__ __forceinline__ void mfb_stage(const MfbCol<KIND> &col, const MfGeom &g, const double *ob, int nb, int lane,
                                           double *st, unsigned &nleaf, unsigned &nent)
 {
-    const unsigned olast = (unsigned)(g.N - 1) * (unsigned)sizeof(double);
-    unsigned off = ((unsigned)rb0 * 64u + (unsigned)lane) * (unsigned)sizeof(double);
-    double oa[5], ob[5];
-    {
-        unsigned oc = off < olast ? off : olast;
-        mfb_obs_load<KIND>(oa, g, oc);
-    }
-#pragma unroll 1
-    for (int e = 0; e < nb; e += 2) {
-        {
-            off += 64u * (unsigned)sizeof(double);
-            unsigned oc = off < olast ? off : olast;
-            asm volatile("" : "+v"(oc));
-            mfb_obs_load<KIND>(ob, g, oc);
-        }
-        st[e * 64 + lane] = mfb_eval<KIND>(col, g, oa, nleaf);
-        nent += 1;
-        if (e + 1 >= nb) break;
-        {
-            off += 64u * (unsigned)sizeof(double);
-            unsigned oc = off < olast ? off : olast;
-            asm volatile("" : "+v"(oc));
-            mfb_obs_load<KIND>(oa, g, oc);
-        }
-        st[(e + 1) * 64 + lane] = mfb_eval<KIND>(col, g, ob, nleaf);
+#pragma unroll 2
+    for (int e = 0; e < nb; ++e) {
+        double o[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) o[q] = q < mfb_nobs<KIND>() ? ob[q * ROWS + e * 64 + lane] : 0.0;
+        st[e * 64 + lane] = mfb_eval<KIND>(col, g, o, nleaf);
         nent += 1;
     }
 }
@@ -177,15 +180,22 @@ mfb_adjoint_kernel(MfGeom g, BatchAdjArgs a, const double *__restrict__ iw, cons
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double ppred[16][17];
+    using TL = MfbTile<MFB_RC_ADJ>;
+    double *obs_s = smem + 2 * TL::BUF;  // 2 x (MFB_NOBS x ROWS): constants of this / the next chunk's rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, k = lane >> 4;
     const int64_t ntiles = (a.M + 15) / 16;
     const int nrb = (int)((a.ld + 63) / 64);
-    const int nch = (nrb + MFB_RC - 1) / MFB_RC;
+    const int nch = (nrb + MFB_RC_ADJ - 1) / MFB_RC_ADJ;
     const d2 *rt = reinterpret_cast<const d2 *>(a.Rt) + (k * 16 + lo);
     double pp = 0.0;
     unsigned nent = 0, nleaf = 0;
+    MfbObsFetch<KIND, TL::ROWS> of;
+    of.fetch(g, 0, tid);
+    of.park(obs_s, tid);
+    int oi = 0;  // obs buffer of the chunk being staged
+    __syncthreads();
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int64_t j = tile * 16 + wave;
         if (j >= a.M) j = a.M - 1;
@@ -193,17 +203,21 @@ mfb_adjoint_kernel(MfGeom g, BatchAdjArgs a, const double *__restrict__ iw, cons
         mfb_col_load<KIND>(col, g, cellc, j);
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
         for (int ch = 0; ch < nch; ++ch) {
-            double *buf = smem + (size_t)(ch & 1) * (MFB_WAVES * MFB_S);
-            const int rb0 = ch * MFB_RC;
-            const int nb = nrb - rb0 < MFB_RC ? nrb - rb0 : MFB_RC;
-            mfb_stage<KIND>(col, g, rb0, nb, lane, buf + wave * MFB_S, nleaf, nent);
+            double *buf = smem + (size_t)(ch & 1) * TL::BUF;
+            const int rb0 = ch * MFB_RC_ADJ;
+            const int nb = nrb - rb0 < MFB_RC_ADJ ? nrb - rb0 : MFB_RC_ADJ;
+            // the next chunk's rows (the first chunk again after the last: the next tile starts there)
+            of.fetch(g, (int64_t)(ch + 1 < nch ? rb0 + MFB_RC_ADJ : 0) * 64, tid);
+            mfb_stage<KIND, TL::ROWS>(col, g, obs_s + oi * (MFB_NOBS * TL::ROWS), nb, lane, buf + wave * TL::S, nleaf, nent);
+            of.park(obs_s + (oi ^ 1) * (MFB_NOBS * TL::ROWS), tid);  // (last read while the previous chunk was staged)
+            oi ^= 1;
             __syncthreads();
-            const double *sr = buf + lo * MFB_S;
+            const double *sr = buf + lo * TL::S;
 #pragma unroll
             for (int pq = 0; pq < 2; ++pq) {
                 const int p = 2 * wave + pq;
-                const int gp = ch * MFB_PATCHES + p;
-                if (gp < a.np) {
+                const int gp = ch * TL::PATCHES + p;
+                if (p < TL::PATCHES && gp < a.np) {
                     const d2 a0 = *reinterpret_cast<const d2 *>(sr + 16 * p + 2 * k);
                     const d2 a1 = *reinterpret_cast<const d2 *>(sr + 16 * p + 8 + 2 * k);
                     const d2 r0 = rt[128 * gp], r1 = rt[128 * gp + 64];
@@ -215,7 +229,7 @@ mfb_adjoint_kernel(MfGeom g, BatchAdjArgs a, const double *__restrict__ iw, cons
             }
         }
         // the waves' accumulators through the staging buffer nobody reads any more, in wave order
-        double *red = smem + (size_t)(nch & 1) * (MFB_WAVES * MFB_S);
+        double *red = smem + (size_t)(nch & 1) * TL::BUF;
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[wave * 256 + q * 64 + lane] = acc[q];
         __syncthreads();
@@ -301,25 +315,33 @@ __global__ void __launch_bounds__(1024)
 mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfStats *stats)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    using TL = MfbTile<MFB_RC_FWD>;
+    double *obs_s = smem + 2 * TL::BUF;  // MFB_NOBS x ROWS: constants of the workgroup's rows, once
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15, k = lane >> 4;
     const int64_t ntiles = (a.M + 15) / 16;
     const int nrb = (int)((a.ld + 63) / 64);
-    const int rb0 = blockIdx.x * MFB_RC;
-    const int nb = nrb - rb0 < MFB_RC ? nrb - rb0 : MFB_RC;
+    const int rb0 = blockIdx.x * MFB_RC_FWD;
+    const int nb = nrb - rb0 < MFB_RC_FWD ? nrb - rb0 : MFB_RC_FWD;
     const int64_t t0 = (int64_t)blockIdx.y * a.tiles_per_range;
     int64_t t1 = t0 + a.tiles_per_range;
     if (t1 > ntiles) t1 = ntiles;
     d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
     unsigned nent = 0, nleaf = 0;
+    {
+        MfbObsFetch<KIND, TL::ROWS> of;
+        of.fetch(g, (int64_t)rb0 * 64, tid);
+        of.park(obs_s, tid);
+    }
+    __syncthreads();
     int it = 0;
     for (int64_t tile = t0; tile < t1; ++tile, ++it) {
         int64_t j = tile * 16 + wave;
         if (j >= a.M) j = a.M - 1;
         MfbCol<KIND> col;
         mfb_col_load<KIND>(col, g, cellc, j);
-        double *buf = smem + (size_t)(it & 1) * (MFB_WAVES * MFB_S);
+        double *buf = smem + (size_t)(it & 1) * TL::BUF;
         // this tile's XS fragments: lane (lo, k) feeds column 4 u + k, chain lo
         double xs[4];
 #pragma unroll
@@ -330,11 +352,11 @@ mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfS
             const double v = a.X[jc * CB + lo] * a.iw[jc];
             xs[u] = ok ? v : 0.0;
         }
-        mfb_stage<KIND>(col, g, rb0, nb, lane, buf + wave * MFB_S, nleaf, nent);
+        mfb_stage<KIND, TL::ROWS>(col, g, obs_s, nb, lane, buf + wave * TL::S, nleaf, nent);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const double *sa = buf + (4 * u + k) * MFB_S + lo;
+            const double *sa = buf + (4 * u + k) * TL::S + lo;
 #pragma unroll
             for (int pq = 0; pq < 2; ++pq) acc[pq] = mfma_f64(sa[16 * (2 * wave + pq)], xs[u], acc[pq]);
         }
@@ -377,38 +399,62 @@ __device__ __forceinline__ int64_t rt_offset(int64_t i, int c)
     return (((p * 2 + (q >> 3)) * 4 + ((q & 7) >> 1)) * CB + c) * 2 + (q & 1);
 }
 
-// Snear[j][c] = sum over the listed rows of column j of delta * r_c[row] (rows ascending)
+// Snear[j][c] = sum over the listed rows of column j of delta * r_c[row].  One workgroup per column:
+// thread (e, c) takes the entries e, e + 16, ... of chain c; the 16 partial sums are added in the order
+// of e (fixed: reproducible).  (A thread per (column, chain) walking its list alone cost 70 us per
+// pass at C4: the polar columns list hundreds of rows.)
 __global__ void __launch_bounds__(256)
 mfb_near_adjoint_kernel(const int64_t *__restrict__ ptr, const int *__restrict__ row, const double *__restrict__ delta,
                         int64_t M, const double *__restrict__ Rt, double *__restrict__ Snear)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= M * CB) return;
-    const int c = (int)(t & 15);
-    const int64_t j = t >> 4;
+    __shared__ double part[16][17];
+    const int64_t j = blockIdx.x;
+    const int c = threadIdx.x & 15, e = threadIdx.x >> 4;
+    const int64_t q0 = ptr[j], q1 = ptr[j + 1];
+    if (q1 == q0) {  // (uniform)
+        if (e == 0) Snear[j * CB + c] = 0.0;
+        return;
+    }
     double s = 0.0;
-    for (int64_t q = ptr[j]; q < ptr[j + 1]; ++q) s += delta[q] * Rt[rt_offset(row[q], c)];
-    Snear[t] = s;
+    for (int64_t q = q0 + e; q < q1; q += 16) s += delta[q] * Rt[rt_offset(row[q], c)];
+    part[e][c] = s;
+    __syncthreads();
+    if (e == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += part[r][c];
+        Snear[j * CB + c] = t;
+    }
 }
 
-// out[i][c] = sum over the listed columns of row i of delta * XS[col][c] (columns ascending); one
-// more block of the forward slab
+// out[i][c] = sum over the listed columns of row i of delta * XS[col][c]; one more block of the
+// forward slab.  One workgroup per row, as above.
 __global__ void __launch_bounds__(256)
 mfb_near_forward_kernel(const int64_t *__restrict__ rptr, const int *__restrict__ rcol, const double *__restrict__ rdelta,
                         int64_t N, int64_t ld, const double *__restrict__ X, const double *__restrict__ iw,
                         double *__restrict__ out)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ld * CB) return;
-    const int c = (int)(t & 15);
-    const int64_t i = t >> 4;
+    __shared__ double part[16][17];
+    const int64_t i = blockIdx.x;
+    const int c = threadIdx.x & 15, e = threadIdx.x >> 4;
+    const int64_t q0 = i < N ? rptr[i] : 0, q1 = i < N ? rptr[i + 1] : 0;
+    if (q1 == q0) {
+        if (e == 0) out[i * CB + c] = 0.0;
+        return;
+    }
     double s = 0.0;
-    if (i < N)
-        for (int64_t q = rptr[i]; q < rptr[i + 1]; ++q) {
-            const int64_t j = rcol[q];
-            s += rdelta[q] * (X[j * CB + c] * iw[j]);
-        }
-    out[t] = s;
+    for (int64_t q = q0 + e; q < q1; q += 16) {
+        const int64_t j = rcol[q];
+        s += rdelta[q] * (X[j * CB + c] * iw[j]);
+    }
+    part[e][c] = s;
+    __syncthreads();
+    if (e == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += part[r][c];
+        out[i * CB + c] = t;
+    }
 }
 
 __global__ void __launch_bounds__(256) mfb_invw_kernel(const double *wm, int64_t M, double *iw)

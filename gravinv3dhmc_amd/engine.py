@@ -104,6 +104,17 @@ class Engine(object):
         if exact is not None:
             self._chk(self._lib.gh_set_matrix_free_exact(self._h, 1 if exact else 0))
 
+    def set_shift_invariant(self, on=True):
+        """Regular spherical grids (every cell row a full circle of longitudes, observations on the same
+        spacing): keep K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] instead of G (gh_set_shift_invariant);
+        build_G raises NotImplementedError with the reason if the geometry lacks the structure."""
+        self._chk(self._lib.gh_set_shift_invariant(self._h, 1 if on else 0))
+
+    def shift_invariant_info(self):
+        n, na, nc, tb = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+        self._chk(self._lib.gh_shift_invariant_info(self._h, C.byref(n), C.byref(na), C.byref(nc), C.byref(tb)))
+        return {"n_lon": n.value, "n_classes": na.value, "n_rows": nc.value, "table_bytes": tb.value}
+
     def matrix_free_stats(self):
         """Entries / GLQ leaves evaluated and launches of the fused matrix-free pass since
         profile_enable(True)."""

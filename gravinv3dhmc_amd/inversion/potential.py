@@ -44,13 +44,18 @@ class GravMagModule(object):
     * matrix_free: never store G; re-evaluate the prism / tesseroid entries in every potential
       evaluation (for kernels larger than HBM; the global tesseroid example: ~5x slower per step than
       the dense path).
+    * shift_invariant: spherical models whose cell rows cover the full circle of longitudes with the
+      observations on the same spacing (example/global/main_global.py:25-28): keep the table
+      K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] (35 MB for the global example) instead of G
+      (4.25 GB); NotImplementedError from the constructor if the geometry lacks the structure.
     """
 
     def __init__(self, dobs, mrange, mspacing, obsurface, fixed=False, grav_fix=[],
                  mratio=1, mseg=False, mdivisionsection=[], weightfactor=0.5,
                  coordinate="cartesian", njobs=1, field="gravity",
                  mangle=(90, 0), wavelet=False, device=0, verbose=True, shard=None,
-                 shard_backend="rccl", matrix_free=False, shard_planes=False, **kwargs):
+                 shard_backend="rccl", matrix_free=False, shard_planes=False, shift_invariant=False,
+                 **kwargs):
         self.dobs = dobs
         self.fixed = fixed
         self.grav_fix = grav_fix
@@ -112,7 +117,12 @@ class GravMagModule(object):
             if wavelet:
                 raise NotImplementedError("wavelet compression needs the stored kernel")
             eng.set_matrix_free(True)
-        self.matrix_free = bool(matrix_free)
+        if shift_invariant:
+            if wavelet or not spherical:
+                raise NotImplementedError("the shift-invariant store is for spherical (tesseroid) models "
+                                          "without wavelet compression")
+            eng.set_shift_invariant(True)
+        self.matrix_free = bool(matrix_free or shift_invariant)
         eng.set_obs(self.lonobs, self.latobs, self.heightobs)
         if spherical:
             self._say("Number of effective tesseroids", bounds.shape[0])

@@ -79,6 +79,22 @@ int gh_set_matrix_free(gh_ctx *ctx, int enable);
  * size test with the same bits either way (_tesseroid_numba.py:135-157).  Without this call the
  * environment variable GRAVHMC_MF_EXACT (0 / 1) chooses, default 0. */
 int gh_set_matrix_free_exact(gh_ctx *ctx, int exact);
+/* Shift-invariant store for regular spherical grids (call before gh_build_G; implies that G is never
+ * stored).  Where every row of tesseroid cells covers the full circle of longitudes with one spacing
+ * and the observations sit on that spacing (example/global/main_global.py:25-28: 3-degree mesh under a
+ * 3-degree observation grid) the entry of (observation i, cell (row c, longitude k)) depends on the two
+ * longitudes through their difference only (gravmag/_tesseroid_numba.py:207-222: cos(lon - lon')):
+ * K[i, (c, k)] = T[c][class of (lat_i, h_i)][(m_i - k) mod n].  gh_build_G then evaluates the table T
+ * once with the reference's adaptive engine (near-field pairs included; C4: 600 x 61 x 120 doubles =
+ * 35 MB instead of 4.25 GB of G or 5.3e8 evaluations per step) and every pass -- forward, adjoint, the
+ * fused leapfrog step -- becomes circular correlations along the longitude served from LDS.  Values
+ * agree with the stored kernel to the rounding of cos(lon - lon') at a shifted pair of longitudes
+ * (stated tolerance 1e-10).  gh_build_G fails with GH_ERR_UNSUPPORTED and the reason when the geometry
+ * lacks the structure (or a cell row's table does not fit the LDS). */
+int gh_set_shift_invariant(gh_ctx *ctx, int enable);
+/* The structure gh_build_G found: longitudes per cell row, observation classes (distinct latitude /
+ * height pairs), cell rows, bytes of the table (all 0 when the store is not in use). */
+int gh_shift_invariant_info(const gh_ctx *ctx, int *n_lon, int *n_classes, int *n_rows, int64_t *table_bytes);
 /* Work of the matrix-free passes since gh_profile_enable(ctx, 1) (fused form only): entries
  * evaluated, 2x2x2 Gauss-Legendre leaves evaluated (tesseroids; = entries for prisms), launches.
  * Tesseroids: the pairs that need the reference's adaptive subdivision (_tesseroid_numba.py:135-157)

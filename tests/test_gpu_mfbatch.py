@@ -186,3 +186,96 @@ def test_c4_matrix_free_eight_chains_full_size(G):
     assert worst < 1e-10
     for e in (eb, es, ed):
         e.close()
+
+
+# ------------------------------------------------------------------ shift-invariant store (lonsym.hip.h)
+
+def _global_model(G, dlon, dlat, dr, obs_h, nlat_obs_step=None):
+    mesh = G.mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (dr, dlat, dlon))
+    lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, dlon), np.arange(-90, 91, nlat_obs_step or dlat),
+                                               indexing="ij")]
+    return mesh, lon, lat, np.full_like(lon, obs_h)
+
+
+@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size"])
+def test_shift_invariant_store_matches_the_stored_kernel(G, case):
+    """gh_set_shift_invariant: K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] for regular spherical grids
+    (example/global/main_global.py:25-28; BASELINE configs[3]'s geometry) against the dense engine on the
+    same problem: column norms, unweighted forward (the reference's gz), adjoint, potential + gradient
+    for a cell-local and a stencil regulariser, and a chain with identical decisions.  coarse: 36 longitudes
+    (not a multiple of 8 per block boundary: 36 = 4.5 blocks), duplicated +-180 observations, shuffled
+    observation order, two observation heights (classes = (lat, h) pairs)."""
+    rng = np.random.default_rng(12)
+    if case == "coarse_odd_sizes":
+        mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
+        h[::3] = 45000.0
+        perm = rng.permutation(lon.size)
+        lon, lat, h = lon[perm], lat[perm], h[perm]
+        tol = 1e-10
+    else:
+        mesh, lon, lat, h = _global_model(G, 3.0, 3.0, -300000, 5000.0)
+        tol = 1e-10
+    N, M = lon.size, mesh.size
+    rho = rng.uniform(0.0, 0.5, M)
+    engs = {}
+    for tag in ("dense", "table"):
+        e = G.Engine(N, M)
+        if tag == "table":
+            e.set_shift_invariant(True)
+        e.set_obs(lon, lat, h)
+        e.set_cells(mesh.cell_bounds(), 1, 1.6)
+        e.build_G()
+        engs[tag] = e
+    d, t = engs["dense"], engs["table"]
+    info = t.shift_invariant_info()
+    assert info["n_lon"] == mesh.shape[2] and info["n_rows"] == mesh.shape[0] * mesh.shape[1]
+    assert info["table_bytes"] < N * M * 8 / 50
+    dtrue = d.forward(rho)
+    e_fwd = relmax(t.forward(rho), dtrue)
+    wd, wt = d.weight(0.5), t.weight(0.5)
+    e_w = relmax(wt, wd)
+    r = rng.normal(size=N)
+    e_adj = relmax(t.adjoint(r), d.adjoint(r))
+    dobs = dtrue + 0.02 * np.abs(dtrue).max() * rng.normal(size=N)
+    x = rng.uniform(0, 0.8, M) * wd
+    worst = 0.0
+    for reg in ("Damping", "TV"):
+        for e in (d, t):
+            e.set_data(dobs)
+            e.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wd)
+        a, b = t.misfit_and_grad(x), d.misfit_and_grad(x)
+        worst = max(worst, abs(a[0] - b[0]) / abs(b[0]), relmax(a[1], b[1]), relmax(a[2], b[2]))
+    print("shift-invariant store [%s]: %r; vs dense: forward %.2e weights %.2e adjoint %.2e potential/gradient %.2e"
+          % (case, info, e_fwd, e_w, e_adj, worst))
+    assert e_fwd < tol and e_w < tol and e_adj < tol and worst < tol
+    trajs = [(int(rng.integers(2, 7)), rng.normal(size=M) * 0.001, float(rng.uniform())) for _ in range(5)]
+    outs = {}
+    for tag, e in engs.items():
+        e.chain_init(0.001 * wd, 0.0 * wd, 0.8 * wd)
+        res = []
+        e.run_chain(iter(trajs), 0.005, lambda L, acc, o, xx, res=res: res.append((acc, o.copy())))
+        outs[tag] = (res, e.chain_get_x())
+    for (a1, o1), (a2, o2) in zip(outs["table"][0], outs["dense"][0]):
+        assert a1 == a2 and relmax(o1, o2) < 1e-9
+    assert relmax(outs["table"][1], outs["dense"][1]) < 1e-9
+    for e in engs.values():
+        e.close()
+
+
+def test_shift_invariant_store_refuses_irregular_geometry(G):
+    """Geometry without the structure: gh_build_G fails with the reason (no silent fallback)."""
+    mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
+    for what in ("obs_off_grid", "half_circle", "prisms"):
+        e = G.Engine(lon.size, mesh.size)
+        e.set_shift_invariant(True)
+        b = mesh.cell_bounds().copy()
+        lo = lon.copy()
+        if what == "obs_off_grid":
+            lo[5] += 1.234
+        if what == "half_circle":
+            b[:, 0:2] *= 0.5
+        e.set_obs(lo, lat, h)
+        e.set_cells(b, 0 if what == "prisms" else 1, 1.6)
+        with pytest.raises(NotImplementedError, match="shift-invariant"):
+            e.build_G()
+        e.close()
