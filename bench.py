@@ -294,6 +294,7 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
 #: the other BASELINE.json configurations, each measured by a child process of the default run
 #: (same script, its own workload) and summarised under `extra`, so one driver record carries them
 EXTRA_RUNS = [
+    ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
     ("c3_segment_wavelet3d_tv", ["--workload", "c3_segment_wavelet3d_tv", "--steps", "20000", "--warmup", "2000"]),
     ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
                                          "--warmup", "10"]),
@@ -320,6 +321,8 @@ def extra_run(device, extra_args):
     if out.returncode != 0:
         return {"error": out.stderr[-400:]}
     l = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    if "hmcsample" in l:
+        return l["hmcsample"]
     r = l["roofline"]
     keep = ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_ms", "launches", "us_per_evaluation",
             "near_field_table", "entries_per_s", "flop_model", "table", "table_read_GBps", "dense_G_equiv_GBps")
@@ -330,6 +333,66 @@ def extra_run(device, extra_args):
                                                         "wavelet_nnz", "dt", "traj_len", "accepted",
                                                         "trajectories")},
             "roofline": {k: r[k] for k in keep if k in r}}
+
+
+def hmcsample_block(device, workload, nsamples=60):
+    """The SAMPLER at the headline workload (BASELINE configs[1]: "4000 samples"): HMCSample as the
+    reference's drivers call it (example/uniformgrid/main_uniform.py:17-88, inversion/hmc.py:252-343) --
+    Lrange [5, 20], draws in the reference's RNG order, misfit.dat and the accepted models written --
+    until `nsamples` proposals have been accepted, once with the binary sample sink and once with the
+    reference's text rows (5.5 MB of '%.8f' per sample at C2); next to it Engine.run_chain alone on the
+    same model (the rate the headline line reports).  Host loop, formatter, file I/O and RNG overlap are
+    all inside these numbers."""
+    import contextlib
+    import shutil
+    import tempfile
+    import gravinv3dhmc_amd as g
+    mesh, xp, yp, zp, rho = make_problem(workload)
+    N, M = xp.size, mesh.size
+    nx, ny, nz = WORKLOADS[workload][:3]
+    mrange = (0, 100.0 * nx, 0, 100.0 * ny, 0, 100.0 * nz)
+    dt = WORKLOADS[workload][4]
+    t0 = time.time()
+    gm = g.GravMagModule(np.zeros(N), mrange, (100.0, 100.0, 100.0), (xp, yp, zp), device=device, verbose=False)
+    eng = gm._engine
+    wm = gm.Wm.diagonal()
+    d_true = eng.forward(wm * rho)
+    dobs = d_true + np.random.default_rng(0).normal(0.0, 0.02 * np.abs(d_true).max(), N)
+    eng.set_data(dobs)
+    gm.dobs = dobs
+    t_setup = time.time() - t0
+    out = {"workload": workload, "N_obs": int(N), "M_cells": int(M), "nsamples": nsamples, "Lrange": [5, 20],
+           "dt": dt, "setup_s": round(t_setup, 2)}
+    ones = np.ones(M)
+    tmp = tempfile.mkdtemp(prefix="gravhmc_bench_")
+    try:
+        for sink in ("binary", "text"):
+            with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+                t0 = time.perf_counter()
+                chain = g.HMCSample(gm, nsamples, 0, dt, [5, 20], 0.001 * ones, 0.001 * ones,
+                                    np.c_[0.0 * ones, ones], "mandatory", 1000, dobs, "Fixed", 0.8, 1.0, "Damping",
+                                    0.01, 100, 0.001, save_folder=os.path.join(tmp, sink + "_chain"),
+                                    sample_sink=sink, posterior_last=0)
+                eng.synchronize()
+                el = time.perf_counter() - t0
+            folder = os.path.join(tmp, sink + "_chain0")
+            written = sum(os.path.getsize(os.path.join(folder, f)) for f in os.listdir(folder))
+            out[sink + "_sink"] = {"seconds": el, "accepted_samples_per_s": nsamples / el,
+                                   "leapfrog_steps": chain.leapfrog_steps, "trajectories": chain.trajectories,
+                                   "leapfrog_steps_per_s": chain.leapfrog_steps / el,
+                                   "bytes_written": int(written)}
+        # the chain driver alone (what the headline `value` measures), same model, L = 12
+        eng.set_reg("Damping", 1.0, 0.01, mesh.shape, 0.001 * wm)
+        eng.chain_init(0.001 * wm, 0.0 * wm, 1.0 * wm)
+        steps = out["binary_sink"]["leapfrog_steps"]
+        el, nacc, ntraj, prof = run_single_chain(eng, M, 0.001, dt, 12, steps, 24, 100)
+        out["run_chain_steps_per_s"] = steps / el
+        out["sampler_vs_run_chain"] = out["binary_sink"]["leapfrog_steps_per_s"] / out["run_chain_steps_per_s"]
+        out["text_sink_cost_s_per_sample"] = (out["text_sink"]["seconds"] - out["binary_sink"]["seconds"]) / nsamples
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    eng.close()
+    return out
 
 
 def c1_block(device, want_cpu):
@@ -403,6 +466,9 @@ def main():
                     help="regular spherical grids (C4): keep the longitude-shift-invariant table instead of G "
                          "(gh_set_shift_invariant: 35 MB instead of 4.25 GB)")
     ap.add_argument("--traj-len", type=int, default=10, help="leapfrog steps per trajectory")
+    ap.add_argument("--hmcsample", type=int, default=0, metavar="NSAMPLES",
+                    help="measure the SAMPLER (HMCSample, binary and text sinks, Lrange [5,20]) on the workload "
+                         "until NSAMPLES proposals are accepted, print its block and exit")
     ap.add_argument("--seed", type=int, default=100,
                     help="np.random.seed of the chain of rank 0; rank r takes seed + r (hmc.py:369)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -417,6 +483,10 @@ def main():
                     help="all ranks share GPU 0 (rehearsal of the N>1 launch path on a 1-GPU box)")
     args = ap.parse_args()
 
+    if args.hmcsample > 0:
+        print(json.dumps({"hmcsample": hmcsample_block(int(os.environ.get("LOCAL_RANK", "0")), args.workload,
+                                                       args.hmcsample)}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as the driver types it for N = 1: start the N ranks ourselves, as
         # CHILD processes of a parent that has not touched the GPU (no HIP call, no library load so

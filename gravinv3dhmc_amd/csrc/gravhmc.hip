@@ -131,6 +131,11 @@ int gh_set_obs(gh_ctx *c, const double *a, const double *b, const double *cc)
         TRY(dalloc(c, &c->obs[i], (size_t)c->N));
         TRY(h2d(c, c->obs[i], src[i], (size_t)c->N));
     }
+    // (tesseroids: one height for all observations lets the matrix-free batch hoist what depends on
+    // the radius alone out of the entries, mfbatch.hip.h)
+    c->obs_h_uniform = true;
+    for (int64_t i = 1; i < c->N && c->obs_h_uniform; ++i) c->obs_h_uniform = cc[i] == cc[0];
+    c->obs_h0 = cc[0];
     c->have_obs = true;
     return GH_OK;
 }

@@ -10,7 +10,8 @@ static int mfb_kind(const gh_ctx *c)
 {
     if (c->cell_kind != GH_CELL_TESSEROID) return 0;
     if (!c->mf_near_on) return 1;
-    return c->mf_exact ? 2 : 3;
+    if (c->mf_exact) return 2;
+    return (c->obs_h_uniform && env_int("GRAVHMC_MFB_RU", 1) != 0) ? 4 : 3;  // 4: one observation height
 }
 
 typedef void (*mfb_adj_fn)(MfGeom, BatchAdjArgs, const double *, const double *, const double *, MfStats *);
@@ -22,7 +23,8 @@ static mfb_adj_fn mfb_adj_for(const gh_ctx *c)
     case 0: return mfb_adjoint_kernel<0>;
     case 1: return mfb_adjoint_kernel<1>;
     case 2: return mfb_adjoint_kernel<2>;
-    default: return mfb_adjoint_kernel<3>;
+    case 3: return mfb_adjoint_kernel<3>;
+    default: return mfb_adjoint_kernel<4>;
     }
 }
 
@@ -32,7 +34,8 @@ static mfb_fwd_fn mfb_fwd_for(const gh_ctx *c)
     case 0: return mfb_forward_kernel<0>;
     case 1: return mfb_forward_kernel<1>;
     case 2: return mfb_forward_kernel<2>;
-    default: return mfb_forward_kernel<3>;
+    case 3: return mfb_forward_kernel<3>;
+    default: return mfb_forward_kernel<4>;
     }
 }
 
@@ -73,7 +76,7 @@ static int mfb_plan(gh_ctx *c)
         TRY(dalloc(c, &b.ndelta, (size_t)n, false));
         const MfGeom g = mf_geom(c);
         MfNear near{c->mf_near_ptr, c->mf_near_row, c->mf_near_val};
-        if (kind == 3)
+        if (kind >= 3)
             mfb_near_delta_kernel<3><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(g, c->mf_cellc, near, n, d_colof, b.ndelta);
         else
             mfb_near_delta_kernel<2><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(g, c->mf_cellc, near, n, d_colof, b.ndelta);

@@ -24,6 +24,8 @@ struct gh_ctx {
     // geometry / kernel
     double *obs[3] = {nullptr, nullptr, nullptr};
     double *bounds = nullptr;
+    bool obs_h_uniform = false;  // every observation at the same height (third coordinate)
+    double obs_h0 = 0.0;
     int cell_kind = -1;
     double ratio = 1.6;
     bool have_obs = false, have_cells = false, have_G = false, weighted = false;

@@ -169,6 +169,7 @@ static MfGeom mf_geom(const gh_ctx *c)
 {
     MfGeom g;
     g.kind = c->cell_kind;
+    g.radius_u = (c->cell_kind == GH_CELL_TESSEROID && c->obs_h_uniform) ? 6378137.0 + c->obs_h0 : 0.0;
     g.N = c->N;
     g.M = c->M;
     if (c->cell_kind == GH_CELL_TESSEROID) {

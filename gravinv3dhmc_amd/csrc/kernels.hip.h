@@ -1551,6 +1551,7 @@ ring_stats_kernel(const double *ring, int64_t M, int nvalid, double *mean, doubl
 
 struct MfGeom {
     int kind;  // 0 prism, 1 tesseroid
+    double radius_u;  // tesseroids, every observation at one height: its radius R + h (else 0)
     int64_t N, M;
     const double *o0, *o1, *o2, *o3;  // prism: x,y,z,-  tesseroid: lon_r, sinlat, coslat, radius
     const double *o4, *o5;            // tesseroid: sin lon, cos lon (fast leaf)
@@ -1821,6 +1822,53 @@ __device__ __forceinline__ double tess_leaf_fast(double sinlon, double coslon_o,
                 // y^3 (2.5 - 1.5 l y^2) as y^3 + 1.5 (y^3 (1 - l y^2)): one constant that is not an
                 // inline operand instead of two (each costs two moves per use: an instruction reads
                 // one scalar register pair at most)
+                const double w = fma(y3 * fma(-l, y2, 1.0), 1.5, y3);
+                const double fg = fma(j ? (k ? G11 : G10) : (k ? G01 : G00), cospsi,
+                                      j ? (k ? H11 : H10) : (k ? H01 : H00));
+                result = fma(fg, w, result);
+            }
+        }
+    }
+    return result * cc[23];
+}
+
+// tess_leaf_fast with what depends on (observation radius, cell) alone hoisted out of the entry: for
+// observations at ONE height these eight numbers are per-column constants.
+// pre = {r^2 + rc0^2, r^2 + rc1^2, -2 r rc0, -2 r rc1, -kappa_00 r, -kappa_01 r, -kappa_10 r, -kappa_11 r}
+__device__ __forceinline__ void tess_leaf_fast_pre(double radius, const double *__restrict__ cc, double (&pre)[8])
+{
+    const double r_sqr = radius * radius;
+    const double tr = -2.0 * radius;
+    pre[0] = r_sqr + cc[16];
+    pre[1] = r_sqr + cc[17];
+    pre[2] = cc[14] * tr;
+    pre[3] = cc[15] * tr;
+    pre[4] = -cc[18] * radius;
+    pre[5] = -cc[19] * radius;
+    pre[6] = -cc[20] * radius;
+    pre[7] = -cc[21] * radius;
+}
+
+__device__ __forceinline__ double tess_leaf_fast_ru(double sinlon, double coslon_o, double sinlat, double coslat,
+                                                    const double *__restrict__ cc, const double (&pre)[8])
+{
+    const double A0 = pre[0], A1 = pre[1], m0 = pre[2], m1 = pre[3];
+    const double G00 = cc[28], G01 = cc[29], G10 = cc[30], G11 = cc[31];
+    const double H00 = pre[4], H01 = pre[5], H10 = pre[6], H11 = pre[7];
+    const double P0 = coslat * cc[12], P1 = coslat * cc[13], Q0 = sinlat * cc[10], Q1 = sinlat * cc[11];
+    double result = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double coslon = fma(sinlon, cc[26 + i], coslon_o * cc[24 + i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double cospsi = fma(j ? P1 : P0, coslon, j ? Q1 : Q0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double l = fma(k ? m1 : m0, cospsi, k ? A1 : A0);
+                const double y = __builtin_amdgcn_rsq(l);
+                const double y2 = y * y;
+                const double y3 = y2 * y;
                 const double w = fma(y3 * fma(-l, y2, 1.0), 1.5, y3);
                 const double fg = fma(j ? (k ? G11 : G10) : (k ? G01 : G00), cospsi,
                                       j ? (k ? H11 : H10) : (k ? H01 : H00));

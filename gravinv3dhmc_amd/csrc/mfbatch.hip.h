@@ -58,10 +58,14 @@ constexpr size_t MFB_LDS_FWD = (2 * (size_t)MfbTile<MFB_RC_FWD>::BUF + (size_t)M
 constexpr size_t MFB_LDS_ADJ = (2 * (size_t)MfbTile<MFB_RC_ADJ>::BUF + 2 * (size_t)MFB_NOBS * MfbTile<MFB_RC_ADJ>::ROWS) * sizeof(double);  // 152576 B
 
 // the column's constants in (scalar) registers
+// KIND: 0 prisms; 1 tesseroids with the subdivision inside the pass; 2 / 3 tesseroids with the near-field
+// list and the reference-order / the fast root leaf; 4 = 3 with every observation at one height: what
+// depends on (radius, cell) alone is formed once per column (10 of an entry's 97 instructions).
 template <int KIND>
 struct MfbCol {
     double cc[KIND == 0 ? 1 : TESS_NC];
     double b[KIND == 0 ? 6 : 1];
+    double pre[KIND == 4 ? 8 : 1];
     const double *ccp, *bp;  // KIND 1: the generic engine takes pointers
 };
 
@@ -75,12 +79,13 @@ __device__ __forceinline__ void mfb_col_load(MfbCol<KIND> &c, const MfGeom &g, c
         c.ccp = c.bp = nullptr;
     } else {
         const kconst_ptr ck = as_kconst(cellc) + (int64_t)TESS_NC * j;
-        constexpr int Q0 = KIND == 3 ? 10 : (KIND == 2 ? 8 : 0);
-        constexpr int Q1 = KIND == 3 ? TESS_NC : 23;
+        constexpr int Q0 = KIND >= 3 ? 10 : (KIND == 2 ? 8 : 0);
+        constexpr int Q1 = KIND >= 3 ? TESS_NC : 23;
 #pragma unroll
         for (int q = Q0; q < Q1; ++q) c.cc[q] = ck[q];
         c.ccp = cellc + (int64_t)TESS_NC * j;
         c.bp = g.bounds6 + 6 * j;
+        if constexpr (KIND == 4) tess_leaf_fast_pre(g.radius_u, c.cc, c.pre);
     }
 }
 
@@ -89,10 +94,10 @@ __device__ __forceinline__ void mfb_col_load(MfbCol<KIND> &c, const MfGeom &g, c
 template <int KIND>
 __device__ __forceinline__ const double *mfb_obs_array(const MfGeom &g, int q)
 {
-    if constexpr (KIND == 3) return q == 0 ? g.o4 : q == 1 ? g.o5 : q == 2 ? g.o1 : q == 3 ? g.o2 : g.o3;
+    if constexpr (KIND >= 3) return q == 0 ? g.o4 : q == 1 ? g.o5 : q == 2 ? g.o1 : q == 3 ? g.o2 : g.o3;
     return q == 0 ? g.o0 : q == 1 ? g.o1 : q == 2 ? g.o2 : g.o3;
 }
-template <int KIND> constexpr int mfb_nobs() { return KIND == 0 ? 3 : KIND == 3 ? 5 : 4; }
+template <int KIND> constexpr int mfb_nobs() { return KIND == 0 ? 3 : KIND == 3 ? 5 : 4; }  // (KIND 4: no radius)
 
 // The constants of `rows` rows starting at row0, fetched by the whole workgroup (rows past the end
 // re-read the last row: finite values whose products meet zero residuals / are never stored): each
@@ -133,25 +138,35 @@ __device__ __forceinline__ double mfb_eval(const MfbCol<KIND> &c, const MfGeom &
     } else if constexpr (KIND == 2) {
         nleaf += 1;
         return tess_leaf_cc(o[0], o[1], o[2], o[3], c.cc);
-    } else {
+    } else if constexpr (KIND == 3) {
         nleaf += 1;
         return tess_leaf_fast(o[0], o[1], o[2], o[3], o[4], c.cc);
+    } else {
+        nleaf += 1;
+        return tess_leaf_fast_ru(o[0], o[1], o[2], o[3], c.cc, c.pre);
     }
 }
 
 // One wave stages its column for `nb` row blocks of a chunk: st[e * 64 + lane]; the rows' constants
-// come from the chunk's LDS copy ob[q * ROWS + e * 64 + lane].
-template <int KIND, int ROWS>
+// come from the chunk's LDS copy ob[q * ROWS + e * 64 + lane].  between(e) runs after evaluation e:
+// the MFMAs of the PREVIOUS chunk / tile ride there, one per evaluation -- issued to the matrix
+// pipe, they execute in the shadow of the next evaluation's VALU work.  (All of them right behind the
+// barrier, every wave at once, left the VALU idle for 13 % of the pass: fp64 MFMA takes 16 passes on
+// gfx950.)
+template <int KIND, int ROWS, typename F>
 __device__ __forceinline__ void mfb_stage(const MfbCol<KIND> &col, const MfGeom &g, const double *ob, int nb, int lane,
-                                          double *st, unsigned &nleaf, unsigned &nent)
+                                          double *st, unsigned &nleaf, F between)
 {
-#pragma unroll 2
-    for (int e = 0; e < nb; ++e) {
-        double o[5];
+    // (unrolled: between(e) picks its operands by e -- as a run-time index that is a chain of selects)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) o[q] = q < mfb_nobs<KIND>() ? ob[q * ROWS + e * 64 + lane] : 0.0;
-        st[e * 64 + lane] = mfb_eval<KIND>(col, g, o, nleaf);
-        nent += 1;
+    for (int e = 0; e < ROWS / 64; ++e) {
+        if (e < nb) {
+            double o[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) o[q] = q < mfb_nobs<KIND>() ? ob[q * ROWS + e * 64 + lane] : 0.0;
+            st[e * 64 + lane] = mfb_eval<KIND>(col, g, o, nleaf);
+            between(e);
+        }
     }
 }
 
@@ -202,32 +217,54 @@ mfb_adjoint_kernel(MfGeom g, BatchAdjArgs a, const double *__restrict__ iw, cons
         MfbCol<KIND> col;
         mfb_col_load<KIND>(col, g, cellc, j);
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        // MFMAs of the chunk staged before this one: operands of the wave's two patches, 8 parts
+        d2 pa0[2], pa1[2], pr0[2], pr1[2];
+        bool pok[2] = {false, false};
+        auto load_parts = [&](const double *buf, int ch) {
+            const double *sr = buf + lo * TL::S;
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+                const int p = 2 * wave + pq;
+                const int gp = ch * TL::PATCHES + p;
+                pok[pq] = p < TL::PATCHES && gp < a.np;
+                const int pc = pok[pq] ? p : 0, gc = pok[pq] ? gp : 0;
+                pa0[pq] = *reinterpret_cast<const d2 *>(sr + 16 * pc + 2 * k);
+                pa1[pq] = *reinterpret_cast<const d2 *>(sr + 16 * pc + 8 + 2 * k);
+                pr0[pq] = rt[128 * gc];
+                pr1[pq] = rt[128 * gc + 64];
+            }
+        };
+        auto part = [&](int e) {  // part e of 8: patch e >> 2, MFMA e & 3
+            if (e >= 8) return;
+            const int pq = e >> 2;
+            if (!pok[pq]) return;
+            const int m = e & 3;
+            const double av = m == 0 ? pa0[pq].x : m == 1 ? pa0[pq].y : m == 2 ? pa1[pq].x : pa1[pq].y;
+            const double rv = m == 0 ? pr0[pq].x : m == 1 ? pr0[pq].y : m == 2 ? pr1[pq].x : pr1[pq].y;
+            acc = mfma_f64(av, rv, acc);
+        };
         for (int ch = 0; ch < nch; ++ch) {
             double *buf = smem + (size_t)(ch & 1) * TL::BUF;
             const int rb0 = ch * MFB_RC_ADJ;
             const int nb = nrb - rb0 < MFB_RC_ADJ ? nrb - rb0 : MFB_RC_ADJ;
             // the next chunk's rows (the first chunk again after the last: the next tile starts there)
             of.fetch(g, (int64_t)(ch + 1 < nch ? rb0 + MFB_RC_ADJ : 0) * 64, tid);
-            mfb_stage<KIND, TL::ROWS>(col, g, obs_s + oi * (MFB_NOBS * TL::ROWS), nb, lane, buf + wave * TL::S, nleaf, nent);
+            if (ch > 0) load_parts(smem + (size_t)((ch - 1) & 1) * TL::BUF, ch - 1);
+            mfb_stage<KIND, TL::ROWS>(col, g, obs_s + oi * (MFB_NOBS * TL::ROWS), nb, lane, buf + wave * TL::S, nleaf,
+                                      [&](int e) { if (ch > 0) part(e); });
+            if (ch > 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e >= nb) part(e);  // (fewer evaluations than parts: the rest here)
+            }
+            nent += (unsigned)nb;
             of.park(obs_s + (oi ^ 1) * (MFB_NOBS * TL::ROWS), tid);  // (last read while the previous chunk was staged)
             oi ^= 1;
             __syncthreads();
-            const double *sr = buf + lo * TL::S;
-#pragma unroll
-            for (int pq = 0; pq < 2; ++pq) {
-                const int p = 2 * wave + pq;
-                const int gp = ch * TL::PATCHES + p;
-                if (p < TL::PATCHES && gp < a.np) {
-                    const d2 a0 = *reinterpret_cast<const d2 *>(sr + 16 * p + 2 * k);
-                    const d2 a1 = *reinterpret_cast<const d2 *>(sr + 16 * p + 8 + 2 * k);
-                    const d2 r0 = rt[128 * gp], r1 = rt[128 * gp + 64];
-                    acc = mfma_f64(a0.x, r0.x, acc);
-                    acc = mfma_f64(a0.y, r0.y, acc);
-                    acc = mfma_f64(a1.x, r1.x, acc);
-                    acc = mfma_f64(a1.y, r1.y, acc);
-                }
-            }
         }
+        load_parts(smem + (size_t)((nch - 1) & 1) * TL::BUF, nch - 1);  // the tile's last chunk: nothing to hide behind
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part(e);
         // the waves' accumulators through the staging buffer nobody reads any more, in wave order
         double *red = smem + (size_t)(nch & 1) * TL::BUF;
 #pragma unroll
@@ -335,6 +372,15 @@ mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfS
         of.park(obs_s, tid);
     }
     __syncthreads();
+    // MFMAs of the tile staged before this one: its XS fragments and 8 parts (4 column groups x 2 patches)
+    double xsp[4] = {0.0, 0.0, 0.0, 0.0};
+    const double *pbuf = smem;
+    auto part = [&](int e) {
+        if (e >= 8) return;
+        const int u = e >> 1, pq = e & 1;
+        const double av = pbuf[(4 * u + k) * TL::S + lo + 16 * (2 * wave + pq)];
+        acc[pq] = mfma_f64(av, xsp[u], acc[pq]);
+    };
     int it = 0;
     for (int64_t tile = t0; tile < t1; ++tile, ++it) {
         int64_t j = tile * 16 + wave;
@@ -352,14 +398,21 @@ mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfS
             const double v = a.X[jc * CB + lo] * a.iw[jc];
             xs[u] = ok ? v : 0.0;
         }
-        mfb_stage<KIND, TL::ROWS>(col, g, obs_s, nb, lane, buf + wave * TL::S, nleaf, nent);
-        __syncthreads();
+        mfb_stage<KIND, TL::ROWS>(col, g, obs_s, nb, lane, buf + wave * TL::S, nleaf, [&](int e) { if (it > 0) part(e); });
+        if (it > 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double *sa = buf + (4 * u + k) * TL::S + lo;
-#pragma unroll
-            for (int pq = 0; pq < 2; ++pq) acc[pq] = mfma_f64(sa[16 * (2 * wave + pq)], xs[u], acc[pq]);
+            for (int e = 0; e < 8; ++e)
+                if (e >= nb) part(e);
         }
+        nent += (unsigned)nb;
+        __syncthreads();
+        pbuf = buf;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xsp[u] = xs[u];
+    }
+    if (it > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part(e);  // the last tile: nothing to hide behind
     }
     // acc[pq][q] of lane (lo, k): row 16 (2 wave + pq) + k + 4 q of the chunk, chain lo
     double *out = a.slab + (int64_t)blockIdx.y * a.ld * CB;

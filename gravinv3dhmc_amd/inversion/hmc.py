@@ -43,6 +43,9 @@ class HamitonianMC(object):
         self.sample_sink = "text"
         self.posterior_last = 100
         self._chain_x = None  # identity of the host vector the device chain state mirrors
+        #: work of the last sample() call: trajectories run and leapfrog steps taken (accepted or not)
+        self.trajectories = 0
+        self.leapfrog_steps = 0
 
     def _kinetic(self, p):
         """Kinetic energy with the (identity) inverse mass matrix (hmc.py:44-50)."""
@@ -211,9 +214,14 @@ class HamitonianMC(object):
                 source = draws()
             else:
                 source = LegacyDraws(n, self.Lrange, self.Sigma)
+            def on_result(L, acc, o, xs):
+                self.trajectories += 1
+                self.leapfrog_steps += int(L)
+                return record(o[0], o[1], o[2], acc, lambda: xs)
+
+            self.trajectories = self.leapfrog_steps = 0
             try:
-                eng.run_chain(source, self.dt,
-                              lambda L, acc, o, xs: record(o[0], o[1], o[2], acc, lambda: xs),
+                eng.run_chain(source, self.dt, on_result,
                               stop_at_accepts=ndraws + nsamples, record_from=ndraws,
                               want_x=self.sample_sink != "none", overlap=True)
             finally:
@@ -221,8 +229,11 @@ class HamitonianMC(object):
                     source.release()
             self._chain_x = state["x"]
             return state["x"]
+        self.trajectories = self.leapfrog_steps = 0
         while state["i"] < ndraws + nsamples:
             L = np.random.randint(self.Lrange[0], self.Lrange[1] + 1)
+            self.trajectories += 1
+            self.leapfrog_steps += int(L)
             xn, U, _, AcceptFlag, U_data, U_model = self._leapfrog(state["x"], self.dt, L, alpha,
                                                                   state["i"])
             record(U, U_data, U_model, AcceptFlag, lambda xn=xn: xn)

@@ -229,7 +229,7 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, case):
     d, t = engs["dense"], engs["table"]
     info = t.shift_invariant_info()
     assert info["n_lon"] == mesh.shape[2] and info["n_rows"] == mesh.shape[0] * mesh.shape[1]
-    assert info["table_bytes"] < N * M * 8 / 50
+    assert info["table_bytes"] < N * M * 8 / 10
     dtrue = d.forward(rho)
     e_fwd = relmax(t.forward(rho), dtrue)
     wd, wt = d.weight(0.5), t.weight(0.5)
