@@ -1253,7 +1253,7 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
                 }
             }
         }
-        TRY(batch_launch_adjoint(c, a));
+        TRY(batch_launch_adjoint(c, a, any_upd));
         if (any_upd) TRY(batch_evaluate(c, b.Xw[xo], b.Dw, b.GREGw, b.Rtw));
         X_in = b.Xw[xo];
         Rt_in = b.Rtw;
@@ -1268,6 +1268,13 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
     HIPCHK(c, hipMemcpyAsync(h + CB * 4 + (size_t)b.n_waves * CB, b.pp0_part, sizeof(double) * (size_t)b.n_pp0 * CB,
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        // a fused team pass of this round gave up: nothing of the chains' current states was touched --
+        // run the round again (the fused form is off from here on)
+        bool failed = false;
+        TRY(mfb_fused_failed(c, &failed));
+        if (failed) return gh_batch_trajectory(c, p0s, dt, L, us, accepted, out5s);
+    }
     unsigned mask = 0;
     for (int k = 0; k < C; ++k) {
         double pp1 = 0.0, pp0 = 0.0;
@@ -1551,7 +1558,7 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
             scatter_staged(spec, b.Pn);
             batch_sumsq_kernel<<<dim3((unsigned)b.n_pp0), dim3(256), 0, c->stream>>>(b.Pn, c->M, b.pn0_part);
         }
-        TRY(batch_launch_adjoint(c, a));
+        TRY(batch_launch_adjoint(c, a, any_upd));
         if (any_upd) {
             TRY(batch_evaluate(c, b.Xw[run.xi ^ 1], Ds[wset], GREGs[wset], Rts[wset], scals[wset]));
             run.ws = wset;
@@ -1573,6 +1580,14 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
             HIPCHK(c, hipMemcpyAsync(h + h_pn0, b.pn0_part, sizeof(double) * (size_t)b.n_pp0 * CB,
                                      hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        {
+            bool failed = false;
+            TRY(mfb_fused_failed(c, &failed));
+            if (failed)
+                return fail(c, GH_ERR_HIP, "gh_batch_run: the fused matrix-free batch pass timed out (is the GPU shared with "
+                                           "another process?); the trajectories in flight are lost -- call gh_batch_init again "
+                                           "(the two-pass kernels are used from here on; GRAVHMC_MFB_FUSED=0 selects them up front)");
+        }
         unsigned mask = 0;
         // result slots per chain: T, plus one in carry-over mode for the trajectory that came in flight
         const int Tout = carry ? T + 1 : T;
@@ -1634,6 +1649,17 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         any_active = any_active || run.active[k];
     }
     if (!any_active) run.live = false;  // (the working buffers are rebuilt from the current state next time)
+    return GH_OK;
+}
+
+int gh_batch_fused_stats(gh_ctx *c, int *members, int *ranges, int64_t *launches, int *timeouts)
+{
+    if (!c) return GH_ERR_ARG;
+    const gh_ctx::Batch &b = c->bt;
+    if (members) *members = b.fus_on ? b.fus_members : 0;
+    if (ranges) *ranges = b.fus_on ? b.fus_ranges : 0;
+    if (launches) *launches = b.fus_launches;
+    if (timeouts) *timeouts = b.fus_aborts;
     return GH_OK;
 }
 

@@ -28,6 +28,19 @@ static mfb_adj_fn mfb_adj_for(const gh_ctx *c)
     }
 }
 
+typedef void (*mfb_fus_fn)(MfGeom, BatchAdjArgs, MfbFusArgs, const double *, const double *, const double *, MfStats *);
+
+static mfb_fus_fn mfb_fus_for(const gh_ctx *c)
+{
+    switch (mfb_kind(c)) {
+    case 0: return mfb_fused_kernel<0>;
+    case 1: return mfb_fused_kernel<1>;
+    case 2: return mfb_fused_kernel<2>;
+    case 3: return mfb_fused_kernel<3>;
+    default: return mfb_fused_kernel<4>;
+    }
+}
+
 static mfb_fwd_fn mfb_fwd_for(const gh_ctx *c)
 {
     switch (mfb_kind(c)) {
@@ -59,6 +72,27 @@ static int mfb_plan(gh_ctx *c)
     b.mfb_tpr = (int)((ntiles + ranges - 1) / ranges);
     b.mfb_ranges = (int)((ntiles + b.mfb_tpr - 1) / b.mfb_tpr);
     TRY(dalloc(c, &b.iw, (size_t)c->M));
+    // one evaluation per entry and step: teams of workgroups (mfb_fused_kernel), every workgroup resident
+    b.fus_on = false;
+    b.fus_members = (nrb + MFB_RC_FUS - 1) / MFB_RC_FUS;
+    if (env_int("GRAVHMC_MFB_FUSED", 1) != 0 && b.fus_members <= MFB_FUS_MAXMEM && b.fus_members <= c->cus) {
+        int fr = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.fus_members));
+        b.fus_tpr = (int)((ntiles + fr - 1) / fr);
+        b.fus_ranges = (int)((ntiles + b.fus_tpr - 1) / b.fus_tpr);
+        mfb_fus_fn ff = mfb_fus_for(c);
+        int per_cu = 0;
+        if (allow_dynamic_lds(reinterpret_cast<const void *>(ff), MFB_LDS_FUS) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(ff), 1024, MFB_LDS_FUS) ==
+                hipSuccess &&
+            per_cu >= 1 && (int64_t)per_cu * c->cus >= (int64_t)b.fus_members * b.fus_ranges) {
+            TRY(dalloc(c, &b.fus_gran, (size_t)b.fus_ranges * MFB_FUS_RING * MFB_FUS_MAXMEM * 512));
+            TRY(dalloc(c, &b.fus_abort, 4));
+            b.fus_tag = 0;
+            b.fus_on = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     b.mfb_near = false;
     const int kind = mfb_kind(c);
     if (kind >= 2 && c->mf_near_n > 0) {
@@ -105,7 +139,8 @@ static int mfb_plan(gh_ctx *c)
         TRY(dalloc(c, &b.Snear, (size_t)c->M * CB));
         b.mfb_near = true;
     }
-    b.n_colblocks = b.mfb_ranges + (b.mfb_near ? 1 : 0);
+    b.n_colblocks = std::max(b.mfb_ranges, b.fus_on ? b.fus_ranges : 0) + (b.mfb_near ? 1 : 0);
+    b.slab_live = b.n_colblocks;
     b.cols_per_block = (int64_t)b.mfb_tpr * 16;
     return GH_OK;
 }
@@ -117,35 +152,76 @@ static int batch_time_end(gh_ctx *c, bool timed);
 static int mfb_forward(gh_ctx *c, const double *X)
 {
     gh_ctx::Batch &b = c->bt;
-    MfbFwdArgs f;
-    f.ld = c->ld;
-    f.M = c->M;
-    f.X = X;
-    f.iw = b.iw;
-    f.tiles_per_range = b.mfb_tpr;
-    f.slab = b.slab;
-    bool timed;
-    TRY(batch_time_begin(c, timed));
-    hipLaunchKernelGGL(mfb_fwd_for(c), dim3((unsigned)b.mfb_rchunks, (unsigned)b.mfb_ranges), dim3(1024), MFB_LDS_FWD,
-                       c->stream, mf_geom(c), f, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,
-                       c->prof ? c->mf_stats : nullptr);
-    TRY(batch_time_end(c, timed));
-    if (c->prof) c->mf_launches += 1;
+    int ranges = b.mfb_ranges;
+    if (b.fus_fwd_of == X) {
+        // the fused kernel that produced X left its forward partials in the slab already
+        ranges = b.fus_ranges;
+    } else {
+        MfbFwdArgs f;
+        f.ld = c->ld;
+        f.M = c->M;
+        f.X = X;
+        f.iw = b.iw;
+        f.tiles_per_range = b.mfb_tpr;
+        f.slab = b.slab;
+        f.dbg = env_int("GRAVHMC_MFB_DBG", 0);
+        bool timed;
+        TRY(batch_time_begin(c, timed));
+        hipLaunchKernelGGL(mfb_fwd_for(c), dim3((unsigned)b.mfb_rchunks, (unsigned)b.mfb_ranges), dim3(1024), MFB_LDS_FWD,
+                           c->stream, mf_geom(c), f, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,
+                           c->prof ? c->mf_stats : nullptr);
+        TRY(batch_time_end(c, timed));
+        if (c->prof) c->mf_launches += 1;
+    }
+    b.fus_fwd_of = nullptr;
     if (b.mfb_near) {
         const int64_t l16 = c->ld * CB;
         mfb_near_forward_kernel<<<dim3((unsigned)c->ld), dim3(256), 0, c->stream>>>(
-            b.rptr, b.rcol, b.rdelta, c->N, c->ld, X, b.iw, b.slab + (size_t)b.mfb_ranges * (size_t)l16);
+            b.rptr, b.rcol, b.rdelta, c->N, c->ld, X, b.iw, b.slab + (size_t)ranges * (size_t)l16);
     }
+    b.slab_live = ranges + (b.mfb_near ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     return GH_OK;
 }
 
-// adjoint of all chains + leapfrog update: the dense batch's MFMA kernel or the matrix-free one
-static int batch_launch_adjoint(gh_ctx *c, BatchAdjArgs &a)
+// adjoint of all chains + leapfrog update: the dense batch's MFMA kernel or the matrix-free one.
+// fwd_follows: the caller evaluates the potential at a.X_out next (batch_evaluate) -- on the matrix-free
+// kernel the fused team pass then delivers the forward partials from the same evaluation of the entries.
+static int batch_launch_adjoint(gh_ctx *c, BatchAdjArgs &a, bool fwd_follows)
 {
     gh_ctx::Batch &b = c->bt;
     bool timed;
-    if (c->mf) {
+    b.fus_fwd_of = nullptr;
+    if (c->mf && b.fus_on && fwd_follows) {
+        if (b.mfb_near) {
+            mfb_near_adjoint_kernel<<<dim3((unsigned)c->M), dim3(256), 0, c->stream>>>(
+                c->mf_near_ptr, c->mf_near_row, b.ndelta, c->M, a.Rt, b.Snear);
+        }
+        if ((uint64_t)b.fus_tag + (uint64_t)b.fus_tpr + 2 > 0xf0000000ull) {
+            HIPCHK(c, hipMemsetAsync(b.fus_gran, 0, sizeof(u64) * (size_t)b.fus_ranges * MFB_FUS_RING * MFB_FUS_MAXMEM * 512,
+                                     c->stream));
+            b.fus_tag = 0;
+        }
+        MfbFusArgs f;
+        f.tiles_per_range = b.fus_tpr;
+        f.slab = b.slab;
+        f.gran = b.fus_gran;
+        f.tag0 = b.fus_tag;
+        f.abort_w = b.fus_abort;
+        // test hook: the members wait for a part that never comes, time out and give up
+        f.poll_members = b.fus_members + ((env_int("GRAVHMC_MFB_TEST_ABORT", 0) && b.fus_members < MFB_FUS_MAXMEM) ? 1 : 0);
+        f.n_pp = b.n_waves;
+        TRY(batch_time_begin(c, timed));
+        hipLaunchKernelGGL(mfb_fus_for(c), dim3((unsigned)b.fus_members, (unsigned)b.fus_ranges), dim3(1024), MFB_LDS_FUS,
+                           c->stream, mf_geom(c), a, f, b.iw, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,
+                           b.mfb_near ? b.Snear : nullptr, c->prof ? c->mf_stats : nullptr);
+        TRY(batch_time_end(c, timed));
+        if (c->prof) c->mf_launches += 1;
+        b.fus_tag += (unsigned)b.fus_tpr + 1u;
+        b.fus_inflight = true;
+        b.fus_launches += 1;
+        b.fus_fwd_of = a.X_out;
+    } else if (c->mf) {
         if (b.mfb_near) {
             mfb_near_adjoint_kernel<<<dim3((unsigned)c->M), dim3(256), 0, c->stream>>>(
                 c->mf_near_ptr, c->mf_near_row, b.ndelta, c->M, a.Rt, b.Snear);
@@ -249,6 +325,29 @@ static int batch_time_end(gh_ctx *c, bool timed)
     return GH_OK;
 }
 
+// After a synchronisation point: did a fused team pass since the last look give up (its workgroups were
+// not all resident -- the GPU shared with somebody else)?  Everything it fed is void; the fused form
+// is switched off for good (the two-pass kernels need no co-residency).
+static int mfb_fused_failed(gh_ctx *c, bool *failed)
+{
+    gh_ctx::Batch &b = c->bt;
+    *failed = false;
+    if (!b.fus_inflight) return GH_OK;
+    b.fus_inflight = false;
+    unsigned w[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(w, b.fus_abort, sizeof w, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (w[0] == 0u) return GH_OK;
+    fprintf(stderr, "libgravhmc: the fused matrix-free batch pass timed out waiting for its workgroups; "
+                    "continuing with the two-pass kernels\n");
+    HIPCHK(c, hipMemsetAsync(b.fus_abort, 0, 4 * sizeof(unsigned), c->stream));
+    b.fus_on = false;
+    b.fus_aborts += 1;
+    b.fus_fwd_of = nullptr;
+    *failed = true;
+    return GH_OK;
+}
+
 // forward of all chains at X, then regulariser and residuals into (D, GREG, Rt, scal)
 static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, double *Rt, double *scal = nullptr)
 {
@@ -271,8 +370,8 @@ static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, d
         TRY(batch_time_end(c, timed));
     }
     const int64_t n16 = c->ld * CB;
-    batch_reduce_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(b.slab, b.n_colblocks,
-                                                                                        n16, D);
+    batch_reduce_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(
+        b.slab, c->mf ? b.slab_live : b.n_colblocks, n16, D);
     BatchRegArgs ra;
     ra.kind = c->reg_kind;
     ra.M = c->M;

@@ -188,6 +188,15 @@ struct gh_ctx {
         int *rcol = nullptr;
         bool mfb_near = false;
         int mfb_grid_adj = 0, mfb_rchunks = 0, mfb_ranges = 0, mfb_tpr = 0;
+        int slab_live = 0;        // blocks of the slab the last matrix-free forward wrote
+        // fused team pass (mfb_fused_kernel): one evaluation per entry and step
+        bool fus_on = false, fus_inflight = false;
+        int fus_members = 0, fus_ranges = 0, fus_tpr = 0, fus_aborts = 0;
+        ghk::u64 *fus_gran = nullptr;
+        unsigned *fus_abort = nullptr;
+        unsigned fus_tag = 0;
+        int64_t fus_launches = 0;
+        const double *fus_fwd_of = nullptr;  // the X whose forward partials the last fused launch left in the slab
         double *h = nullptr;      // pinned
         int n_colblocks = 0, n_regblocks = 0, n_waves = 0, n_pp0 = 0;
         int64_t cols_per_block = 0;

@@ -185,6 +185,48 @@ __device__ __forceinline__ void mfb_count(MfStats *stats, unsigned nent, unsigne
     }
 }
 
+// Leapfrog update of one (cell, chain) pair from its gradient gr, by the chain's phase (the epilogue of
+// batch_adjoint_kernel; hmc.py:114-152).  write: this thread stores the results and counts p^2.
+// Returns the position the forward product of the next evaluation uses.
+__device__ __forceinline__ double mfb_update(const BatchAdjArgs &a, int64_t idx, int64_t jc, int c, double gr, bool write,
+                                             double &pp)
+{
+    const int ph = a.phase[c];
+    double xo = a.X_in[idx], po = a.P_in[idx];
+    if (ph == PH_GOUT) {
+        if (write) a.G_out[idx] = gr;
+        return xo;
+    }
+    if (ph == PH_UPD || ph == PH_PFIN_SPEC) {
+        if (ph == PH_PFIN_SPEC) {
+            const double pf = po - a.cp[c] * gr;
+            if (write) pp += pf * pf;
+            po = a.Pn[idx];
+        }
+        double pj = po - a.cu[c] * gr;
+        double xj = xo + a.dt * pj;
+        const double hi = a.high[jc], lw = a.low[jc];
+        if (xj > hi) {
+            xj = hi;
+            pj = -pj;
+        } else if (xj < lw) {
+            xj = lw;
+            pj = -pj;
+        }
+        po = pj;
+        xo = xj;
+    } else if (ph == PH_PFIN) {
+        const double pf = po - a.cp[c] * gr;
+        if (write) pp += pf * pf;
+        po = pf;
+    }
+    if (write) {
+        a.P_out[idx] = po;
+        a.X_out[idx] = xo;
+    }
+    return xo;
+}
+
 // ---- adjoint of all chains + leapfrog update (hmc.py:114-152) ------------------------------------
 // BatchAdjArgs as batch_adjoint_kernel (G / Gb unused); iw = 1 / wm (1 where wm == 0), Snear =
 // near-field part of S (M x 16) or nullptr; pp_part has gridDim.x x 16 entries.
@@ -282,47 +324,7 @@ mfb_adjoint_kernel(MfGeom g, BatchAdjArgs a, const double *__restrict__ iw, cons
                 const int64_t idx = jc * CB + c;
                 if (Snear) s += Snear[idx];
                 s = s * iw[jc];
-                const int ph = a.phase[c];
-                const double gr = 2.0 * s + (a.GREG ? a.GREG[idx] : 0.0);
-                if (ph == PH_GOUT) {
-                    a.G_out[idx] = gr;
-                } else if (ph == PH_UPD) {
-                    double pj = a.P_in[idx] - a.cu[c] * gr;
-                    double xj = a.X_in[idx] + a.dt * pj;
-                    const double hi = a.high[jc], lw = a.low[jc];
-                    if (xj > hi) {
-                        xj = hi;
-                        pj = -pj;
-                    } else if (xj < lw) {
-                        xj = lw;
-                        pj = -pj;
-                    }
-                    a.P_out[idx] = pj;
-                    a.X_out[idx] = xj;
-                } else if (ph == PH_PFIN) {
-                    const double pf = a.P_in[idx] - a.cp[c] * gr;
-                    pp += pf * pf;
-                    a.P_out[idx] = pf;
-                    a.X_out[idx] = a.X_in[idx];
-                } else if (ph == PH_PFIN_SPEC) {
-                    const double pf = a.P_in[idx] - a.cp[c] * gr;
-                    pp += pf * pf;
-                    double pj = a.Pn[idx] - a.cu[c] * gr;
-                    double xj = a.X_in[idx] + a.dt * pj;
-                    const double hi = a.high[jc], lw = a.low[jc];
-                    if (xj > hi) {
-                        xj = hi;
-                        pj = -pj;
-                    } else if (xj < lw) {
-                        xj = lw;
-                        pj = -pj;
-                    }
-                    a.P_out[idx] = pj;
-                    a.X_out[idx] = xj;
-                } else {
-                    a.P_out[idx] = a.P_in[idx];
-                    a.X_out[idx] = a.X_in[idx];
-                }
+                (void)mfb_update(a, idx, jc, c, 2.0 * s + (a.GREG ? a.GREG[idx] : 0.0), true, pp);
             }
         }
         __syncthreads();  // (the reduction buffer is the next tile's first staging buffer when nch is even)
@@ -345,6 +347,7 @@ struct MfbFwdArgs {
     const double *iw;  // M: 1 / wm (1 where wm == 0 or the kernel is not weighted)
     int tiles_per_range;
     double *slab;      // gridDim.y x (ld x 16)
+    int dbg;           // timing experiments only (GRAVHMC_MFB_DBG): 1 no barrier, 2 no MFMA, 4 no evaluation, 8 one column
 };
 
 template <int KIND>
@@ -385,6 +388,7 @@ mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfS
     for (int64_t tile = t0; tile < t1; ++tile, ++it) {
         int64_t j = tile * 16 + wave;
         if (j >= a.M) j = a.M - 1;
+        if (a.dbg & 8) j = wave;
         MfbCol<KIND> col;
         mfb_col_load<KIND>(col, g, cellc, j);
         double *buf = smem + (size_t)(it & 1) * TL::BUF;
@@ -398,14 +402,19 @@ mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfS
             const double v = a.X[jc * CB + lo] * a.iw[jc];
             xs[u] = ok ? v : 0.0;
         }
-        mfb_stage<KIND, TL::ROWS>(col, g, obs_s, nb, lane, buf + wave * TL::S, nleaf, [&](int e) { if (it > 0) part(e); });
-        if (it > 0) {
+        if (a.dbg & 4) {
+            for (int e = 0; e < nb; ++e) (buf + wave * TL::S)[e * 64 + lane] = obs_s[e * 64 + lane];
+        } else {
+            mfb_stage<KIND, TL::ROWS>(col, g, obs_s, nb, lane, buf + wave * TL::S, nleaf,
+                                      [&](int e) { if (it > 0 && !(a.dbg & 2)) part(e); });
+        }
+        if (it > 0 && !(a.dbg & 2)) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (e >= nb) part(e);
         }
         nent += (unsigned)nb;
-        __syncthreads();
+        if (!(a.dbg & 1)) __syncthreads();
         pbuf = buf;
 #pragma unroll
         for (int u = 0; u < 4; ++u) xsp[u] = xs[u];
@@ -423,6 +432,216 @@ mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfS
             const int64_t row = (int64_t)rb0 * 64 + 16 * (2 * wave + pq) + k + 4 * q;
             if (row < a.ld) out[row * CB + lo] = acc[pq][q];
         }
+    mfb_count(stats, nent, nleaf, lane);
+}
+
+// ---- both products from ONE evaluation of every entry: teams of workgroups --------------------------
+// The two-pass form above evaluates every entry twice per step because the update between the dot and
+// the axpy needs the dot over ALL rows.  Here the workgroups that hold the row chunks of the same
+// column tiles form a TEAM (grid = members x ranges of column tiles, every workgroup resident: one per
+// CU) and hand each other their 16 x 16 partial dots per tile through memory, like the team sweep of
+// the stored kernel (teamsweep.hip.h): a member stages its 448 rows of a tile once, forms its part of
+// S from it, publishes the part, and -- one tile later, when everybody's parts have long arrived --
+// sums the parts in member order, applies the leapfrog update (every member the same arithmetic, the
+// same bits; member 0 stores the results) and feeds the new positions to the forward MFMAs on the
+// tile it still holds in its other staging buffer.  One evaluation per entry and step for all chains.
+//
+// Exchange: the data is the flag (resident.hip.h): a double travels as two tagged 8-byte granules,
+// written through, read with agent-scope loads; no counters, no fences; correct under any placement.
+// A ring of four slots per team (a member is never more than one tile ahead of another).  Every wait
+// is bounded (2 s): on a time-out the abort word is raised, every workgroup leaves, later launches
+// return at once and the host repeats the work with the two-pass kernels.
+constexpr int MFB_RC_FUS = 7;
+constexpr int MFB_FUS_ADJW = 7;     // waves that run the adjoint MFMAs, four row patches each
+constexpr int MFB_FUS_MAXMEM = 32;  // members of a team at most
+constexpr int MFB_FUS_RING = 4;
+constexpr size_t MFB_LDS_FUS = (2 * (size_t)MfbTile<MFB_RC_FUS>::BUF + (size_t)MFB_NOBS * MfbTile<MFB_RC_FUS>::ROWS +
+                                (size_t)MFB_FUS_ADJW * 256 + 4 * 256 + 256) * sizeof(double);  // 154112 B
+
+struct MfbFusArgs {
+    int tiles_per_range;
+    double *slab;        // gridDim.y x (ld x 16)
+    u64 *gran;           // [gridDim.y][MFB_FUS_RING][MFB_FUS_MAXMEM][256][2]
+    unsigned tag0;       // tags tag0 + 1 .. tag0 + tiles_per_range belong to this launch
+    unsigned *abort_w;
+    int poll_members;    // gridDim.x (+ 1 in the time-out test: one part never comes)
+    int n_pp;            // rows of pp_part the host sums (those beyond the ranges are zeroed)
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(1024)
+mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restrict__ iw, const double *__restrict__ cellc,
+                 const double *__restrict__ Snear, MfStats *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double ppred[16][17];
+    __shared__ int abort_s;
+    using TL = MfbTile<MFB_RC_FUS>;
+    double *obs_s = smem + 2 * TL::BUF;                  // MFB_NOBS x ROWS
+    double *red = obs_s + MFB_NOBS * TL::ROWS;           // MFB_FUS_ADJW x 256: the adjoint waves' accumulators
+    double *gp = red + MFB_FUS_ADJW * 256;               // 4 x 256: sums over the members q, q + 4, ...
+    double *xs_s = gp + 4 * 256;                         // 256: XS of the tile being finished, [col][chain]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lo = lane & 15, k = lane >> 4;
+    const int mem = blockIdx.x, cr = blockIdx.y;
+    const int64_t ntiles = (a.M + 15) / 16;
+    const int nrb = (int)((a.ld + 63) / 64);
+    const int rb0 = mem * MFB_RC_FUS;
+    const int nb = nrb - rb0 < MFB_RC_FUS ? nrb - rb0 : MFB_RC_FUS;
+    const int64_t t0 = (int64_t)cr * f.tiles_per_range;
+    const int ntl = (int)((ntiles - t0 < f.tiles_per_range) ? ntiles - t0 : f.tiles_per_range);
+    if (tid == 0) abort_s = (__hip_atomic_load(f.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
+    {
+        MfbObsFetch<KIND, TL::ROWS> of;
+        of.fetch(g, (int64_t)rb0 * 64, tid);
+        of.park(obs_s, tid);
+    }
+    // adjoint: wave w < 7 contracts the row patches w, w + 7, w + 14, w + 21 of the member; their
+    // residual fragments never change during the launch
+    d2 ar0[4], ar1[4];
+    bool aok[4];
+    {
+        const d2 *rt = reinterpret_cast<const d2 *>(a.Rt) + (k * 16 + lo);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = wave + MFB_FUS_ADJW * q;
+            const int gpi = mem * TL::PATCHES + p;
+            aok[q] = wave < MFB_FUS_ADJW && p < TL::PATCHES && gpi < a.np;
+            const int gc = aok[q] ? gpi : 0;
+            ar0[q] = rt[128 * gc];
+            ar1[q] = rt[128 * gc + 64];
+        }
+    }
+    u64 *gteam = f.gran + (size_t)cr * MFB_FUS_RING * MFB_FUS_MAXMEM * 512;
+    auto gran_of = [&](int it, int member) -> u64 * {
+        return gteam + ((size_t)(it & (MFB_FUS_RING - 1)) * MFB_FUS_MAXMEM + member) * 512;
+    };
+    d4 accf[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    double pp = 0.0;
+    unsigned nent = 0, nleaf = 0;
+    __syncthreads();
+    if (abort_s) return;  // an earlier launch of this stream gave up: the host repeats the work
+    for (int it = 0; it <= ntl; ++it) {
+        const bool stg = it < ntl, fin = it >= 1;
+        double *buf = smem + (size_t)(it & 1) * TL::BUF;
+        if (stg) {
+            int64_t j = (t0 + it) * 16 + wave;
+            if (j >= a.M) j = a.M - 1;
+            MfbCol<KIND> col;
+            mfb_col_load<KIND>(col, g, cellc, j);
+            mfb_stage<KIND, TL::ROWS>(col, g, obs_s, nb, lane, buf + wave * TL::S, nleaf, [](int) {});
+            nent += (unsigned)nb;
+        }
+        __syncthreads();  // the tile is staged; everybody is done with the forward of tile it - 2
+        if (stg && wave < MFB_FUS_ADJW) {
+            const double *sr = buf + lo * TL::S;
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (aok[q]) {
+                    const int p = wave + MFB_FUS_ADJW * q;
+                    const d2 a0 = *reinterpret_cast<const d2 *>(sr + 16 * p + 2 * k);
+                    const d2 a1 = *reinterpret_cast<const d2 *>(sr + 16 * p + 8 + 2 * k);
+                    acc = mfma_f64(a0.x, ar0[q].x, acc);
+                    acc = mfma_f64(a0.y, ar0[q].y, acc);
+                    acc = mfma_f64(a1.x, ar1[q].x, acc);
+                    acc = mfma_f64(a1.y, ar1[q].y, acc);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave * 256 + q * 64 + lane] = acc[q];
+        }
+        if (fin) {
+            // the parts of tile it - 1, published an iteration ago: thread (v, q) sums the members q, q + 4, ...
+            const int v = tid & 255, q = tid >> 8;
+            const unsigned tag = f.tag0 + (unsigned)it;  // tile it - 1 carries tag0 + (it - 1) + 1
+            double sum = 0.0;
+            bool ok = true;
+            for (int m = q; m < f.poll_members && ok; m += 4) {
+                double val = 0.0;
+                unsigned spins = 0;
+                long long tstart = 0;
+                while (!ld_gran(gran_of(it - 1, m) + 2 * v, tag, val)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63u) == 0) {
+                        const long long now = wall_clock64();
+                        if (tstart == 0) tstart = now;
+                        if (__hip_atomic_load(f.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                            now - tstart > RES_TIMEOUT_TICKS) {
+                            __hip_atomic_store(f.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = false;
+                            break;
+                        }
+                    }
+                }
+                sum += val;
+            }
+            gp[q * 256 + v] = sum;
+            if (!ok) abort_s = 1;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int cl = tid >> 4, c = tid & 15;
+            if (stg) {
+                // this member's part of S for tile it (acc[q] of lane (lo, k): column k + 4 q, chain lo)
+                const int ridx = (cl >> 2) * 64 + (cl & 3) * 16 + c;
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < MFB_FUS_ADJW; ++w) s += red[w * 256 + ridx];
+                st_gran(gran_of(it, mem) + 2 * tid, f.tag0 + (unsigned)it + 1u, s);
+            }
+            if (fin) {
+                double s = ((gp[tid] + gp[256 + tid]) + gp[512 + tid]) + gp[768 + tid];
+                const int64_t jc = (t0 + it - 1) * 16 + cl;
+                double xs = 0.0;
+                if (jc < a.M) {
+                    const int64_t idx = jc * CB + c;
+                    if (Snear) s += Snear[idx];
+                    s = s * iw[jc];
+                    const double xn = mfb_update(a, idx, jc, c, 2.0 * s + (a.GREG ? a.GREG[idx] : 0.0), mem == 0, pp);
+                    xs = xn * iw[jc];
+                }
+                xs_s[tid] = xs;
+            }
+        }
+        __syncthreads();
+        if (abort_s) return;
+        if (fin && wave < TL::PATCHES / 2) {
+            const double *pbuf = smem + (size_t)((it - 1) & 1) * TL::BUF;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double b = xs_s[(4 * u + k) * 16 + lo];
+                const double *sa = pbuf + (4 * u + k) * TL::S + lo;
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) accf[pq] = mfma_f64(sa[16 * (2 * wave + pq)], b, accf[pq]);
+            }
+        }
+        __syncthreads();  // (the next tile is staged into the buffer the forward just read)
+    }
+    double *out = f.slab + (int64_t)cr * a.ld * CB;
+    if (wave < TL::PATCHES / 2) {
+#pragma unroll
+        for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t row = (int64_t)rb0 * 64 + 16 * (2 * wave + pq) + k + 4 * q;
+                if (row < a.ld) out[row * CB + lo] = accf[pq][q];
+            }
+    }
+    if (mem == 0 && a.pp_part) {
+        if (tid < 256) ppred[tid >> 4][tid & 15] = pp;
+        __syncthreads();
+        if (tid < 16 && (a.phase[tid] == PH_PFIN || a.phase[tid] == PH_PFIN_SPEC)) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += ppred[r][tid];
+            a.pp_part[(int64_t)cr * CB + tid] = t;
+            // (the host sums n_pp rows: the two-pass adjoint writes more of them)
+            if (cr == 0)
+                for (int r = (int)gridDim.y; r < f.n_pp; ++r) a.pp_part[(int64_t)r * CB + tid] = 0.0;
+        }
+    }
     mfb_count(stats, nent, nleaf, lane);
 }
 

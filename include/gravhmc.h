@@ -268,6 +268,16 @@ int gh_batch_trajectory(gh_ctx *ctx, const double *p0s, double dt, const int *L,
 int gh_batch_run(gh_ctx *ctx, int T, const int *L, const double *const *p0_rows, const double *us,
                  double dt, int *accepted, double *out5s, double *x_out, int *n_started, int *n_done);
 int gh_batch_get_x(gh_ctx *ctx, int chain, double *x /* M */);
+/* Batched chains on a MATRIX-FREE context (gh_set_matrix_free): every entry a pass evaluates serves all
+ * chains (example/global/run_main.sh:16 runs its chains as separate ranks, each re-evaluating the whole
+ * tesseroid kernel, gravmag/_tesseroid_numba.py:32-71).  Two forms: an adjoint/update pass and a forward
+ * pass (two evaluations per entry and step, any N), or -- while every workgroup of the launch is
+ * resident, one per CU -- ONE pass in which the workgroups holding the row chunks of the same column tiles
+ * exchange their partial dots through memory (teams; csrc/mfbatch.hip.h).  members x ranges = grid of the
+ * team form (0: not in use), launches so far, timeouts: launches that gave up waiting (after the first the
+ * context stays on the two-pass form; gh_batch_trajectory repeats the round, gh_batch_run returns an error
+ * and wants gh_batch_init again). */
+int gh_batch_fused_stats(gh_ctx *ctx, int *members, int *ranges, int64_t *launches, int *timeouts);
 
 /* Posterior statistics without text I/O.  The reference appends every accepted
  * model as a '%.8f' text row to model.dat (hmc.py:328-332) and its plot scripts take np.mean /

@@ -45,11 +45,18 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("form", ["teams_one_evaluation", "two_passes", "teams_time_out"])
 @pytest.mark.parametrize("case", list(CASES))
-def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case):
+def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case, form):
+    """form: the fused team pass (one evaluation per entry and step), the two-pass kernels
+    (GRAVHMC_MFB_FUSED=0), or a team pass that gives up (test hook: its members wait for a part that never
+    comes) -- the round is then repeated with the two-pass kernels: same chains."""
+    if form == "teams_time_out" and case != "tess_fast_leaf_near_table":
+        pytest.skip("the time-out path is exercised once (2 s)")
     problem, exact, near, reg = CASES[case]
     monkeypatch.setenv("GRAVHMC_MF_EXACT", exact)
     monkeypatch.setenv("GRAVHMC_MF_NEAR", near)
+    monkeypatch.setenv("GRAVHMC_MFB_FUSED", "0" if form == "two_passes" else "1")
     obs, bounds, kind, shape = problem(G)
     N, M = obs[0].size, bounds.shape[0]
     rng = np.random.default_rng(5)
@@ -92,20 +99,30 @@ def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case
         singles.append(e)
     n_acc = n_rej = 0
     worst = 0.0
+    fs0 = eb.batch_fused_stats()
+    assert (fs0["members"] > 0) == (form != "two_passes"), fs0
     for it in range(3):
         Ls = rng.integers(1, 6, size=C)
         p0s = rng.normal(size=(C, M)) * sig
         us = rng.uniform(size=C) * (0.05 if it == 1 else 1.0)
+        if form == "teams_time_out" and it == 1:
+            monkeypatch.setenv("GRAVHMC_MFB_TEST_ABORT", "1")
         acc, out5 = eb.batch_trajectory(p0s, dt, Ls, us)
+        monkeypatch.delenv("GRAVHMC_MFB_TEST_ABORT", raising=False)
         for c in range(C):
             a1, o1 = singles[c].chain_trajectory(p0s[c], dt, int(Ls[c]), float(us[c]))
             assert a1 == acc[c], (case, it, c, o1, out5[c])
             worst = max(worst, relmax(out5[c], o1), relmax(eb.batch_get_x(c), singles[c].chain_get_x()))
             n_acc += a1
             n_rej += not a1
-    print("matrix-free batch [%s]: N %d M %d, %d chains, accepted %d rejected %d, worst deviation from the "
-          "single-chain matrix-free engine %.2e; near field %r" % (case, N, M, C, n_acc, n_rej, worst, st))
+    fs = eb.batch_fused_stats()
+    print("matrix-free batch [%s, %s]: N %d M %d, %d chains, accepted %d rejected %d, worst deviation from the "
+          "single-chain matrix-free engine %.2e; near field %r; team form %r" % (case, form, N, M, C, n_acc, n_rej, worst, st, fs))
     assert worst < 1e-10 and n_acc > 0
+    if form == "teams_one_evaluation":
+        assert fs["launches"] > 0 and fs["timeouts"] == 0
+    if form == "teams_time_out":
+        assert fs["timeouts"] == 1 and fs["members"] == 0     # gave up once, two-pass kernels from there on
     # against the DENSE single-chain engine as well (stored G: the reference's formulation)
     a = ed.misfit_and_grad(eb.batch_get_x(2))
     b = singles[2].misfit_and_grad(singles[2].chain_get_x())
