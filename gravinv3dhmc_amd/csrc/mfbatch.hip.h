@@ -227,6 +227,63 @@ __device__ __forceinline__ double mfb_update(const BatchAdjArgs &a, int64_t idx,
     return xo;
 }
 
+// The same with the pair's operands requested ahead (the fused team pass: the loads are in flight while
+// the adjoint MFMAs run and the team's parts are collected).
+struct MfbUpd {
+    double x, p, greg, pn, hi, lo, snear, iw;
+};
+
+__device__ __forceinline__ void mfb_upd_load(MfbUpd &u, const BatchAdjArgs &a, const double *Snear, const double *iw,
+                                             int64_t idx, int64_t jc)
+{
+    u.x = a.X_in[idx];
+    u.p = a.P_in[idx];
+    u.greg = a.GREG ? a.GREG[idx] : 0.0;
+    u.pn = a.Pn ? a.Pn[idx] : 0.0;
+    u.hi = a.high[jc];
+    u.lo = a.low[jc];
+    u.snear = Snear ? Snear[idx] : 0.0;
+    u.iw = iw[jc];
+}
+
+__device__ __forceinline__ double mfb_update_pre(const BatchAdjArgs &a, const MfbUpd &u, int64_t idx, int c, double gr,
+                                                 bool write, double &pp)
+{
+    const int ph = a.phase[c];
+    double xo = u.x, po = u.p;
+    if (ph == PH_GOUT) {
+        if (write) a.G_out[idx] = gr;
+        return xo;
+    }
+    if (ph == PH_UPD || ph == PH_PFIN_SPEC) {
+        if (ph == PH_PFIN_SPEC) {
+            const double pf = po - a.cp[c] * gr;
+            if (write) pp += pf * pf;
+            po = u.pn;
+        }
+        double pj = po - a.cu[c] * gr;
+        double xj = xo + a.dt * pj;
+        if (xj > u.hi) {
+            xj = u.hi;
+            pj = -pj;
+        } else if (xj < u.lo) {
+            xj = u.lo;
+            pj = -pj;
+        }
+        po = pj;
+        xo = xj;
+    } else if (ph == PH_PFIN) {
+        const double pf = po - a.cp[c] * gr;
+        if (write) pp += pf * pf;
+        po = pf;
+    }
+    if (write) {
+        a.P_out[idx] = po;
+        a.X_out[idx] = xo;
+    }
+    return xo;
+}
+
 // ---- adjoint of all chains + leapfrog update (hmc.py:114-152) ------------------------------------
 // BatchAdjArgs as batch_adjoint_kernel (G / Gb unused); iw = 1 / wm (1 where wm == 0), Snear =
 // near-field part of S (M x 16) or nullptr; pp_part has gridDim.x x 16 entries.
@@ -453,7 +510,7 @@ mfb_forward_kernel(MfGeom g, MfbFwdArgs a, const double *__restrict__ cellc, MfS
 // return at once and the host repeats the work with the two-pass kernels.
 constexpr int MFB_RC_FUS = 7;
 constexpr int MFB_FUS_ADJW = 7;     // waves that run the adjoint MFMAs, four row patches each
-constexpr int MFB_FUS_MAXMEM = 32;  // members of a team at most
+constexpr int MFB_FUS_MAXMEM = 20;  // members of a team at most (N <= 8960 rows)
 constexpr int MFB_FUS_RING = 4;
 constexpr size_t MFB_LDS_FUS = (2 * (size_t)MfbTile<MFB_RC_FUS>::BUF + (size_t)MFB_NOBS * MfbTile<MFB_RC_FUS>::ROWS +
                                 (size_t)MFB_FUS_ADJW * 256 + 4 * 256 + 256) * sizeof(double);  // 154112 B
@@ -497,21 +554,16 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
         of.fetch(g, (int64_t)rb0 * 64, tid);
         of.park(obs_s, tid);
     }
-    // adjoint: wave w < 7 contracts the row patches w, w + 7, w + 14, w + 21 of the member; their
-    // residual fragments never change during the launch
-    d2 ar0[4], ar1[4];
+    // adjoint: wave w < 7 contracts the row patches w, w + 7, w + 14, w + 21 of the member
+    const d2 *rt = reinterpret_cast<const d2 *>(a.Rt) + (k * 16 + lo);
     bool aok[4];
-    {
-        const d2 *rt = reinterpret_cast<const d2 *>(a.Rt) + (k * 16 + lo);
+    int agp[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = wave + MFB_FUS_ADJW * q;
-            const int gpi = mem * TL::PATCHES + p;
-            aok[q] = wave < MFB_FUS_ADJW && p < TL::PATCHES && gpi < a.np;
-            const int gc = aok[q] ? gpi : 0;
-            ar0[q] = rt[128 * gc];
-            ar1[q] = rt[128 * gc + 64];
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int p = wave + MFB_FUS_ADJW * q;
+        const int gpi = mem * TL::PATCHES + p;
+        aok[q] = wave < MFB_FUS_ADJW && p < TL::PATCHES && gpi < a.np;
+        agp[q] = aok[q] ? gpi : 0;
     }
     u64 *gteam = f.gran + (size_t)cr * MFB_FUS_RING * MFB_FUS_MAXMEM * 512;
     auto gran_of = [&](int it, int member) -> u64 * {
@@ -534,7 +586,14 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
             nent += (unsigned)nb;
         }
         __syncthreads();  // the tile is staged; everybody is done with the forward of tile it - 2
+        // this member's part of S for the tile just staged
         if (stg && wave < MFB_FUS_ADJW) {
+            d2 ar0[4], ar1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ar0[q] = rt[128 * agp[q]];
+                ar1[q] = rt[128 * agp[q] + 64];
+            }
             const double *sr = buf + lo * TL::S;
             d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -552,55 +611,74 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[wave * 256 + q * 64 + lane] = acc[q];
         }
+        // the parts of tile it - 1, published an iteration ago: thread (v, q) collects the members q, q + 4, ...
+        // -- every load requested before anything is looked at (one after the other, the round trips of
+        // the members stood in front of every tile's forward), from uniform bases at one lane offset
+        const int gv = tid & 255;
+        const int gq = __builtin_amdgcn_readfirstlane(tid >> 8);
+        const unsigned gtag = f.tag0 + (unsigned)it;  // tile it - 1 carries tag0 + (it - 1) + 1
+        u64 ga[MFB_FUS_MAXMEM / 4], gb[MFB_FUS_MAXMEM / 4];
+        MfbUpd up;
+        const int ucl = tid >> 4, uc = tid & 15;
+        const int64_t ujc = (t0 + it - 1) * 16 + ucl;
+        const bool uok = fin && tid < 256 && ujc < a.M;
         if (fin) {
-            // the parts of tile it - 1, published an iteration ago: thread (v, q) sums the members q, q + 4, ...
-            const int v = tid & 255, q = tid >> 8;
-            const unsigned tag = f.tag0 + (unsigned)it;  // tile it - 1 carries tag0 + (it - 1) + 1
+#pragma unroll
+            for (int i = 0; i < MFB_FUS_MAXMEM / 4; ++i) {
+                const int m = gq + 4 * i;
+                ga[i] = gb[i] = 0;
+                if (m < f.poll_members) ld_gran_issue(gran_of(it - 1, m) + 2 * gv, ga[i], gb[i]);
+            }
+            if (uok) mfb_upd_load(up, a, Snear, iw, ujc * CB + uc, ujc);
+        }
+        if (fin) {
             double sum = 0.0;
             bool ok = true;
-            for (int m = q; m < f.poll_members && ok; m += 4) {
-                double val = 0.0;
-                unsigned spins = 0;
-                long long tstart = 0;
-                while (!ld_gran(gran_of(it - 1, m) + 2 * v, tag, val)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 63u) == 0) {
-                        const long long now = wall_clock64();
-                        if (tstart == 0) tstart = now;
-                        if (__hip_atomic_load(f.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                            now - tstart > RES_TIMEOUT_TICKS) {
-                            __hip_atomic_store(f.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = false;
-                            break;
+#pragma unroll
+            for (int i = 0; i < MFB_FUS_MAXMEM / 4; ++i) {
+                const int m = gq + 4 * i;
+                if (m < f.poll_members) {
+                    double val = 0.0;
+                    if (!gran_value(ga[i], gb[i], gtag, val)) {
+                        // (a member lags by more than an iteration) poll until its part is there
+                        unsigned spins = 0;
+                        long long tstart = 0;
+                        while (ok && !ld_gran(gran_of(it - 1, m) + 2 * gv, gtag, val)) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((++spins & 63u) == 0) {
+                                const long long now = wall_clock64();
+                                if (tstart == 0) tstart = now;
+                                if (__hip_atomic_load(f.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                    now - tstart > RES_TIMEOUT_TICKS) {
+                                    __hip_atomic_store(f.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = false;
+                                }
+                            }
                         }
                     }
+                    sum += val;
                 }
-                sum += val;
             }
-            gp[q * 256 + v] = sum;
+            gp[gq * 256 + gv] = sum;
             if (!ok) abort_s = 1;
         }
         __syncthreads();
         if (tid < 256) {
-            const int cl = tid >> 4, c = tid & 15;
             if (stg) {
                 // this member's part of S for tile it (acc[q] of lane (lo, k): column k + 4 q, chain lo)
-                const int ridx = (cl >> 2) * 64 + (cl & 3) * 16 + c;
-                double s = 0.0;
+                const int ridx = (ucl >> 2) * 64 + (ucl & 3) * 16 + uc;
+                double sp = 0.0;
 #pragma unroll
-                for (int w = 0; w < MFB_FUS_ADJW; ++w) s += red[w * 256 + ridx];
-                st_gran(gran_of(it, mem) + 2 * tid, f.tag0 + (unsigned)it + 1u, s);
+                for (int w = 0; w < MFB_FUS_ADJW; ++w) sp += red[w * 256 + ridx];
+                st_gran(gran_of(it, mem) + 2 * tid, f.tag0 + (unsigned)it + 1u, sp);
             }
             if (fin) {
-                double s = ((gp[tid] + gp[256 + tid]) + gp[512 + tid]) + gp[768 + tid];
-                const int64_t jc = (t0 + it - 1) * 16 + cl;
                 double xs = 0.0;
-                if (jc < a.M) {
-                    const int64_t idx = jc * CB + c;
-                    if (Snear) s += Snear[idx];
-                    s = s * iw[jc];
-                    const double xn = mfb_update(a, idx, jc, c, 2.0 * s + (a.GREG ? a.GREG[idx] : 0.0), mem == 0, pp);
-                    xs = xn * iw[jc];
+                if (uok) {
+                    double st = ((gp[tid] + gp[256 + tid]) + gp[512 + tid]) + gp[768 + tid];
+                    st = (st + up.snear) * up.iw;
+                    const double xn = mfb_update_pre(a, up, ujc * CB + uc, uc, 2.0 * st + up.greg, mem == 0, pp);
+                    xs = xn * up.iw;
                 }
                 xs_s[tid] = xs;
             }
