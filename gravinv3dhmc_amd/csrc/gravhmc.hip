@@ -1652,6 +1652,18 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
     return GH_OK;
 }
 
+// Diagnostic (not in the public header): accumulated phase times of the fused matrix-free batch pass
+// (GRAVHMC_MFB_TIMING=1), 100 MHz ticks of workgroup (0, 0).
+int gh_debug_mfb_timing(gh_ctx *c, long long out8[8])
+{
+    if (!c || !out8) return GH_ERR_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!c->bt.fus_dbg) return GH_OK;
+    HIPCHK(c, hipMemcpyAsync(out8, c->bt.fus_dbg, 8 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
 int gh_batch_fused_stats(gh_ctx *c, int *members, int *ranges, int64_t *launches, int *timeouts)
 {
     if (!c) return GH_ERR_ARG;

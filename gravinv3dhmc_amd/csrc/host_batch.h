@@ -211,6 +211,11 @@ static int batch_launch_adjoint(gh_ctx *c, BatchAdjArgs &a, bool fwd_follows)
         // test hook: the members wait for a part that never comes, time out and give up
         f.poll_members = b.fus_members + ((env_int("GRAVHMC_MFB_TEST_ABORT", 0) && b.fus_members < MFB_FUS_MAXMEM) ? 1 : 0);
         f.n_pp = b.n_waves;
+        f.dbg = nullptr;
+        if (env_int("GRAVHMC_MFB_TIMING", 0)) {
+            TRY(dalloc(c, &b.fus_dbg, 8));
+            f.dbg = b.fus_dbg;
+        }
         TRY(batch_time_begin(c, timed));
         hipLaunchKernelGGL(mfb_fus_for(c), dim3((unsigned)b.fus_members, (unsigned)b.fus_ranges), dim3(1024), MFB_LDS_FUS,
                            c->stream, mf_geom(c), a, f, b.iw, c->cell_kind == GH_CELL_TESSEROID ? c->mf_cellc : nullptr,

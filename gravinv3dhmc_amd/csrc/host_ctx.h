@@ -194,6 +194,7 @@ struct gh_ctx {
         int fus_members = 0, fus_ranges = 0, fus_tpr = 0, fus_aborts = 0;
         ghk::u64 *fus_gran = nullptr;
         unsigned *fus_abort = nullptr;
+        long long *fus_dbg = nullptr;  // GRAVHMC_MFB_TIMING: per-phase clocks of one workgroup
         unsigned fus_tag = 0;
         int64_t fus_launches = 0;
         const double *fus_fwd_of = nullptr;  // the X whose forward partials the last fused launch left in the slab

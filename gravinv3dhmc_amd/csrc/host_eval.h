@@ -183,7 +183,7 @@ static int ensure_work(gh_ctx *c)
         TRY(dalloc(c, &c->slab2, (size_t)c->slab2_rows * ld));
     }
     c->n_dpart = (int)((c->ld + 31) / 32);
-    if (c->ld >= 2048 && c->TW > 1 && c->n_panels == 1 && !c->mf && env_int("GRAVHMC_EPILOGUE1", 1) != 0) {
+    if (c->ld >= 2048 && ((c->TW > 1 && c->n_panels == 1 && !c->mf) || lonsym_on(c)) && env_int("GRAVHMC_EPILOGUE1", 1) != 0) {
         TRY(dalloc(c, &c->dsum, (size_t)c->grid));
         for (int i = 0; i < 4; ++i) TRY(dalloc(c, &c->st[i].part, (size_t)c->n_dpart + (size_t)((c->M + 255) / 256)));
     }

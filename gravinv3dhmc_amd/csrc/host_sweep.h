@@ -521,7 +521,13 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
         c->slab_live = c->grid;
         c->dsum_live = false;
     }
-    if (c->mf) return launch_mf(c, a);
+    if (c->mf) {
+        if (lonsym_on(c) && (a.mode & SW_FWD) && c->dsum) {
+            a.dsum = c->dsum;  // (the shift-invariant pass delivers the sums of its slab rows as well)
+            c->dsum_live = true;
+        }
+        return launch_mf(c, a);
+    }
     if (c->n_panels == 1) {
         a.row0 = 0;
         a.rows = c->ld;

@@ -211,7 +211,17 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
         }
         __syncthreads();
         double *out = a.slab + (int64_t)blockIdx.x * a.ld;
-        for (int64_t i = tid; i < a.ld; i += LS_THREADS) out[i] = i < g.N ? Tc[g.lds_of[i]] : 0.0;
+        double rs = 0.0;
+        for (int64_t i = tid; i < a.ld; i += LS_THREADS) {
+            const double v = i < g.N ? Tc[g.lds_of[i]] : 0.0;
+            out[i] = v;
+            rs += v;
+        }
+        if (a.dsum) {
+            // (sum of this workgroup's slab row: the epilogue then knows mean(d) up front and needs one launch)
+            const double t = block_allreduce_sum(rs, red, LS_WAVES);
+            if (tid == 0) a.dsum[blockIdx.x] = t;
+        }
     }
 }
 

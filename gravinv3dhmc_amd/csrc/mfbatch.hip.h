@@ -157,7 +157,25 @@ template <int KIND, int ROWS, typename F>
 __device__ __forceinline__ void mfb_stage(const MfbCol<KIND> &col, const MfGeom &g, const double *ob, int nb, int lane,
                                           double *st, unsigned &nleaf, F between)
 {
-    // (unrolled: between(e) picks its operands by e -- as a run-time index that is a chain of selects)
+    // (unrolled: between(e) picks its operands by e -- as a run-time index that is a chain of selects;
+    // a full chunk, the usual case, without a branch per evaluation: the next evaluation's LDS reads
+    // may then move up into this one instead of being waited for at its start)
+    if (nb == ROWS / 64) {
+        double o[2][5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) o[0][q] = q < mfb_nobs<KIND>() ? ob[q * ROWS + lane] : 0.0;
+#pragma unroll
+        for (int e = 0; e < ROWS / 64; ++e) {
+            if (e + 1 < ROWS / 64) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) o[(e + 1) & 1][q] = q < mfb_nobs<KIND>() ? ob[q * ROWS + (e + 1) * 64 + lane] : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (the reads above stay in front of this evaluation)
+            st[e * 64 + lane] = mfb_eval<KIND>(col, g, o[e & 1], nleaf);
+            between(e);
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < ROWS / 64; ++e) {
         if (e < nb) {
@@ -246,10 +264,11 @@ __device__ __forceinline__ void mfb_upd_load(MfbUpd &u, const BatchAdjArgs &a, c
     u.iw = iw[jc];
 }
 
-__device__ __forceinline__ double mfb_update_pre(const BatchAdjArgs &a, const MfbUpd &u, int64_t idx, int c, double gr,
-                                                 bool write, double &pp)
+// (ph, cu, cp: the chain's phase and coefficients, read once per launch -- indexed by the thread they
+// are loads from the kernel-argument segment, a memory round trip in front of every tile's update)
+__device__ __forceinline__ double mfb_update_pre(const BatchAdjArgs &a, const MfbUpd &u, int64_t idx, int ph, double cu,
+                                                 double cp, double gr, bool write, double &pp)
 {
-    const int ph = a.phase[c];
     double xo = u.x, po = u.p;
     if (ph == PH_GOUT) {
         if (write) a.G_out[idx] = gr;
@@ -257,11 +276,11 @@ __device__ __forceinline__ double mfb_update_pre(const BatchAdjArgs &a, const Mf
     }
     if (ph == PH_UPD || ph == PH_PFIN_SPEC) {
         if (ph == PH_PFIN_SPEC) {
-            const double pf = po - a.cp[c] * gr;
+            const double pf = po - cp * gr;
             if (write) pp += pf * pf;
             po = u.pn;
         }
-        double pj = po - a.cu[c] * gr;
+        double pj = po - cu * gr;
         double xj = xo + a.dt * pj;
         if (xj > u.hi) {
             xj = u.hi;
@@ -273,7 +292,7 @@ __device__ __forceinline__ double mfb_update_pre(const BatchAdjArgs &a, const Mf
         po = pj;
         xo = xj;
     } else if (ph == PH_PFIN) {
-        const double pf = po - a.cp[c] * gr;
+        const double pf = po - cp * gr;
         if (write) pp += pf * pf;
         po = pf;
     }
@@ -523,6 +542,7 @@ struct MfbFusArgs {
     unsigned *abort_w;
     int poll_members;    // gridDim.x (+ 1 in the time-out test: one part never comes)
     int n_pp;            // rows of pp_part the host sums (those beyond the ranges are zeroed)
+    long long *dbg;      // optional: 8 accumulated phase times (100 MHz ticks) of workgroup (0, 0), wave 0
 };
 
 template <int KIND>
@@ -532,11 +552,13 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double ppred[16][17];
+    __shared__ double chs[3][16];  // phase, cu, cp of the chains
+    __shared__ long long tph_s[9];
     __shared__ int abort_s;
     using TL = MfbTile<MFB_RC_FUS>;
     double *obs_s = smem + 2 * TL::BUF;                  // MFB_NOBS x ROWS
     double *red = obs_s + MFB_NOBS * TL::ROWS;           // MFB_FUS_ADJW x 256: the adjoint waves' accumulators
-    double *gp = red + MFB_FUS_ADJW * 256;               // 4 x 256: sums over the members q, q + 4, ...
+    double *gp = red + MFB_FUS_ADJW * 256;               // 2 x 256: sums over the members q, q + 2, ...
     double *xs_s = gp + 4 * 256;                         // 256: XS of the tile being finished, [col][chain]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -572,8 +594,29 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
     d4 accf[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
     double pp = 0.0;
     unsigned nent = 0, nleaf = 0;
+    // the chain of this thread in the exchange / the update never changes: its phase and coefficients once
+    // (parked in LDS: as registers they push the evaluation loop into spills)
+    if (tid < 16) {
+        chs[0][tid] = (double)a.phase[tid];
+        chs[1][tid] = a.cu[tid];
+        chs[2][tid] = a.cp[tid];
+    }
+    const bool my_live = a.phase[tid & 15] != PH_IDLE;  // (idle chains -- and the unused slots of a batch of < 16 -- exchange nothing)
     __syncthreads();
     if (abort_s) return;  // an earlier launch of this stream gave up: the host repeats the work
+    // (per-phase clocks of one thread, kept in LDS: as registers they cost every thread 18 VGPRs)
+    const bool clk = f.dbg != nullptr && mem == 0 && cr == 0 && tid == 0;
+    if (clk) {
+        for (int q = 0; q < 8; ++q) tph_s[q] = 0;
+        tph_s[8] = wall_clock64();
+    }
+    auto mark = [&](int ph) {
+        if (clk) {
+            const long long now = wall_clock64();
+            tph_s[ph] += now - tph_s[8];
+            tph_s[8] = now;
+        }
+    };
     for (int it = 0; it <= ntl; ++it) {
         const bool stg = it < ntl, fin = it >= 1;
         double *buf = smem + (size_t)(it & 1) * TL::BUF;
@@ -585,8 +628,21 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
             mfb_stage<KIND, TL::ROWS>(col, g, obs_s, nb, lane, buf + wave * TL::S, nleaf, [](int) {});
             nent += (unsigned)nb;
         }
+        mark(0);
         __syncthreads();  // the tile is staged; everybody is done with the forward of tile it - 2
-        // this member's part of S for the tile just staged
+        mark(1);
+        // Waves 0 .. 6: this member's part of S for the tile just staged (adjoint MFMAs).  Waves 8 .. 15
+        // meanwhile: the parts of tile it - 1, published an iteration ago -- thread (v, q) collects the
+        // members q, q + 2, ...: every load requested before anything is looked at, from uniform bases at
+        // one lane offset; waves 8 .. 11 also request the operands of the update of their (cell, chain).
+        const int gv = tid & 255;
+        const int gq = __builtin_amdgcn_readfirstlane((tid >> 8) & 1);
+        const unsigned gtag = f.tag0 + (unsigned)it;  // tile it - 1 carries tag0 + (it - 1) + 1
+        MfbUpd up;
+        const int ucl = gv >> 4, uc = gv & 15;
+        const int64_t ujc = (t0 + it - 1) * 16 + ucl;
+        const bool uthr = wave >= 8 && wave < 12;      // threads 512 .. 767: one per (cell, chain) of the tile
+        const bool uok = fin && uthr && ujc < a.M;
         if (stg && wave < MFB_FUS_ADJW) {
             d2 ar0[4], ar1[4];
 #pragma unroll
@@ -611,33 +667,21 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[wave * 256 + q * 64 + lane] = acc[q];
         }
-        // the parts of tile it - 1, published an iteration ago: thread (v, q) collects the members q, q + 4, ...
-        // -- every load requested before anything is looked at (one after the other, the round trips of
-        // the members stood in front of every tile's forward), from uniform bases at one lane offset
-        const int gv = tid & 255;
-        const int gq = __builtin_amdgcn_readfirstlane(tid >> 8);
-        const unsigned gtag = f.tag0 + (unsigned)it;  // tile it - 1 carries tag0 + (it - 1) + 1
-        u64 ga[MFB_FUS_MAXMEM / 4], gb[MFB_FUS_MAXMEM / 4];
-        MfbUpd up;
-        const int ucl = tid >> 4, uc = tid & 15;
-        const int64_t ujc = (t0 + it - 1) * 16 + ucl;
-        const bool uok = fin && tid < 256 && ujc < a.M;
-        if (fin) {
+        if (fin && wave >= 8) {
+            u64 ga[MFB_FUS_MAXMEM / 2], gb[MFB_FUS_MAXMEM / 2];
 #pragma unroll
-            for (int i = 0; i < MFB_FUS_MAXMEM / 4; ++i) {
-                const int m = gq + 4 * i;
+            for (int i = 0; i < MFB_FUS_MAXMEM / 2; ++i) {
+                const int m = gq + 2 * i;
                 ga[i] = gb[i] = 0;
-                if (m < f.poll_members) ld_gran_issue(gran_of(it - 1, m) + 2 * gv, ga[i], gb[i]);
+                if (m < f.poll_members && my_live) ld_gran_issue(gran_of(it - 1, m) + 2 * gv, ga[i], gb[i]);
             }
             if (uok) mfb_upd_load(up, a, Snear, iw, ujc * CB + uc, ujc);
-        }
-        if (fin) {
             double sum = 0.0;
             bool ok = true;
 #pragma unroll
-            for (int i = 0; i < MFB_FUS_MAXMEM / 4; ++i) {
-                const int m = gq + 4 * i;
-                if (m < f.poll_members) {
+            for (int i = 0; i < MFB_FUS_MAXMEM / 2; ++i) {
+                const int m = gq + 2 * i;
+                if (m < f.poll_members && my_live) {
                     double val = 0.0;
                     if (!gran_value(ga[i], gb[i], gtag, val)) {
                         // (a member lags by more than an iteration) poll until its part is there
@@ -662,28 +706,34 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
             gp[gq * 256 + gv] = sum;
             if (!ok) abort_s = 1;
         }
+        mark(2);
         __syncthreads();
-        if (tid < 256) {
-            if (stg) {
-                // this member's part of S for tile it (acc[q] of lane (lo, k): column k + 4 q, chain lo)
-                const int ridx = (ucl >> 2) * 64 + (ucl & 3) * 16 + uc;
+        mark(3);
+        if (stg && tid < 256) {
+            // this member's part of S for tile it (acc[q] of lane (lo, k): column k + 4 q, chain lo)
+            const int cl = tid >> 4, c = tid & 15;
+            const int ridx = (cl >> 2) * 64 + (cl & 3) * 16 + c;
+            if (my_live) {
                 double sp = 0.0;
 #pragma unroll
                 for (int w = 0; w < MFB_FUS_ADJW; ++w) sp += red[w * 256 + ridx];
                 st_gran(gran_of(it, mem) + 2 * tid, f.tag0 + (unsigned)it + 1u, sp);
             }
-            if (fin) {
-                double xs = 0.0;
-                if (uok) {
-                    double st = ((gp[tid] + gp[256 + tid]) + gp[512 + tid]) + gp[768 + tid];
-                    st = (st + up.snear) * up.iw;
-                    const double xn = mfb_update_pre(a, up, ujc * CB + uc, uc, 2.0 * st + up.greg, mem == 0, pp);
-                    xs = xn * up.iw;
-                }
-                xs_s[tid] = xs;
-            }
         }
+        if (fin && uthr) {
+            double xs = 0.0;
+            if (uok) {
+                double st = gp[gv] + gp[256 + gv];
+                st = (st + up.snear) * up.iw;
+                const double xn = mfb_update_pre(a, up, ujc * CB + uc, (int)chs[0][uc], chs[1][uc], chs[2][uc],
+                                                 2.0 * st + up.greg, mem == 0, pp);
+                xs = xn * up.iw;
+            }
+            xs_s[gv] = xs;
+        }
+        mark(4);
         __syncthreads();
+        mark(5);
         if (abort_s) return;
         if (fin && wave < TL::PATCHES / 2) {
             const double *pbuf = smem + (size_t)((it - 1) & 1) * TL::BUF;
@@ -695,8 +745,12 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
                 for (int pq = 0; pq < 2; ++pq) accf[pq] = mfma_f64(sa[16 * (2 * wave + pq)], b, accf[pq]);
             }
         }
+        mark(6);
         __syncthreads();  // (the next tile is staged into the buffer the forward just read)
+        mark(7);
     }
+    if (clk)
+        for (int q = 0; q < 8; ++q) f.dbg[q] += tph_s[q];
     double *out = f.slab + (int64_t)cr * a.ld * CB;
     if (wave < TL::PATCHES / 2) {
 #pragma unroll
@@ -708,7 +762,7 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
             }
     }
     if (mem == 0 && a.pp_part) {
-        if (tid < 256) ppred[tid >> 4][tid & 15] = pp;
+        if (tid >= 512 && tid < 768) ppred[(tid - 512) >> 4][tid & 15] = pp;
         __syncthreads();
         if (tid < 16 && (a.phase[tid] == PH_PFIN || a.phase[tid] == PH_PFIN_SPEC)) {
             double t = 0.0;

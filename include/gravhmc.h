@@ -18,6 +18,26 @@
  *   - dense matrices are column-major N x M ("Fortran order": one cell = one contiguous column
  *     of N observations), the layout the reference ends up with for Aw (potential.py:259).
  *   - there is no CPU fallback: without a usable HIP device gh_create fails.
+ *
+ * Environment switches read by the library (diagnostics and A/B measurements; the defaults are what
+ * the tests pin and what DESIGN.md's numbers were measured with).  Part of this interface:
+ *   code path, SAME arithmetic to rounding of the summation order (results agree to <= 1e-12):
+ *     GRAVHMC_RESIDENT=0 (no resident chain kernel), GRAVHMC_RESIDENT_LOCAL / _REGS / _STREAM /
+ *     _STREAM_MB / _CT / _WGS (its variants), GRAVHMC_TEAM=0 / GRAVHMC_TEAM_LAG (N > 16384: row panels
+ *     / lag of the team sweep), GRAVHMC_EPILOGUE1=0 (two-launch epilogue), GRAVHMC_MF_FUSED=0 /
+ *     GRAVHMC_MF_PIPE=0 / GRAVHMC_MF_NEAR=0 (matrix-free: two-pass form / plain build / subdivision
+ *     inside the pass instead of the near-field table), GRAVHMC_MFB_FUSED=0 (matrix-free batch: two
+ *     passes instead of teams), GRAVHMC_MFB_RU=0 (no one-height specialisation), GRAVHMC_BATCH_SPEC=0,
+ *     GRAVHMC_BATCH_RELAYOUT=0, GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
+ *   arithmetic of an entry (within the path's stated 1e-10, ~1e-14 measured): GRAVHMC_MF_EXACT -- the
+ *     DEFAULT of gh_set_matrix_free_exact only; that call overrides it;
+ *   tuning without any effect on results: GRAVHMC_PF, _NT, _TW, _TW8, _WG_PER_CU, _MIN_COLS,
+ *     _INFLIGHT_MB, GRAVHMC_MF_T, _MF_WG_PER_CU, GRAVHMC_MFB_WG_PER_CU, _MFB_RANGES, GRAVHMC_RNG_THREADS;
+ *   test hooks (force a time-out path): GRAVHMC_TEAM_TEST_ABORT, GRAVHMC_RESIDENT_TEST_ABORT,
+ *     GRAVHMC_MFB_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, and
+ *     GRAVHMC_RESIDENT_TIMING (per-phase clocks, results intact).
+ * (Python side: GRAVHMC_HOST_RNG=numpy draws with np.random itself -- same stream; GRAVHMC_LIB = path
+ * of the shared library.)
  */
 #ifndef GRAVHMC_H
 #define GRAVHMC_H

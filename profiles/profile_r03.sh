@@ -39,6 +39,19 @@ if [ $which = all ] || [ $which = c4b ]; then
     cp $OUT/c4b_trace.json $SUM/bench_c4_matrix_free_8chains_under_rocprof_trace.json
   fi
 fi
+if [ $which = all ] || [ $which = c4b2 ]; then
+  # the two-pass form of the same workload (no co-residency needed): GRAVHMC_MFB_FUSED=0
+  export GRAVHMC_MFB_FUSED=0
+  A="--workload c4_global_tesseroid --matrix-free --chains-per-gpu 8 --no-cpu-baseline"
+  if prof c4b2_trace --kernel-trace --stats -- $A --steps 100 --warmup 20 \
+     && prof c4b2_sq --pmc $SQ1 --kernel-trace -- $A --steps 20 --warmup 0 \
+     && prof c4b2_sq2 --pmc $SQ2 --kernel-trace -- $A --steps 20 --warmup 0; then
+    python3 $REPO/profiles/summarize.py stats $OUT/c4b2_trace $SUM/c4_matrix_free_8chains_two_pass_kernel_stats.csv
+    python3 $REPO/profiles/summarize.py pmc $SUM/c4_matrix_free_8chains_two_pass_pmc_summary.json "GRAVHMC_MFB_FUSED=0 rocprofv3 --pmc passes (SQ counters, with --kernel-trace only) of python3 bench.py $A --steps 20 --warmup 0 on MI355X; recipe profiles/profile_r03.sh; per-dispatch averages; SQ cycle counters in quad-cycles summed over the chip" $OUT/c4b2_sq $OUT/c4b2_sq2
+    cp $OUT/c4b2_trace.json $SUM/bench_c4_matrix_free_8chains_two_pass_under_rocprof_trace.json
+  fi
+  unset GRAVHMC_MFB_FUSED
+fi
 if [ $which = all ] || [ $which = c4s ]; then
   A="--workload c4_global_tesseroid --shift-invariant --no-cpu-baseline"
   if prof c4s_trace --kernel-trace --stats -- $A --steps 2000 --warmup 200 \
