@@ -1403,6 +1403,10 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
     TRY(dalloc(c, &b.scal2, CB * 4));
     TRY(dalloc(c, &b.Pn, (size_t)n16));
     TRY(dalloc(c, &b.pn0_part, (size_t)b.n_pp0 * CB));
+    // (matrix-free team pass: the momentum every trajectory in flight started with, so that the
+    // trajectories can be replayed if a pass gives up)
+    const bool keep_pstart = c->mf && b.fus_on;
+    if (keep_pstart) TRY(dalloc(c, &b.Pstart, (size_t)n16));
     // two working sets: a sweep reads set run.ws, the evaluation behind it writes the other one
     double *GREGs[2] = {b.GREGw, b.GREGw2}, *Ds[2] = {b.Dw, b.Dw2}, *Rts[2] = {b.Rtw, b.Rtw2},
            *scals[2] = {b.scal, b.scal2};
@@ -1473,6 +1477,7 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         for (int ch = 0; ch < C; ++ch)
             if ((mask & (1u << ch)) && !staged[ch]) TRY(upload(ch, c->stream));
         scatter_staged(mask, b.Pw[run.pin]);
+        if (keep_pstart) batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Pw[run.pin], b.Pstart, n16, mask);
         batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xc, b.Xw[run.xi], n16, mask);
         batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, GREGs[run.ws], n16, mask);
         batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, Ds[run.ws], l16, mask);
@@ -1581,12 +1586,28 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
                                      hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         {
+            // a team pass since the last look gave up: what the trajectories in flight accumulated since is
+            // void, the chains' current states are intact (nothing is committed before this point) -- every
+            // active chain starts its trajectory again from its current state and its own momentum, on the
+            // two-pass kernels (which need no co-residency)
             bool failed = false;
             TRY(mfb_fused_failed(c, &failed));
-            if (failed)
-                return fail(c, GH_ERR_HIP, "gh_batch_run: the fused matrix-free batch pass timed out (is the GPU shared with "
-                                           "another process?); the trajectories in flight are lost -- call gh_batch_init again "
-                                           "(the two-pass kernels are used from here on; GRAVHMC_MFB_FUSED=0 selects them up front)");
+            if (failed) {
+                if (!b.Pstart) return fail(c, GH_ERR_HIP, "gh_batch_run: the fused matrix-free batch pass timed out");
+                unsigned act = 0;
+                for (int k = 0; k < C; ++k)
+                    if (run.active[k]) {
+                        act |= 1u << k;
+                        run.s_of[k] = 0;
+                    }
+                batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Pstart, b.Pw[run.pin], n16, act);
+                batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Xc, b.Xw[run.xi], n16, act);
+                batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.GREGc, GREGs[run.ws], n16, act);
+                batch_commit_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Dc, Ds[run.ws], l16, act);
+                batch_commit_rt_kernel<<<blocks(l16), dim3(256), 0, c->stream>>>(b.Rtc, Rts[run.ws], l16, act);
+                HIPCHK(c, hipGetLastError());
+                continue;
+            }
         }
         unsigned mask = 0;
         // result slots per chain: T, plus one in carry-over mode for the trajectory that came in flight
@@ -1635,6 +1656,7 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
                     double s = 0.0;
                     for (int w = 0; w < b.n_pp0; ++w) s += h[h_pn0 + (size_t)w * CB + k];
                     take_next(k, s, 1);
+                    if (keep_pstart) batch_commit_kernel<<<blocks(n16), dim3(256), 0, c->stream>>>(b.Pn, b.Pstart, n16, 1u << k);
                 }
             }
     }

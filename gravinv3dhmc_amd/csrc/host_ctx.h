@@ -195,6 +195,7 @@ struct gh_ctx {
         ghk::u64 *fus_gran = nullptr;
         unsigned *fus_abort = nullptr;
         long long *fus_dbg = nullptr;  // GRAVHMC_MFB_TIMING: per-phase clocks of one workgroup
+        double *Pstart = nullptr;      // M x 16: the momentum each trajectory in flight started with (gh_batch_run)
         unsigned fus_tag = 0;
         int64_t fus_launches = 0;
         const double *fus_fwd_of = nullptr;  // the X whose forward partials the last fused launch left in the slab

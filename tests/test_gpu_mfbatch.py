@@ -45,14 +45,14 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("form", ["teams_one_evaluation", "two_passes", "teams_time_out"])
+@pytest.mark.parametrize("form", ["teams_one_evaluation", "two_passes", "teams_time_out", "teams_time_out_desync"])
 @pytest.mark.parametrize("case", list(CASES))
 def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case, form):
     """form: the fused team pass (one evaluation per entry and step), the two-pass kernels
     (GRAVHMC_MFB_FUSED=0), or a team pass that gives up (test hook: its members wait for a part that never
     comes) -- the round is then repeated with the two-pass kernels: same chains."""
-    if form == "teams_time_out" and case != "tess_fast_leaf_near_table":
-        pytest.skip("the time-out path is exercised once (2 s)")
+    if form.startswith("teams_time_out") and case != "tess_fast_leaf_near_table":
+        pytest.skip("the time-out paths are exercised once each (2 s)")
     problem, exact, near, reg = CASES[case]
     monkeypatch.setenv("GRAVHMC_MF_EXACT", exact)
     monkeypatch.setenv("GRAVHMC_MF_NEAR", near)
@@ -123,6 +123,10 @@ def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case
         assert fs["launches"] > 0 and fs["timeouts"] == 0
     if form == "teams_time_out":
         assert fs["timeouts"] == 1 and fs["members"] == 0     # gave up once, two-pass kernels from there on
+    if form == "teams_time_out_desync":
+        # a team pass gives up in the middle of gh_batch_run: the trajectories in flight are replayed from
+        # their chains' current states and their own momenta (kept on the device), on the two-pass kernels
+        monkeypatch.setenv("GRAVHMC_MFB_TEST_ABORT", "1")
     # against the DENSE single-chain engine as well (stored G: the reference's formulation)
     a = ed.misfit_and_grad(eb.batch_get_x(2))
     b = singles[2].misfit_and_grad(singles[2].chain_get_x())
@@ -134,6 +138,10 @@ def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case
     p0s = rng.normal(size=(C, T, M)) * sig
     us = rng.uniform(size=(C, T))
     acc_a, out_a, xs_a = eb.batch_run(p0s, dt, Ls, us, want_x=True)
+    monkeypatch.delenv("GRAVHMC_MFB_TEST_ABORT", raising=False)
+    if form == "teams_time_out_desync":
+        fs = eb.batch_fused_stats()
+        assert fs["timeouts"] == 1 and fs["members"] == 0, fs
     for t in range(T):
         for c in range(C):
             a1, o1 = singles[c].chain_trajectory(p0s[c, t], dt, int(Ls[c, t]), float(us[c, t]))
@@ -296,3 +304,43 @@ def test_shift_invariant_store_refuses_irregular_geometry(G):
         with pytest.raises(NotImplementedError, match="shift-invariant"):
             e.build_G()
         e.close()
+
+
+def test_hmcsample_batch_on_a_matrix_free_global_model(G, tmp_path, capsys):
+    """The reference's `mpiexec -n K python main_global.py` (example/global/run_main.sh:16) on ONE GPU without
+    a stored kernel: HMCSampleBatch over a matrix-free spherical GravMagModule -- chains = ranks 0..2, each
+    its own legacy RandomState(seed + rank), folder and console lines -- against separate HMCSample(myrank=r)
+    runs on the DENSE module: the same console lines (7 printed digits), the same model.dat rows."""
+    rng = np.random.default_rng(21)
+    mrange, mspacing = (-180, 180, -90, 90, 0, -3000000), (-1000000, 15, 10)
+    lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 10.0), np.arange(-90, 91, 15.0), indexing="ij")]
+    h = np.full_like(lon, 30000.0)
+    mesh = G.mesher.TesseroidMesh(mrange, mspacing)
+    M, N = mesh.size, lon.size
+    probe = G.GravMagModule(np.zeros(N), mrange, mspacing, (lon, lat, h), coordinate="spherical", verbose=False)
+    rho = np.zeros(mesh.shape)
+    rho[1:, 4:8, 10:20] = 0.3
+    dobs = probe._engine.forward(probe.Wm.diagonal() * rho.ravel()) * (1.0 + 0.01 * rng.normal(size=N))
+    probe._engine.close()
+    args = (np.full(M, 0.001), np.full(M, 0.001), np.c_[np.zeros(M), np.full(M, 0.8)], "mandatory", 1000, dobs,
+            "Fixed", 0.8, 0.05, "Damping", 0.01, 100, 0.001)
+    nsamp, dt = 6, 0.005
+    gm = G.GravMagModule(dobs, mrange, mspacing, (lon, lat, h), coordinate="spherical", verbose=False,
+                         matrix_free=True)
+    capsys.readouterr()
+    G.HMCSampleBatch(gm, 3, nsamp, 0, dt, [5, 20], *args, save_folder=str(tmp_path / "mfbatch_chain"))
+    out = capsys.readouterr().out.splitlines()
+    fs = gm._engine.batch_fused_stats()
+    assert fs["launches"] > 0 and fs["timeouts"] == 0, fs
+    for r in range(3):
+        gs = G.GravMagModule(dobs, mrange, mspacing, (lon, lat, h), coordinate="spherical", verbose=False)
+        capsys.readouterr()
+        G.HMCSample(gs, nsamp, 0, dt, [5, 20], *args, myrank=r, save_folder=str(tmp_path / "dense_chain"))
+        single = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain %d:" % r)]
+        assert [l for l in out if l.startswith("chain %d:" % r)] == single
+        a = np.loadtxt(str(tmp_path / ("mfbatch_chain%d" % r)) + "/model.dat")
+        b = np.loadtxt(str(tmp_path / ("dense_chain%d" % r)) + "/model.dat")
+        assert a.shape == (nsamp, M)
+        np.testing.assert_allclose(a, b, atol=2e-8)
+        gs._engine.close()
+    gm._engine.close()
