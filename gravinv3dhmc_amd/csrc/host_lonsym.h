@@ -9,14 +9,15 @@ struct LonSymHost {
     double *T = nullptr;
     int *slot_ptr = nullptr, *slot_obs = nullptr, *lds_of = nullptr, *a_of = nullptr, *m_of = nullptr;
     size_t lds = 0;
-    int grid = 0, items = 1;  // items: work items per wave (instantiation of the kernel)
+    int grid = 0, items = 1, W = 8, thr = 1024;  // items: work items per wave, W: longitudes per work item (instantiation of the kernel)
     std::string why;  // why the geometry does not qualify (gh_last_error text)
 };
 
 typedef void (*lonsym_fn_t)(LonSymGeom, SweepArgs, const double *);
-static lonsym_fn_t lonsym_fn(int items)
+static lonsym_fn_t lonsym_fn(int items, int W, int T)
 {
-    return items <= 1 ? lonsym_sweep_kernel<1> : items <= 2 ? lonsym_sweep_kernel<2> : lonsym_sweep_kernel<4>;
+    if (W == 16) return T == 512 ? lonsym_sweep_kernel<1, 16, 512> : lonsym_sweep_kernel<1, 16, 1024>;
+    return items <= 1 ? lonsym_sweep_kernel<1, 8, 1024> : items <= 2 ? lonsym_sweep_kernel<2, 8, 1024> : lonsym_sweep_kernel<4, 8, 1024>;
 }
 
 static LonSymGeom lonsym_geom(const gh_ctx *c)
@@ -100,13 +101,19 @@ static int lonsym_build(gh_ctx *c)
     h.nc = (int)nc;
     h.SW = (int)((n + 15) / 16 * 16 + 1);
     h.AG = (int)((na + 63) / 64);
-    h.KB = (int)((n + 7) / 8);
-    const int steps = (int)((n + 7) / 8 * 8);
-    h.lds = sizeof(double) * ((size_t)(2 * na + 1) * h.SW + steps + 8 + (size_t)h.AG * h.KB * 8 + 32);
+    // 16 longitudes per work item where that still gives every SIMD a wave (and the items fit two per wave)
+    h.W = (env_int("GRAVHMC_LONSYM_W", 16) == 16 && h.AG * ((n + 15) / 16) >= 4 && h.AG * ((n + 15) / 16) <= LS_WAVES) ? 16 : 8;
+    h.KB = (int)((n + h.W - 1) / h.W);
+    // (eight waves cover the items: half the threads, twice the registers -- the 16 + 16 + 16 doubles of
+    // a work item's accumulators and table window then stay out of scratch)
+    h.thr = (h.W == 16 && h.AG * h.KB <= 8 && n <= 512) ? 512 : 1024;
+    const int steps = h.KB * h.W;
+    h.SW = (int)((steps + 15) / 16 * 16 + 1);
+    h.lds = sizeof(double) * ((size_t)(2 * na + 1) * h.SW + steps + 8 + (size_t)h.AG * h.KB * h.W + 32);
     if (n > LS_THREADS) return no("more than 1024 longitudes per cell row");
-    if (h.AG * h.KB > LS_WAVES * LS_MAXITEMS) return no("too many (class, longitude block) work items for one workgroup");
+    if (h.AG * h.KB > (h.thr / 64) * (h.W == 16 ? 1 : LS_MAXITEMS)) return no("too many (class, longitude block) work items for one workgroup");
     if (h.lds > 160 * 1024 - 512) return no("a cell row's table and the residual grid do not fit the LDS");
-    if (na * n > (int64_t)1 << 24) return no("table too wide");
+    if (na * n > (int64_t)8 * LS_THREADS) return no("a cell row's table has more than 8192 entries");
     // the table: every class at every shift against the cells of longitude index 0 (reference engine)
     const int64_t Np = na * n;
     h.ldT = (Np + 15) / 16 * 16;
@@ -168,8 +175,8 @@ static int lonsym_build(gh_ctx *c)
     TRY(up(&h.a_of, a_of));
     TRY(up(&h.m_of, m_of));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    h.items = (h.AG * h.KB + LS_WAVES - 1) / LS_WAVES;
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsym_fn(h.items)), h.lds));
+    h.items = (h.AG * h.KB + h.thr / 64 - 1) / (h.thr / 64);
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsym_fn(h.items, h.W, h.thr)), h.lds));
     h.grid = (int)std::min<int64_t>(nc, c->cus);
     h.on = true;
     return GH_OK;
@@ -184,7 +191,7 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
     const LonSymHost &h = *c->ls;
     a.ld = c->ld;
     a.M = c->M;
-    hipLaunchKernelGGL(lonsym_fn(h.items), dim3((unsigned)h.grid), dim3(LS_THREADS), h.lds, c->stream, lonsym_geom(c), a,
+    hipLaunchKernelGGL(lonsym_fn(h.items, h.W, h.thr), dim3((unsigned)h.grid), dim3((unsigned)h.thr), h.lds, c->stream, lonsym_geom(c), a,
                        c->weighted ? c->wm : nullptr);
     return GH_OK;
 }

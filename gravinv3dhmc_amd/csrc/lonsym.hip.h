@@ -34,7 +34,7 @@ namespace ghk {
 struct LonSymGeom {
     int n, na, nc;         // longitudes per cell row, observation classes, cell rows
     int SW;                // row stride of the LDS copies (doubles)
-    int AG, KB;            // lane groups of 64 classes, blocks of 8 longitudes: AG * KB work items
+    int AG, KB;            // lane groups of 64 classes, blocks of W longitudes: AG * KB work items
     int64_t ldT;           // doubles per cell row of the table
     const double *T;       // [nc][ldT], T[c][a * n + delta]
     const int *slot_ptr;   // na * n + 1: observations of slot (a, m), ascending
@@ -50,54 +50,59 @@ constexpr int LS_MAXITEMS = 4;  // work items per wave at most (8 forward accumu
 // acc[u] += sum over t of window(t)[u] * v(t): see the header.  ADJ: u = 7 - j and v = Rrow[t] (this
 // lane's row of R); forward: u = j and v = xsr[t] (uniform).  Trow = this lane's row of T[c]; b0 = first
 // shift of the window at t = 0; steps = multiple of 8 (v is zero beyond n).
-template <bool ADJ>
-__device__ __forceinline__ void ls_correlate(double (&acc)[8], const double *Trow, const double *v, int b0, int n, int steps)
+template <bool ADJ, int W>
+__device__ __forceinline__ void ls_correlate(double (&acc)[W], const double *Trow, const double *v, int b0, int n, int steps)
 {
-    double w[8];
+    double w[W];
     int ti = b0;
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
+    for (int x = 0; x < W; ++x) {
         w[x] = Trow[ti];
         ti = ti + 1 == n ? 0 : ti + 1;
     }
-    for (int t0 = 0; t0 < steps; t0 += 8) {
+    for (int t0 = 0; t0 < steps; t0 += W) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < W; ++t) {
             const double vv = v[t0 + t];
             const double nx = Trow[ti];  // the element that joins the window at the next step
             ti = ti + 1 == n ? 0 : ti + 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[ADJ ? 7 - j : j] = fma(w[(t + j) & 7], vv, acc[ADJ ? 7 - j : j]);
+            for (int j = 0; j < W; ++j) acc[ADJ ? W - 1 - j : j] = fma(w[(t + j) & (W - 1)], vv, acc[ADJ ? W - 1 - j : j]);
             w[t] = nx;
         }
     }
 }
 
 // The fused pass (modes of SweepArgs as sweep_kernel / mf_fused_kernel).  ITEMS = work items per wave
-// (AG * KB <= 16 ITEMS): the forward accumulators are registers.
-template <int ITEMS>
-__global__ void __launch_bounds__(LS_THREADS)
+// (AG * KB <= 16 ITEMS): the forward accumulators are registers.  W = longitudes a work item owns
+// (8 or 16): every table value read from LDS feeds W FMAs -- at 8 the two LDS reads per step of the
+// 15 waves (1 KB per 512 FMAs) saturate the LDS before the VALU (measured: VALU busy 43 %); at 16 half
+// as many waves do twice the FMAs per read.
+// T = threads per workgroup (1024, or 512 when eight waves cover the work items: twice the registers).
+template <int ITEMS, int W, int T>
+__global__ void __launch_bounds__(T)
 lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NWV = T / 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = g.n, na = g.na, SW = g.SW;
     const int mode = a.mode;
-    const int steps = (n + 7) & ~7;
+    const int steps = (n + W - 1) / W * W;
     double *Tc = smem;                                   // na x SW
     double *Rg = Tc + (size_t)na * SW;                   // (na + 1) x SW: row na is zero
     double *xsr = Rg + (size_t)(na + 1) * SW;            // steps + 8: xs reversed, zero beyond n
-    double *Sp = xsr + steps + 8;                        // AG x (KB * 8)
-    double *red = Sp + (size_t)g.AG * g.KB * 8;          // 32
+    double *Sp = xsr + steps + 8;                        // AG x (KB * W)
+    double *red = Sp + (size_t)g.AG * g.KB * W;          // 32
     const int nitems = g.AG * g.KB;
 
     // R[a][m] = sum of r over the slot's observations; zero elsewhere (padding, the extra row)
-    for (int e = tid; e < (na + 1) * SW; e += LS_THREADS) Rg[e] = 0.0;
-    for (int e = tid; e < steps + 8; e += LS_THREADS) xsr[e] = 0.0;
+    for (int e = tid; e < (na + 1) * SW; e += T) Rg[e] = 0.0;
+    for (int e = tid; e < steps + 8; e += T) xsr[e] = 0.0;
     __syncthreads();
     if (mode & SW_ADJ) {
-        for (int aa = wave; aa < na; aa += LS_WAVES)
+        for (int aa = wave; aa < na; aa += NWV)
             for (int m = lane; m < n; m += 64) {
                 const int s = aa * n + m;
                 double t = 0.0;
@@ -105,121 +110,156 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
                 Rg[aa * SW + m] = t;
             }
     }
-    double dacc[ITEMS][8];
+    double dacc[ITEMS][W];
 #pragma unroll
     for (int q = 0; q < ITEMS; ++q)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dacc[q][u] = 0.0;
+        for (int u = 0; u < W; ++u) dacc[q][u] = 0.0;
     double pp = 0.0;
+    // A thread's share of a cell row's table on its way from memory to LDS: requested while the
+    // previous row is still being worked on, parked after that row's last barrier.
+    constexpr int TPER = 8192 / T;  // T threads x TPER >= na * n for everything that fits the LDS
+    double tnext[TPER];
+    auto t_fetch = [&](int c) {
+        const double *Tg = g.T + (int64_t)c * g.ldT;
+        const int tot = na * n;
+#pragma unroll
+        for (int q = 0; q < TPER; ++q) {
+            const int e = tid + q * T;
+            tnext[q] = Tg[e < tot ? e : tot - 1];
+        }
+    };
+    auto t_park = [&]() {
+        const int tot = na * n;
+#pragma unroll
+        for (int q = 0; q < TPER; ++q) {
+            const int e = tid + q * T;
+            if (e < tot) {
+                const int aa = e / n;
+                Tc[aa * SW + (e - aa * n)] = tnext[q];
+            }
+        }
+    };
+    if ((int)blockIdx.x < g.nc) t_fetch(blockIdx.x);
     for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
         __syncthreads();  // (the previous row's forward has finished with Tc and xsr; first trip: Rg is complete)
-        {
-            const double *Tg = g.T + (int64_t)c * g.ldT;
-            for (int aa = wave; aa < na; aa += LS_WAVES)
-                for (int m = lane; m < n; m += 64) Tc[aa * SW + m] = Tg[aa * n + m];
+        t_park();
+        // the operands of this row's update (thread tid < n: cell (c, tid)): requested now, looked at
+        // after the dots -- their round trip used to stand between the dots and the forward
+        const int64_t j = (int64_t)c * n + tid;
+        double u_w = 1.0, u_x = 0.0, u_g = 0.0, u_p = 0.0, u_pn = 0.0, u_hi = 0.0, u_lo = 0.0;
+        if (tid < n) {
+            u_w = wm ? wm[j] : 1.0;
+            u_x = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+            if (mode & SW_ADJ) {
+                u_g = a.greg ? a.greg[j] : 0.0;
+                if (mode & (SW_PFIN | SW_UPD)) u_p = a.p_in[j];
+                if (mode & SW_SPEC) u_pn = a.pn_in[j];
+                if (mode & SW_UPD) {
+                    u_hi = a.high[j];
+                    u_lo = a.low[j];
+                }
+            }
         }
         __syncthreads();
-        const int64_t j = (int64_t)c * n + tid;  // thread tid < n: cell (c, tid)
-        double xj = 0.0, iwj = 1.0;
-        if (tid < n) {
-            const double w = wm ? wm[j] : 1.0;
-            iwj = (w != 0.0) ? 1.0 / w : 1.0;
-            xj = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
-        }
+        double xj = u_x, iwj = 1.0;
         if (mode & SW_ADJ) {
 #pragma unroll 1
-            for (int it = wave; it < nitems; it += LS_WAVES) {
+            for (int it = wave; it < nitems; it += NWV) {
                 const int ag = it / g.KB, kb = it - ag * g.KB;
                 const int aa = ag * 64 + lane;
                 const double *Trow = Tc + (aa < na ? aa : na - 1) * SW;
                 const double *Rrow = Rg + (aa < na ? aa : na) * SW;  // row na: zeros
-                int b0 = (-(kb * 8 + 7)) % n;
+                int b0 = (-(kb * W + W - 1)) % n;
                 if (b0 < 0) b0 += n;
-                double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                ls_correlate<true>(acc, Trow, Rrow, b0, n, steps);
+                double acc[W];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < W; ++u) acc[u] = 0.0;
+                ls_correlate<true, W>(acc, Trow, Rrow, b0, n, steps);
+#pragma unroll
+                for (int u = 0; u < W; ++u) {
                     const double s = wave_sum_dpp(acc[u]);
-                    if (lane == 0) Sp[ag * g.KB * 8 + kb * 8 + u] = s;
+                    if (lane == 0) Sp[ag * g.KB * W + kb * W + u] = s;
                 }
             }
             __syncthreads();
-            if (tid < n) {
-                double t = 0.0;
-                for (int ag = 0; ag < g.AG; ++ag) t += Sp[ag * g.KB * 8 + tid];
-                t = t * iwj;
-                const double gr = a.greg ? a.greg[j] : 0.0;
-                const double grad = 2.0 * t + gr;
-                if (mode & SW_GOUT) a.g_out[j] = grad;
-                if (mode & SW_PFIN) {
-                    const double pf = a.p_in[j] - a.c_p * grad;
-                    pp += pf * pf;
-                    if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+        }
+        if (tid < n) iwj = (u_w != 0.0) ? 1.0 / u_w : 1.0;
+        if ((mode & SW_ADJ) && tid < n) {
+            double t = 0.0;
+            for (int ag = 0; ag < g.AG; ++ag) t += Sp[ag * g.KB * W + tid];
+            t = t * iwj;
+            const double grad = 2.0 * t + u_g;
+            if (mode & SW_GOUT) a.g_out[j] = grad;
+            if (mode & SW_PFIN) {
+                const double pf = u_p - a.c_p * grad;
+                pp += pf * pf;
+                if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+            }
+            if (mode & SW_UPD) {
+                const double psrc = (mode & SW_SPEC) ? u_pn : u_p;
+                double pj = psrc - a.c_u * grad;
+                xj = xj + a.dt * pj;
+                if (xj > u_hi) {
+                    xj = u_hi;
+                    pj = -pj;
+                } else if (xj < u_lo) {
+                    xj = u_lo;
+                    pj = -pj;
                 }
-                if (mode & SW_UPD) {
-                    const double psrc = (mode & SW_SPEC) ? a.pn_in[j] : a.p_in[j];
-                    double pj = psrc - a.c_u * grad;
-                    xj = xj + a.dt * pj;
-                    const double hi = a.high[j], lo = a.low[j];
-                    if (xj > hi) {
-                        xj = hi;
-                        pj = -pj;
-                    } else if (xj < lo) {
-                        xj = lo;
-                        pj = -pj;
-                    }
-                    a.p_out[j] = pj;
-                    a.x_out[j] = xj;
-                }
+                a.p_out[j] = pj;
+                a.x_out[j] = xj;
             }
         }
+        // the next row's table: in flight behind the forward below
+        if (c + (int)gridDim.x < g.nc) t_fetch(c + gridDim.x);
         if (mode & SW_FWD) {
             if (tid < n) xsr[n - 1 - tid] = xj * iwj;
             __syncthreads();
 #pragma unroll
             for (int qq = 0; qq < ITEMS; ++qq) {
-                const int it = wave + qq * LS_WAVES;
+                const int it = wave + qq * NWV;
                 if (it < nitems) {
                     const int ag = it / g.KB, mb = it - ag * g.KB;
                     const int aa = ag * 64 + lane;
                     const double *Trow = Tc + (aa < na ? aa : na - 1) * SW;
-                    const int b0 = (mb * 8 + 1) % n;
-                    ls_correlate<false>(dacc[qq], Trow, xsr, b0, n, steps);
+                    const int b0 = (mb * W + 1) % n;
+                    ls_correlate<false, W>(dacc[qq], Trow, xsr, b0, n, steps);
                 }
             }
         }
     }
     if ((mode & SW_PFIN)) {
         // sum of p^2 over this workgroup's cells: threads tid < n hold parts
-        const double t = block_allreduce_sum(tid < n ? pp : 0.0, red, LS_WAVES);
+        const double t = block_allreduce_sum(tid < n ? pp : 0.0, red, NWV);
         if (tid == 0) a.pp_part[blockIdx.x] = t;
     }
     if (mode & SW_FWD) {
         __syncthreads();  // everybody is done with Tc: it takes D[a][m]
 #pragma unroll
         for (int qq = 0; qq < ITEMS; ++qq) {
-            const int it = wave + qq * LS_WAVES;
+            const int it = wave + qq * NWV;
             if (it < nitems) {
                 const int ag = it / g.KB, mb = it - ag * g.KB;
                 const int aa = ag * 64 + lane;
                 if (aa < na) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (mb * 8 + u < n) Tc[aa * SW + mb * 8 + u] = dacc[qq][u];
+                    for (int u = 0; u < W; ++u)
+                        if (mb * W + u < n) Tc[aa * SW + mb * W + u] = dacc[qq][u];
                 }
             }
         }
         __syncthreads();
         double *out = a.slab + (int64_t)blockIdx.x * a.ld;
         double rs = 0.0;
-        for (int64_t i = tid; i < a.ld; i += LS_THREADS) {
+        for (int64_t i = tid; i < a.ld; i += T) {
             const double v = i < g.N ? Tc[g.lds_of[i]] : 0.0;
             out[i] = v;
             rs += v;
         }
         if (a.dsum) {
             // (sum of this workgroup's slab row: the epilogue then knows mean(d) up front and needs one launch)
-            const double t = block_allreduce_sum(rs, red, LS_WAVES);
+            const double t = block_allreduce_sum(rs, red, NWV);
             if (tid == 0) a.dsum[blockIdx.x] = t;
         }
     }
