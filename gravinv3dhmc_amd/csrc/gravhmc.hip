@@ -1674,6 +1674,18 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
     return GH_OK;
 }
 
+// Diagnostic (not in the public header): accumulated phase times of the shift-invariant pass
+// (GRAVHMC_LONSYM_TIMING=1), 100 MHz ticks of workgroup 0.
+int gh_debug_lonsym_timing(gh_ctx *c, long long out8[8])
+{
+    if (!c || !out8) return GH_ERR_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!c->ls || !c->ls->dbg) return GH_OK;
+    HIPCHK(c, hipMemcpyAsync(out8, c->ls->dbg, 8 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
 // Diagnostic (not in the public header): accumulated phase times of the fused matrix-free batch pass
 // (GRAVHMC_MFB_TIMING=1), 100 MHz ticks of workgroup (0, 0).
 int gh_debug_mfb_timing(gh_ctx *c, long long out8[8])

@@ -7,7 +7,10 @@ struct LonSymHost {
     int n = 0, na = 0, nc = 0, SW = 0, AG = 0, KB = 0;
     int64_t ldT = 0;
     double *T = nullptr;
-    int *slot_ptr = nullptr, *slot_obs = nullptr, *lds_of = nullptr, *a_of = nullptr, *m_of = nullptr;
+    int *slot_first = nullptr, *xslot = nullptr, *xptr = nullptr, *xobs = nullptr, *lds_of = nullptr, *a_of = nullptr,
+        *m_of = nullptr;
+    int n_xslots = 0;
+    long long *dbg = nullptr;  // GRAVHMC_LONSYM_TIMING: per-phase clocks of one workgroup
     size_t lds = 0;
     int grid = 0, items = 1, W = 8, thr = 1024;  // items: work items per wave, W: longitudes per work item (instantiation of the kernel)
     std::string why;  // why the geometry does not qualify (gh_last_error text)
@@ -32,10 +35,14 @@ static LonSymGeom lonsym_geom(const gh_ctx *c)
     g.KB = h.KB;
     g.ldT = h.ldT;
     g.T = h.T;
-    g.slot_ptr = h.slot_ptr;
-    g.slot_obs = h.slot_obs;
+    g.slot_first = h.slot_first;
+    g.n_xslots = h.n_xslots;
+    g.xslot = h.xslot;
+    g.xptr = h.xptr;
+    g.xobs = h.xobs;
     g.lds_of = h.lds_of;
     g.N = c->N;
+    g.dbg = h.dbg;
     return g;
 }
 
@@ -155,22 +162,38 @@ static int lonsym_build(gh_ctx *c)
     if (e != hipSuccess) return fail(c, GH_ERR_HIP, "shift-invariant table: %s", hipGetErrorString(e));
     if (hs.overflow) return fail(c, GH_ERR_OVERFLOW, "tesseroid stack overflow (> %d entries)", TESS_STACK);
     c->leaves = (int64_t)hs.leaves;
-    // slots (a, m) -> observations, ascending; LDS offset of every observation's slot
-    std::vector<int> sptr((size_t)Np + 1, 0), sobs((size_t)N), ldsof((size_t)N);
-    for (int64_t i = 0; i < N; ++i) sptr[(size_t)(a_of[(size_t)i] * n + m_of[(size_t)i]) + 1] += 1;
-    for (int64_t s = 0; s < Np; ++s) sptr[(size_t)s + 1] += sptr[(size_t)s];
+    // slots (a, m) -> observations, ascending: the first one per slot, and the further ones of the few
+    // slots that hold several (duplicated longitudes); LDS offset of every observation's slot
+    std::vector<int> sfirst((size_t)Np, -1), xslot, xptr(1, 0), xobs, ldsof((size_t)N);
     {
-        std::vector<int> fill(sptr.begin(), sptr.end() - 1);
-        for (int64_t i = 0; i < N; ++i) sobs[(size_t)fill[(size_t)(a_of[(size_t)i] * n + m_of[(size_t)i])]++] = (int)i;
+        std::vector<std::vector<int>> more((size_t)Np);
+        for (int64_t i = 0; i < N; ++i) {
+            const size_t sl = (size_t)(a_of[(size_t)i] * n + m_of[(size_t)i]);
+            if (sfirst[sl] < 0)
+                sfirst[sl] = (int)i;
+            else
+                more[sl].push_back((int)i);
+        }
+        for (int64_t sl = 0; sl < Np; ++sl)
+            if (!more[(size_t)sl].empty()) {
+                xslot.push_back((int)sl);
+                xobs.insert(xobs.end(), more[(size_t)sl].begin(), more[(size_t)sl].end());
+                xptr.push_back((int)xobs.size());
+            }
     }
+    h.n_xslots = (int)xslot.size();
+    if (xslot.empty()) xslot.push_back(0);
+    if (xobs.empty()) xobs.push_back(0);
     for (int64_t i = 0; i < N; ++i) ldsof[(size_t)i] = a_of[(size_t)i] * h.SW + m_of[(size_t)i];
     auto up = [&](int **dst, const std::vector<int> &src) -> int {
         TRY(dalloc(c, dst, src.size(), false));
         HIPCHK(c, hipMemcpyAsync(*dst, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice, c->stream));
         return GH_OK;
     };
-    TRY(up(&h.slot_ptr, sptr));
-    TRY(up(&h.slot_obs, sobs));
+    TRY(up(&h.slot_first, sfirst));
+    TRY(up(&h.xslot, xslot));
+    TRY(up(&h.xptr, xptr));
+    TRY(up(&h.xobs, xobs));
     TRY(up(&h.lds_of, ldsof));
     TRY(up(&h.a_of, a_of));
     TRY(up(&h.m_of, m_of));
@@ -178,6 +201,7 @@ static int lonsym_build(gh_ctx *c)
     h.items = (h.AG * h.KB + h.thr / 64 - 1) / (h.thr / 64);
     HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsym_fn(h.items, h.W, h.thr)), h.lds));
     h.grid = (int)std::min<int64_t>(nc, c->cus);
+    if (env_int("GRAVHMC_LONSYM_TIMING", 0)) TRY(dalloc(c, &h.dbg, 8));
     h.on = true;
     return GH_OK;
 }

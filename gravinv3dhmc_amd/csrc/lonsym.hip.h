@@ -37,10 +37,14 @@ struct LonSymGeom {
     int AG, KB;            // lane groups of 64 classes, blocks of W longitudes: AG * KB work items
     int64_t ldT;           // doubles per cell row of the table
     const double *T;       // [nc][ldT], T[c][a * n + delta]
-    const int *slot_ptr;   // na * n + 1: observations of slot (a, m), ascending
-    const int *slot_obs;   // N
+    const int *slot_first; // na * n: first observation of slot (a, m), or -1
+    int n_xslots;          // slots with more than one observation (duplicated longitudes such as +-180)
+    const int *xslot;      // n_xslots: their slot numbers
+    const int *xptr;       // n_xslots + 1
+    const int *xobs;       // their further observations, ascending
     const int *lds_of;     // N: a_i * SW + m_i
     int64_t N;
+    long long *dbg;        // optional: 8 accumulated phase times (100 MHz ticks) of workgroup 0, thread 0
 };
 
 constexpr int LS_THREADS = 1024;
@@ -96,26 +100,20 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
     double *Sp = xsr + steps + 8;                        // AG x (KB * W)
     double *red = Sp + (size_t)g.AG * g.KB * W;          // 32
     const int nitems = g.AG * g.KB;
-
-    // R[a][m] = sum of r over the slot's observations; zero elsewhere (padding, the extra row)
-    for (int e = tid; e < (na + 1) * SW; e += T) Rg[e] = 0.0;
-    for (int e = tid; e < steps + 8; e += T) xsr[e] = 0.0;
-    __syncthreads();
-    if (mode & SW_ADJ) {
-        for (int aa = wave; aa < na; aa += NWV)
-            for (int m = lane; m < n; m += 64) {
-                const int s = aa * n + m;
-                double t = 0.0;
-                for (int q = g.slot_ptr[s]; q < g.slot_ptr[s + 1]; ++q) t += a.r[g.slot_obs[q]];
-                Rg[aa * SW + m] = t;
-            }
+    __shared__ long long tph_s[9];
+    const bool clk = g.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    if (clk) {
+        for (int q = 0; q < 8; ++q) tph_s[q] = 0;
+        tph_s[8] = wall_clock64();
     }
-    double dacc[ITEMS][W];
-#pragma unroll
-    for (int q = 0; q < ITEMS; ++q)
-#pragma unroll
-        for (int u = 0; u < W; ++u) dacc[q][u] = 0.0;
-    double pp = 0.0;
+    auto mark = [&](int ph) {
+        if (clk) {
+            const long long now = wall_clock64();
+            tph_s[ph] += now - tph_s[8];
+            tph_s[8] = now;
+        }
+    };
+
     // A thread's share of a cell row's table on its way from memory to LDS: requested while the
     // previous row is still being worked on, parked after that row's last barrier.
     constexpr int TPER = 8192 / T;  // T threads x TPER >= na * n for everything that fits the LDS
@@ -140,9 +138,53 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
             }
         }
     };
-    if ((int)blockIdx.x < g.nc) t_fetch(blockIdx.x);
+    if ((int)blockIdx.x < g.nc) t_fetch(blockIdx.x);  // (in flight behind the gather of R below)
+    // R[a][m] = sum of r over the slot's observations; zero elsewhere (padding, the extra row)
+    for (int e = tid; e < (na + 1) * SW; e += T) Rg[e] = 0.0;
+    for (int e = tid; e < steps + 8; e += T) xsr[e] = 0.0;
+    __syncthreads();
+    if (mode & SW_ADJ) {
+        // the first observation of every slot in batches of eight (index, then value: two round trips
+        // per batch -- slot by slot, pointer -> index -> value were three per slot, 16 slots per thread
+        // one after the other: a third of the pass), then the rare further observations of a slot
+        const int tot = na * n;
+        for (int e0 = 0; e0 < tot; e0 += 8 * T) {
+            int idx[8];
+            double val[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q * T + tid;
+                idx[q] = e < tot ? g.slot_first[e] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) val[q] = idx[q] >= 0 ? a.r[idx[q]] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q * T + tid;
+                if (e < tot) {
+                    const int aa = e / n;
+                    Rg[aa * SW + (e - aa * n)] = val[q];
+                }
+            }
+        }
+        __syncthreads();
+        for (int x = tid; x < g.n_xslots; x += T) {
+            const int e = g.xslot[x], aa = e / n;
+            double t = Rg[aa * SW + (e - aa * n)];
+            for (int q = g.xptr[x]; q < g.xptr[x + 1]; ++q) t += a.r[g.xobs[q]];
+            Rg[aa * SW + (e - aa * n)] = t;
+        }
+    }
+    double dacc[ITEMS][W];
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q)
+#pragma unroll
+        for (int u = 0; u < W; ++u) dacc[q][u] = 0.0;
+    double pp = 0.0;
+    mark(0);
     for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
         __syncthreads();  // (the previous row's forward has finished with Tc and xsr; first trip: Rg is complete)
+        mark(6);
         t_park();
         // the operands of this row's update (thread tid < n: cell (c, tid)): requested now, looked at
         // after the dots -- their round trip used to stand between the dots and the forward
@@ -162,6 +204,7 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
             }
         }
         __syncthreads();
+        mark(1);
         double xj = u_x, iwj = 1.0;
         if (mode & SW_ADJ) {
 #pragma unroll 1
@@ -182,7 +225,9 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
                     if (lane == 0) Sp[ag * g.KB * W + kb * W + u] = s;
                 }
             }
+            mark(2);
             __syncthreads();
+            mark(7);
         }
         if (tid < n) iwj = (u_w != 0.0) ? 1.0 / u_w : 1.0;
         if ((mode & SW_ADJ) && tid < n) {
@@ -211,6 +256,7 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
                 a.x_out[j] = xj;
             }
         }
+        mark(3);
         // the next row's table: in flight behind the forward below
         if (c + (int)gridDim.x < g.nc) t_fetch(c + gridDim.x);
         if (mode & SW_FWD) {
@@ -228,6 +274,7 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
                 }
             }
         }
+        mark(4);
     }
     if ((mode & SW_PFIN)) {
         // sum of p^2 over this workgroup's cells: threads tid < n hold parts
@@ -252,10 +299,23 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
         __syncthreads();
         double *out = a.slab + (int64_t)blockIdx.x * a.ld;
         double rs = 0.0;
-        for (int64_t i = tid; i < a.ld; i += T) {
-            const double v = i < g.N ? Tc[g.lds_of[i]] : 0.0;
-            out[i] = v;
-            rs += v;
+        // (the observations' slots in batches of eight: one round trip per batch, not per observation)
+        for (int64_t i0 = 0; i0 < a.ld; i0 += 8 * T) {
+            int off[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t i = i0 + q * T + tid;
+                off[q] = i < g.N ? g.lds_of[i] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t i = i0 + q * T + tid;
+                if (i < a.ld) {
+                    const double v = off[q] >= 0 ? Tc[off[q]] : 0.0;
+                    out[i] = v;
+                    rs += v;
+                }
+            }
         }
         if (a.dsum) {
             // (sum of this workgroup's slab row: the epilogue then knows mean(d) up front and needs one launch)
@@ -263,6 +323,9 @@ lonsym_sweep_kernel(LonSymGeom g, SweepArgs a, const double *__restrict__ wm)
             if (tid == 0) a.dsum[blockIdx.x] = t;
         }
     }
+    mark(5);
+    if (clk)
+        for (int q = 0; q < 8; ++q) g.dbg[q] += tph_s[q];
 }
 
 // wm_j = (sum_i K_ij^2)^wf for j = (c, k): thread per cell, observations in order (serial, fixed order)
