@@ -199,8 +199,8 @@ class BootStrap(object):
 
     def __init__(self, mrange, mspacing, obsurface, dobs, boundary, samples=100, beta=0.01, maxk=100,
                  mratio=1, njobs=1, wavelet=False, device=0, verbose=True, **kwargs):
-        if wavelet:
-            raise NotImplementedError("BootStrap with a wavelet-compressed forward is not built")
+        if wavelet not in (False, None, '1D', '3D'):
+            raise ValueError("wavelet must be False, '1D' or '3D'")
         self.mrange, self.mspacing, self.mratio = mrange, mspacing, mratio
         self.lonobs, self.latobs, self.heightobs = obsurface[0], obsurface[1], obsurface[2]
         self.boundary, self.samples, self.njobs = boundary, samples, njobs
@@ -230,13 +230,29 @@ class BootStrap(object):
         self.Wm, self.WmInv, self.WmSquare = _diag(wm), _diag(inv), _diag(wm * wm)
         self.Aw = DeviceMatrix(eng)
         self._zero = np.zeros(eng.M)
+        self._index = None
+        if wavelet in ('1D', '3D'):
+            # gravmag/compressor1D.py / compressor3D.py on the weighted kernel (reginv.py:546-553)
+            say("Using {} wavelet to compress kernel.".format(wavelet))
+            eng.compress_wavelet(3 if wavelet == '3D' else 1, self.mshape, 0.001, 2)
 
     # terms of one replicate: `counts[r]` = how often observation r was drawn
     def data(self, mw, counts, dobs):
+        if self.wavelet:
+            # reginv.py:590-593: the compressed, UNRESAMPLED operator predicts the data in the original row
+            # order; they are compared with the resampled observations as they are (the reference's own
+            # behaviour, kept)
+            res = self._engine.forward_wavelet(mw) - dobs[self._index]
+            return float(np.sum(res * res))
         res = self._engine.forward(mw) - dobs
         return float(np.sum(counts * res * res))
 
     def data_gfun(self, mw, counts, dobs):
+        if self.wavelet:
+            # 2 AwSample^T (dpre - dobsSample) (reginv.py:608-617): AwSample[i] = Aw[index[i]], so the
+            # residual of draw i goes to row index[i] of the one resident kernel
+            res = self._engine.forward_wavelet(mw) - dobs[self._index]
+            return 2 * self._engine.adjoint(np.bincount(self._index, weights=res, minlength=self.dsize))
         return 2 * self._engine.adjoint(counts * (self._engine.forward(mw) - dobs))
 
     def model_MS(self, mw):
@@ -306,6 +322,7 @@ class BootStrap(object):
             index = np.arange(0, self.dsize)
             indexSample = np.random.choice(index, size=self.dsize, replace=True, p=None)
             counts = np.bincount(indexSample, minlength=self.dsize).astype(np.float64)
+            self._index = indexSample
             model_inv, data_misfit, model_misfit, regul_factor = self.CG(counts, self.dobs, initialModel)
             model_inv_all[sample, :] = model_inv
             data_misfit_all[sample, :] = data_misfit

@@ -78,17 +78,29 @@ def cg(K, dobs, shape, initialModel, apriorModel, boundary, regularization="MS",
     return mw_new / wm, Aw @ mw_new, np.array(dm), np.array(mm), np.array(rf, dtype=float)
 
 
-def bootstrap(K, dobs, boundary, initialModel, samples=3, beta=0.01, maxk=5):
+def bootstrap(K, dobs, boundary, initialModel, samples=3, beta=0.01, maxk=5, wavelet=None, shape=None):
     """inversion/reginv.py:494-755 (BootStrap.BSCG / .CG): CG with the MS variant of that class
-    (no prior, beta squared: :599-629) on row-resampled data, seed = sample index."""
+    (no prior, beta squared: :599-629) on row-resampled data, seed = sample index.
+    wavelet = '1D' / '3D' (reginv.py:546-553): the predicted data of the data term and of its gradient come
+    from the compressed UNRESAMPLED kernel, `modelcompressor(mw, self.Awcp)` (:590-593, :608-617), i.e. in the
+    ORIGINAL row order, and are compared with the RESAMPLED observations -- the reference's behaviour as
+    written (the step length still uses the resampled dense kernel, :655).  PyWavelets is not installed here:
+    the transform is oracle/wavelet.py's restatement (pinned by the reference's wavelet logs only)."""
     Aw, wm = oracle.col_weight(K)
     N, M = Aw.shape
     wm2 = wm * wm
     b2 = beta ** 2
+    pred = None
+    if wavelet:
+        from . import wavelet as ow
+        dims = 3 if wavelet == "3D" else 1
+        Awcp = ow.compress_kernel(Aw, dims, shape)
+        pred = lambda mw: Awcp @ ow.model_coeffs(mw, dims, shape)
 
     def run(A, d):
-        data = lambda mw: np.linalg.norm(A @ mw - d) ** 2
-        data_g = lambda mw: 2 * A.T @ (A @ mw - d)
+        fwd = pred if pred is not None else (lambda mw: A @ mw)
+        data = lambda mw: np.linalg.norm(fwd(mw) - d) ** 2
+        data_g = lambda mw: 2 * A.T @ (fwd(mw) - d)
         model = lambda mw: np.sum(wm2 * mw * mw / (mw * mw + b2))
         model_g = lambda mw: 2 * wm2 * (mw * b2) / (mw * mw + b2) ** 2
 

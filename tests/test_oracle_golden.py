@@ -303,3 +303,31 @@ def test_bootstrap_port_matches_reference_golden():
     res = cg_port.bootstrap(g["K"], g["dobs"], (0.0, 1.0), np.full(M, 0.001), samples=3, beta=0.1, maxk=5)
     for name, v in zip(("models", "dmis", "mmis", "alpha"), res):
         assert relmax(v, b[name]) < 1e-9, name
+
+
+def test_bootstrap_port_with_wavelet_forward_is_the_reference_formulation():
+    """oracle/cg_port.bootstrap(wavelet=...): reginv.py:546-553,590-593,608-617 as written -- the data term
+    and its gradient take the predicted data from the compressed unresampled operator (original row order)
+    against the resampled observations; checked term by term against that formulation spelled out here."""
+    from oracle import cg_port, oracle as orc, wavelet as ow
+    g = gold("cg_small.npz")
+    shape = tuple(int(v) for v in g["shape"])
+    M = int(np.prod(shape))
+    a = cg_port.bootstrap(g["K"], g["dobs"], (0.0, 1.0), np.full(M, 0.001), samples=2, beta=0.1, maxk=2,
+                          wavelet="3D", shape=shape)
+    assert np.isfinite(a[0]).all() and a[0].shape == (2, M)
+    # first CG step of replicate 0 by hand: alpha = 0, I = 2 AwS^T (Awcp W(mw) - dS), k = I.I / |AwS I|^2
+    Aw, wm = orc.col_weight(g["K"])
+    N = Aw.shape[0]
+    np.random.seed(0)
+    idx = np.random.choice(np.arange(N), size=N, replace=True, p=None)
+    AwS, dS = Aw[idx, :], g["dobs"][idx]
+    mw = wm * 0.001
+    dpre = ow.compress_kernel(Aw, 3, shape) @ ow.model_coeffs(mw, 3, shape)
+    I = 2 * AwS.T @ (dpre - dS)
+    k = (I @ I) / np.linalg.norm(AwS @ I) ** 2
+    m1 = np.clip((mw - k * I) / wm, 0.0, 1.0)
+    # (maxk = 2: the second iteration moves on from m1; compare the regularisation factor it derives from it)
+    data1 = np.linalg.norm(ow.compress_kernel(Aw, 3, shape) @ ow.model_coeffs(wm * m1, 3, shape) - dS) ** 2
+    model1 = np.sum(wm * wm * (wm * m1) ** 2 / ((wm * m1) ** 2 + 0.1 ** 2))
+    assert abs(a[3][0, 1] - data1 / model1) < 1e-9 * abs(data1 / model1)
