@@ -722,6 +722,8 @@ def main():
             # trigonometric / logarithm call counted as ONE flop, times the work the kernel counted
             # itself (GLQ leaves of the adaptive tesseroid engine / prism entries).
             st = eng.matrix_free_stats()
+            fus = eng.batch_fused_stats() if CPG > 1 else {"launches": 0, "members": 0, "ranges": 0, "timeouts": 0}
+            teams = fus["launches"] > 0 and fus["timeouts"] == 0
             tess = extra["kind"] == 1
             near = tess and st["near_entries"] > 0
             # executed per entry: prisms the whole entry; tesseroids the root leaf (with the near-field
@@ -741,15 +743,20 @@ def main():
             ref_unit = FLOPS_PER_TESS_LEAF if tess else FLOPS_PER_PRISM_ENTRY
             line["roofline"] = {
                 "bound": "fp64 vector (no stored G: entries re-evaluated, every entry %s per step)"
-                         % ("twice for all chains together" if CPG > 1 else "once"),
+                         % (("once for all chains together" if teams else "twice for all chains together")
+                            if CPG > 1 else "once"),
                 "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / FP64_VECTOR_PEAK_TFLOPS if tflops else None, "traffic": None,
-                "kernel": ("mfb_adjoint_kernel + mfb_forward_kernel (%d chains share every evaluated entry: "
-                           "16 columns x 512 rows staged in LDS, v_mfma_f64_16x16x4 for the chains; two "
-                           "evaluations per entry and step of the whole batch)" % CPG) if CPG > 1 else
+                "kernel": (("mfb_fused_kernel (%d chains share every evaluated entry: teams of %d workgroups x %d "
+                            "ranges of column tiles, 16 columns x 448 rows staged in LDS, partial dots exchanged "
+                            "through memory, v_mfma_f64_16x16x4 for the chains; ONE evaluation per entry and step "
+                            "of the whole batch)" % (CPG, fus["members"], fus["ranges"])) if teams else
+                           ("mfb_adjoint_kernel + mfb_forward_kernel (%d chains share every evaluated entry: "
+                            "16 columns x 512 rows staged in LDS, v_mfma_f64_16x16x4 for the chains; two "
+                            "evaluations per entry and step of the whole batch)" % CPG)) if CPG > 1 else
                           "mf_tess_fast_kernel / mf_fused_kernel (entries of a cell's column evaluated once, "
                           "dot with r, leapfrog update, forward accumulation)",
-                "launches": st["launches"], "avg_ms": sweep_ms,
+                "launches": st["launches"], "avg_ms": sweep_ms, "team_form": fus if CPG > 1 else None,
                 "entries_per_launch": st["entries"] / max(1, st["launches"]),
                 "leaves_per_launch": st["leaves"] / max(1, st["launches"]),
                 "near_field_table": {"entries": st["near_entries"], "glq_leaves": st["near_leaves"],

@@ -157,6 +157,20 @@ template <int KIND, int ROWS, typename F>
 __device__ __forceinline__ void mfb_stage(const MfbCol<KIND> &col, const MfGeom &g, const double *ob, int nb, int lane,
                                           double *st, unsigned &nleaf, F between)
 {
+    if constexpr (KIND == 0 || KIND == 1) {
+        // prisms (8 corners x (sqrt, 2 log, atan2)) and the adaptive tesseroid engine: hundreds of
+        // instructions per entry -- one copy of the evaluation, rolled (fifteen unrolled copies spilled 200 ..
+        // 550 registers); the selects of between(e) by a run-time e are noise here
+#pragma unroll 1
+        for (int e = 0; e < nb; ++e) {
+            double o[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) o[q] = q < mfb_nobs<KIND>() ? ob[q * ROWS + e * 64 + lane] : 0.0;
+            st[e * 64 + lane] = mfb_eval<KIND>(col, g, o, nleaf);
+            between(e);
+        }
+        return;
+    }
     // (unrolled: between(e) picks its operands by e -- as a run-time index that is a chain of selects;
     // a full chunk, the usual case, without a branch per evaluation: the next evaluation's LDS reads
     // may then move up into this one instead of being waited for at its start)
