@@ -602,7 +602,7 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     gh_ctx::Wavelet &w = c->wv;
     if (w.on || w.indptr) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: already compressed");
     if (c->sh.kind != 0) return fail(c, GH_ERR_UNSUPPORTED, "wavelet forward on a sharded kernel is not supported");
-    if (c->mf) return fail(c, GH_ERR_UNSUPPORTED, "wavelet compression needs the stored kernel (not matrix-free)");
+    if (lonsym_on(c)) return fail(c, GH_ERR_UNSUPPORTED, "wavelet compression on the shift-invariant store is not supported");
     if (dims == 3) {
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
             return fail(c, GH_ERR_ARG, "cannot reshape array of size %lld into shape (%d,%d,%d)",
@@ -653,8 +653,17 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
         }
         for (int64_t i0 = 0; i0 < N; i0 += chunk) {
             const int64_t nr = std::min(chunk, N - i0);
-            gather_rows_kernel<<<dim3((unsigned)((M + 31) / 32), (unsigned)((nr + 31) / 32)), dim3(256), 0,
-                                 c->stream>>>(c->G, c->ld, M, i0, nr, X);
+            if (c->mf) {
+                // no stored kernel: the rows are evaluated (twice over the two passes: setup path)
+                for (int64_t r0 = 0; r0 < nr; r0 += 32768) {
+                    const int64_t rn = std::min<int64_t>(32768, nr - r0);
+                    mf_rows_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)rn), dim3(256), 0, c->stream>>>(
+                        mf_geom(c), c->wm, i0 + r0, rn, X + r0 * M);
+                }
+            } else {
+                gather_rows_kernel<<<dim3((unsigned)((M + 31) / 32), (unsigned)((nr + 31) / 32)), dim3(256), 0,
+                                     c->stream>>>(c->G, c->ld, M, i0, nr, X);
+            }
             HIPCHK(c, hipMemsetAsync(C, 0, sizeof(double) * (size_t)(nr * Mp), c->stream));
             rc = run_dwt(c, X, M, nr, C, S1, S2);
             if (rc != GH_OK) break;

@@ -1655,6 +1655,21 @@ mf_forward_kernel(MfGeom g, const double *x, const double *wm, int64_t cells_per
 }
 
 
+// rows [i0, i0 + nrows) of the WEIGHTED kernel of a matrix-free context as a dense row-major block
+// out[nrows][M] (what gather_rows_kernel copies out of a stored G): the wavelet compressor's input
+// (compressor3D.kernelcompressor transforms whole rows).  Entries by the generic engines (mf_entry: the
+// values the dense assembly stores), divided by the column's weight as the in-place weighting does.
+__global__ void __launch_bounds__(256)
+mf_rows_kernel(MfGeom g, const double *__restrict__ wm, int64_t i0, int64_t nrows, double *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= g.M || i >= nrows) return;
+    const double k = mf_entry(g, i0 + i, g.bounds6 + 6 * j);
+    const double w = wm ? wm[j] : 1.0;
+    out[i * g.M + j] = (w != 0.0) ? k * (1.0 / w) : k;
+}
+
 // ---- fused matrix-free pass: every entry evaluated ONCE per leapfrog step -------------------
 // The dense sweep's fusion applied to entries that are computed instead of loaded: a workgroup owns
 // column j, evaluates its N entries once (kept in LDS), forms the dot with r, applies the leapfrog

@@ -114,9 +114,7 @@ class GravMagModule(object):
         else:
             eng = Engine(N, bounds.shape[0], device=device)
         if matrix_free:
-            if wavelet:
-                raise NotImplementedError("wavelet compression needs the stored kernel")
-            eng.set_matrix_free(True)
+            eng.set_matrix_free(True)      # (with wavelet: the compressor's rows are evaluated, never stored)
         if shift_invariant:
             if wavelet or not spherical:
                 raise NotImplementedError("the shift-invariant store is for spherical (tesseroid) models "
