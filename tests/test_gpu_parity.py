@@ -1564,6 +1564,55 @@ def test_bootstrap_matches_reference(G, capsys):
         assert relmax(v, b[name]) < 1e-7, name
 
 
+def test_prism_assembly_against_the_reference_kernel_compiled_from_its_own_source(G, orc):
+    """oracle/_ref/_prism*.so is the reference's own Cython kernel (gravmag/_prism.pyx, compiled unmodified
+    where it lies by oracle/build_ref.py; git-ignored, travels with the snapshot like the repository's own
+    .so files).  On the GPU box: C1's full 600 x 6000 kernel as the HIP assembly builds it against
+    `_prism.gz` itself for 300 random cells (prism.py:291-316 -> _prism.pyx:265-290: kernel1D of every
+    observation, times G * SI2MGAL), and the C restatement against it bit for bit.  Skipped where the
+    extension was not built (no /root/reference at build time)."""
+    import glob
+    import importlib.machinery
+    import importlib.util
+    from conftest import ROOT
+    sos = glob.glob(os.path.join(ROOT, "oracle", "_ref", "_prism*.so"))
+    if not sos:
+        pytest.skip("oracle/_ref/_prism*.so not built")
+    had = hasattr(np, "float")
+    if not had:
+        np.float = float            # (the alias the .pyx names at import time, removed from NumPy 1.24)
+    try:
+        loader = importlib.machinery.ExtensionFileLoader("_prism", sos[0])
+        spec = importlib.util.spec_from_file_location("_prism", sos[0], loader=loader)
+        ref = importlib.util.module_from_spec(spec)
+        loader.exec_module(ref)
+        mesh = G.mesher.PrismMesh((0, 2000, 0, 3000, 0, 1000), (100, 100, 100))
+        yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 3000, 30), np.linspace(0, 2000, 20))]
+        zp = np.zeros_like(xp)
+        bounds = mesh.cell_bounds()
+        eng = G.Engine(xp.size, mesh.size)
+        eng.set_obs(xp, yp, zp)
+        eng.set_cells(bounds, 0)
+        eng.build_G()
+        K = eng.download_G()
+        cols = np.random.default_rng(3).choice(mesh.size, 300, replace=False)
+        Kref = np.zeros((xp.size, cols.size))
+        for q, j in enumerate(cols):
+            res, k1 = np.zeros(xp.size), np.zeros(xp.size)
+            ref.gz(xp, yp, zp, *[float(v) for v in bounds[j]], 1.0, res, k1)
+            Kref[:, q] = k1
+        Kref *= 0.00000006673 * 100000.0        # constants.py:29,34: G, SI2MGAL
+        Ko = orc.prism_gz_kernel(xp, yp, zp, bounds[cols])
+        assert np.array_equal(Ko, Kref)         # the oracle IS the reference's arithmetic
+        err = float(np.abs(K[:, cols] - Kref).max() / np.abs(Kref).max())
+        print("HIP prism assembly vs the reference's compiled _prism.gz (600 x 300 entries of C1): %.2e" % err)
+        assert err < 1e-12
+        eng.close()
+    finally:
+        if not had:
+            del np.float
+
+
 @pytest.mark.parametrize("wavelet", ["3D", "1D"])
 def test_bootstrap_with_wavelet_forward_matches_the_port(G, capsys, wavelet):
     """BootStrap(wavelet=...) (reginv.py:546-553): the data term and its gradient predict the data with the

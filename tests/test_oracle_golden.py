@@ -3,7 +3,9 @@
 import numpy as np
 import pytest
 
-from conftest import gold
+import os
+
+from conftest import ROOT, gold
 from helpers import relmax
 from oracle import oracle
 
@@ -331,3 +333,38 @@ def test_bootstrap_port_with_wavelet_forward_is_the_reference_formulation():
     data1 = np.linalg.norm(ow.compress_kernel(Aw, 3, shape) @ ow.model_coeffs(wm * m1, 3, shape) - dS) ** 2
     model1 = np.sum(wm * wm * (wm * m1) ** 2 / ((wm * m1) ** 2 + 0.1 ** 2))
     assert abs(a[3][0, 1] - data1 / model1) < 1e-9 * abs(data1 / model1)
+
+
+def test_oracle_prism_kernel_is_the_reference_kernel_bit_for_bit():
+    """Where oracle/_ref/_prism*.so exists (the reference's gravmag/_prism.pyx compiled unmodified by
+    oracle/build_ref.py): the C restatement against `_prism.gz` itself on random and singular geometries."""
+    import glob
+    import importlib.machinery
+    import importlib.util
+    from oracle import oracle as orc
+    sos = glob.glob(os.path.join(ROOT, "oracle", "_ref", "_prism*.so"))
+    if not sos:
+        pytest.skip("oracle/_ref/_prism*.so not built (no /root/reference at build time)")
+    had = hasattr(np, "float")
+    if not had:
+        np.float = float
+    try:
+        loader = importlib.machinery.ExtensionFileLoader("_prism", sos[0])
+        spec = importlib.util.spec_from_file_location("_prism", sos[0], loader=loader)
+        ref = importlib.util.module_from_spec(spec)
+        loader.exec_module(ref)
+        rng = np.random.default_rng(9)
+        n = 200
+        xp, yp, zp = rng.uniform(-500, 2500, n), rng.uniform(-500, 3500, n), -rng.uniform(0, 50, n)
+        xp[:5], yp[:5], zp[:5] = [0.0, 100.0, 50.0, 0.0, 100.0], [0.0, 0.0, 50.0, 100.0, 100.0], 0.0   # corners / face
+        cells = np.array([[0, 100, 0, 100, 0, 100], [300, 400, 500, 700, 50, 250], [-50, 50, -30, 70, 10, 60.5]], float)
+        K = np.zeros((n, len(cells)))
+        for c, b in enumerate(cells):
+            res, k1 = np.zeros(n), np.zeros(n)
+            ref.gz(xp, yp, zp, *[float(v) for v in b], 1.0, res, k1)
+            K[:, c] = k1
+        K *= 0.00000006673 * 100000.0
+        assert np.array_equal(orc.prism_gz_kernel(xp, yp, zp, cells), K)
+    finally:
+        if not had:
+            del np.float
