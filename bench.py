@@ -724,6 +724,7 @@ def main():
             st = eng.matrix_free_stats()
             fus = eng.batch_fused_stats() if CPG > 1 else {"launches": 0, "members": 0, "ranges": 0, "timeouts": 0}
             teams = fus["launches"] > 0 and fus["timeouts"] == 0
+            tms = eng.matrix_free_team_stats() if CPG == 1 else {"launches": 0, "members": 0, "ranges": 0}
             tess = extra["kind"] == 1
             near = tess and st["near_entries"] > 0
             # executed per entry: prisms the whole entry; tesseroids the root leaf (with the near-field
@@ -754,6 +755,9 @@ def main():
                            ("mfb_adjoint_kernel + mfb_forward_kernel (%d chains share every evaluated entry: "
                             "16 columns x 512 rows staged in LDS, v_mfma_f64_16x16x4 for the chains; two "
                             "evaluations per entry and step of the whole batch)" % CPG)) if CPG > 1 else
+                          ("mf_team_kernel (teams of %d workgroups x %d ranges of column tiles: a wave keeps its "
+                           "column's dot as one number per tile, 16 doubles per member and tile cross the team; "
+                           "every entry evaluated once)" % (tms["members"], tms["ranges"])) if tms["launches"] > 0 else
                           "mf_tess_fast_kernel / mf_fused_kernel (entries of a cell's column evaluated once, "
                           "dot with r, leapfrog update, forward accumulation)",
                 "launches": st["launches"], "avg_ms": sweep_ms, "team_form": fus if CPG > 1 else None,

@@ -817,6 +817,12 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
     if (L < 1) return fail(c, GH_ERR_ARG, "gh_chain_trajectory: L must be >= 1");
     HIPCHK(c, hipSetDevice(c->device));
     TRY(chain_state_fresh(c));
+    // (sweeps launched from here may run on teams of workgroups whose time-out this function handles)
+    struct TeamsOk {
+        gh_ctx *c;
+        ~TeamsOk() { c->chain_teams_ok = false; }
+    } teams_guard{c};
+    c->chain_teams_ok = true;
     const size_t M = (size_t)c->M;
     const int nt = c->n_teams;
     // Was the first step of this trajectory already taken speculatively by the previous call's
@@ -934,6 +940,7 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
     // chain: decided by all ranks together, below (the flag rides on the scalar all-reduce)
     bool failed = false;
     TRY(team_failed(c, &failed));
+    if (!failed) TRY(mft_failed(c, &failed));  // (matrix-free chain on teams: same contract)
     auto redo = [&]() -> int {
         c->spec_valid = c->pn_valid = false;
         const int rc = chain_trajectory_impl(c, p0, dt, L, u, p0_next, accepted, out5);
@@ -1715,6 +1722,17 @@ int gh_batch_fused_stats(gh_ctx *c, int *members, int *ranges, int64_t *launches
     if (ranges) *ranges = b.fus_on ? b.fus_ranges : 0;
     if (launches) *launches = b.fus_launches;
     if (timeouts) *timeouts = b.fus_aborts;
+    return GH_OK;
+}
+
+int gh_matrix_free_team_stats(gh_ctx *c, int *members, int *ranges, int64_t *launches, int *timeouts)
+{
+    if (!c) return GH_ERR_ARG;
+    const gh_ctx::MfTeam &t = c->mft;
+    if (members) *members = t.state == 1 ? t.members : 0;
+    if (ranges) *ranges = t.state == 1 ? t.ranges : 0;
+    if (launches) *launches = t.launches;
+    if (timeouts) *timeouts = t.aborts;
     return GH_OK;
 }
 

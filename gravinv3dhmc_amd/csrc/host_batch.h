@@ -52,47 +52,14 @@ static mfb_fwd_fn mfb_fwd_for(const gh_ctx *c)
     }
 }
 
-// Partition of the two passes and, for tesseroids with the near-field table, the listed pairs as
-// differences to the root leaf the dense passes stage (column-major for the adjoint, a row-major
-// copy for the forward: both sums then run in a fixed order without atomics).
-static int mfb_plan(gh_ctx *c)
+// Tesseroids with the near-field list: the listed pairs as differences to the root leaf the team / batch
+// passes stage for every pair (column-major for the adjoint, a row-major copy for the forward: both sums
+// then run in a fixed order without atomics).  Built once per context.
+static int mf_near_deltas(gh_ctx *c)
 {
     gh_ctx::Batch &b = c->bt;
-    const int64_t ntiles = (c->M + 15) / 16;
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_adj_for(c)), MFB_LDS_ADJ));
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_fwd_for(c)), MFB_LDS_FWD));
-    // one workgroup of 16 waves per CU (133 KB of staging): adjoint = column tiles dealt round-robin
-    b.mfb_grid_adj = (int)std::min<int64_t>(ntiles, (int64_t)c->cus * env_int("GRAVHMC_MFB_WG_PER_CU", 1));
-    b.n_waves = b.mfb_grid_adj;  // rows of pp_part: one per workgroup
-    // forward = 512-row chunks x ranges of column tiles, about one workgroup per CU
-    const int nrb = (int)((c->ld + 63) / 64);
-    b.mfb_rchunks = (nrb + MFB_RC_FWD - 1) / MFB_RC_FWD;
-    int ranges = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.mfb_rchunks));
-    ranges = env_int("GRAVHMC_MFB_RANGES", ranges);
-    b.mfb_tpr = (int)((ntiles + ranges - 1) / ranges);
-    b.mfb_ranges = (int)((ntiles + b.mfb_tpr - 1) / b.mfb_tpr);
-    TRY(dalloc(c, &b.iw, (size_t)c->M));
-    // one evaluation per entry and step: teams of workgroups (mfb_fused_kernel), every workgroup resident
-    b.fus_on = false;
-    b.fus_members = (nrb + MFB_RC_FUS - 1) / MFB_RC_FUS;
-    if (env_int("GRAVHMC_MFB_FUSED", 1) != 0 && b.fus_members <= MFB_FUS_MAXMEM && b.fus_members <= c->cus) {
-        int fr = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.fus_members));
-        b.fus_tpr = (int)((ntiles + fr - 1) / fr);
-        b.fus_ranges = (int)((ntiles + b.fus_tpr - 1) / b.fus_tpr);
-        mfb_fus_fn ff = mfb_fus_for(c);
-        int per_cu = 0;
-        if (allow_dynamic_lds(reinterpret_cast<const void *>(ff), MFB_LDS_FUS) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(ff), 1024, MFB_LDS_FUS) ==
-                hipSuccess &&
-            per_cu >= 1 && (int64_t)per_cu * c->cus >= (int64_t)b.fus_members * b.fus_ranges) {
-            TRY(dalloc(c, &b.fus_gran, (size_t)b.fus_ranges * MFB_FUS_RING * MFB_FUS_MAXMEM * 512));
-            TRY(dalloc(c, &b.fus_abort, 4));
-            b.fus_tag = 0;
-            b.fus_on = true;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
+    if (b.near_built) return GH_OK;
+    b.near_built = true;
     b.mfb_near = false;
     const int kind = mfb_kind(c);
     if (kind >= 2 && c->mf_near_n > 0) {
@@ -139,6 +106,163 @@ static int mfb_plan(gh_ctx *c)
         TRY(dalloc(c, &b.Snear, (size_t)c->M * CB));
         b.mfb_near = true;
     }
+    return GH_OK;
+}
+
+// ---- ONE chain on teams of workgroups (mf_team_kernel) -----------------------------------------------
+typedef void (*mft_fn)(MfGeom, SweepArgs, MftArgs, const double *, const double *, MfStats *);
+
+static mft_fn mft_for(const gh_ctx *c)
+{
+    switch (mfb_kind(c)) {
+    case 0: return mf_team_kernel<0>;
+    case 1: return mf_team_kernel<1>;
+    case 2: return mf_team_kernel<2>;
+    case 3: return mf_team_kernel<3>;
+    default: return mf_team_kernel<4>;
+    }
+}
+
+static bool mft_plan(gh_ctx *c)
+{
+    gh_ctx::MfTeam &t = c->mft;
+    if (t.state != 0) return t.state > 0;
+    t.state = -1;
+    if (!c->mf || !c->mf_fused || lonsym_on(c) || c->sh.kind != 0) return false;
+    if (c->cell_kind != GH_CELL_TESSEROID || mfb_kind(c) < 2) return false;  // (the fast / reference-order leaf with the near-field list)
+    if (env_int("GRAVHMC_MF_TEAM", 1) == 0) return false;
+    const int64_t ntiles = (c->M + 15) / 16;
+    const int nrb = (int)((c->ld + 63) / 64);
+    t.members = (nrb + MFB_RC_FUS - 1) / MFB_RC_FUS;
+    if (t.members > MFT_MAXMEM || t.members > c->cus) return false;
+    int fr = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / t.members));
+    fr = std::min(fr, c->grid - 1);  // (slab rows: one per range and one for the near field)
+    if (fr < 1) return false;
+    t.tpr = (int)((ntiles + fr - 1) / fr);
+    t.ranges = (int)((ntiles + t.tpr - 1) / t.tpr);
+    mft_fn f = mft_for(c);
+    int per_cu = 0;
+    if (allow_dynamic_lds(reinterpret_cast<const void *>(f), MFT_LDS) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), 1024, MFT_LDS) != hipSuccess ||
+        per_cu < 1 || (int64_t)per_cu * c->cus < (int64_t)t.members * t.ranges) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (mf_near_deltas(c) != GH_OK) return false;
+    if (dalloc(c, &t.gran, (size_t)t.ranges * MFB_FUS_RING * MFT_MAXMEM * 32) != GH_OK || dalloc(c, &t.abort_w, 4) != GH_OK ||
+        dalloc(c, &t.snear, (size_t)c->M) != GH_OK)
+        return false;
+    t.tag = 0;
+    t.state = 1;
+    return true;
+}
+
+// the fused leapfrog pass of one chain on teams (modes with SW_ADJ and an update / final half step)
+static int mft_launch(gh_ctx *c, SweepArgs &a)
+{
+    gh_ctx::MfTeam &t = c->mft;
+    gh_ctx::Batch &b = c->bt;
+    a.ld = c->ld;
+    a.M = c->M;
+    if ((uint64_t)t.tag + (uint64_t)t.tpr + 2 > 0xf0000000ull) {
+        HIPCHK(c, hipMemsetAsync(t.gran, 0, sizeof(u64) * (size_t)t.ranges * MFB_FUS_RING * MFT_MAXMEM * 32, c->stream));
+        t.tag = 0;
+    }
+    const double *wm = c->weighted ? c->wm : nullptr;
+    if (b.mfb_near)
+        mf1_near_adjoint_kernel<<<dim3((unsigned)c->M), dim3(64), 0, c->stream>>>(c->mf_near_ptr, c->mf_near_row, b.ndelta,
+                                                                                 a.r, t.snear);
+    MftArgs f;
+    f.tiles_per_range = t.tpr;
+    f.gran = t.gran;
+    f.tag0 = t.tag;
+    f.abort_w = t.abort_w;
+    f.poll_members = t.members + ((env_int("GRAVHMC_MF_TEAM_TEST_ABORT", 0) && t.members < MFT_MAXMEM) ? 1 : 0);
+    f.n_pp = c->n_teams;
+    f.snear = b.mfb_near ? t.snear : nullptr;
+    hipLaunchKernelGGL(mft_for(c), dim3((unsigned)t.members, (unsigned)t.ranges), dim3(1024), MFT_LDS, c->stream, mf_geom(c),
+                       a, f, wm, c->mf_cellc, c->prof ? c->mf_stats : nullptr);
+    t.tag += (unsigned)t.tpr + 1u;
+    t.inflight = true;
+    t.launches += 1;
+    if (a.mode & SW_FWD) {
+        int rows = t.ranges;
+        if (b.mfb_near) {
+            const double *x = (a.mode & SW_UPD) ? a.x_out : a.x_in;
+            HIPCHK(c, hipMemsetAsync(a.slab + (size_t)rows * (size_t)c->ld, 0, sizeof(double) * (size_t)c->ld, c->stream));
+            mf1_near_forward_kernel<<<dim3((unsigned)c->N), dim3(64), 0, c->stream>>>(b.rptr, b.rcol, b.rdelta, c->N, x, wm,
+                                                                                     a.slab + (size_t)rows * (size_t)c->ld);
+            rows += 1;
+        }
+        c->slab_live = rows;
+    }
+    HIPCHK(c, hipGetLastError());
+    return GH_OK;
+}
+
+// after a synchronisation point: did a team pass of the single chain give up?  (Then everything it fed
+// is void; the teams are off for good, the caller repeats its trajectory on the column-per-workgroup pass.)
+static int mft_failed(gh_ctx *c, bool *failed)
+{
+    gh_ctx::MfTeam &t = c->mft;
+    *failed = false;
+    if (!t.inflight) return GH_OK;
+    t.inflight = false;
+    unsigned w[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(w, t.abort_w, sizeof w, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (w[0] == 0u) return GH_OK;
+    fprintf(stderr, "libgravhmc: the matrix-free team pass timed out waiting for its workgroups; repeating the "
+                    "trajectory on the column-per-workgroup pass\n");
+    HIPCHK(c, hipMemsetAsync(t.abort_w, 0, 4 * sizeof(unsigned), c->stream));
+    t.state = -1;
+    t.aborts += 1;
+    *failed = true;
+    return GH_OK;
+}
+
+// Partition of the two passes and, for tesseroids with the near-field table, the listed pairs as
+// differences to the root leaf the dense passes stage (column-major for the adjoint, a row-major
+// copy for the forward: both sums then run in a fixed order without atomics).
+static int mfb_plan(gh_ctx *c)
+{
+    gh_ctx::Batch &b = c->bt;
+    const int64_t ntiles = (c->M + 15) / 16;
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_adj_for(c)), MFB_LDS_ADJ));
+    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(mfb_fwd_for(c)), MFB_LDS_FWD));
+    // one workgroup of 16 waves per CU (133 KB of staging): adjoint = column tiles dealt round-robin
+    b.mfb_grid_adj = (int)std::min<int64_t>(ntiles, (int64_t)c->cus * env_int("GRAVHMC_MFB_WG_PER_CU", 1));
+    b.n_waves = b.mfb_grid_adj;  // rows of pp_part: one per workgroup
+    // forward = 512-row chunks x ranges of column tiles, about one workgroup per CU
+    const int nrb = (int)((c->ld + 63) / 64);
+    b.mfb_rchunks = (nrb + MFB_RC_FWD - 1) / MFB_RC_FWD;
+    int ranges = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.mfb_rchunks));
+    ranges = env_int("GRAVHMC_MFB_RANGES", ranges);
+    b.mfb_tpr = (int)((ntiles + ranges - 1) / ranges);
+    b.mfb_ranges = (int)((ntiles + b.mfb_tpr - 1) / b.mfb_tpr);
+    TRY(dalloc(c, &b.iw, (size_t)c->M));
+    // one evaluation per entry and step: teams of workgroups (mfb_fused_kernel), every workgroup resident
+    b.fus_on = false;
+    b.fus_members = (nrb + MFB_RC_FUS - 1) / MFB_RC_FUS;
+    if (env_int("GRAVHMC_MFB_FUSED", 1) != 0 && b.fus_members <= MFB_FUS_MAXMEM && b.fus_members <= c->cus) {
+        int fr = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.fus_members));
+        b.fus_tpr = (int)((ntiles + fr - 1) / fr);
+        b.fus_ranges = (int)((ntiles + b.fus_tpr - 1) / b.fus_tpr);
+        mfb_fus_fn ff = mfb_fus_for(c);
+        int per_cu = 0;
+        if (allow_dynamic_lds(reinterpret_cast<const void *>(ff), MFB_LDS_FUS) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(ff), 1024, MFB_LDS_FUS) ==
+                hipSuccess &&
+            per_cu >= 1 && (int64_t)per_cu * c->cus >= (int64_t)b.fus_members * b.fus_ranges) {
+            TRY(dalloc(c, &b.fus_gran, (size_t)b.fus_ranges * MFB_FUS_RING * MFB_FUS_MAXMEM * 512));
+            TRY(dalloc(c, &b.fus_abort, 4));
+            b.fus_tag = 0;
+            b.fus_on = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    TRY(mf_near_deltas(c));
     b.n_colblocks = std::max(b.mfb_ranges, b.fus_on ? b.fus_ranges : 0) + (b.mfb_near ? 1 : 0);
     b.slab_live = b.n_colblocks;
     b.cols_per_block = (int64_t)b.mfb_tpr * 16;

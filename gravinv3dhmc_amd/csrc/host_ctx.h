@@ -51,6 +51,19 @@ struct gh_ctx {
     double *mf_near_val = nullptr;
     int64_t mf_near_n = 0, mf_near_leaves = 0;
     int64_t mf_launches = 0;
+    // single chain on teams of workgroups (mf_team_kernel, mfbatch.hip.h)
+    struct MfTeam {
+        int state = 0;  // 0 not planned, 1 usable, -1 not applicable / given up
+        int members = 0, ranges = 0, tpr = 0;
+        ghk::u64 *gran = nullptr;
+        unsigned *abort_w = nullptr;
+        unsigned tag = 0;
+        double *snear = nullptr;
+        bool inflight = false;
+        int aborts = 0;
+        int64_t launches = 0;
+    } mft;
+    bool chain_teams_ok = false;  // set by the trajectory code around its sweeps (it handles a time-out)
     // shift-invariant store of a regular spherical grid (lonsym.hip.h): a table instead of G or of
     // per-step evaluations; a flavour of the matrix-free mode (gh_set_shift_invariant)
     LonSymHost *ls = nullptr;
@@ -186,7 +199,7 @@ struct gh_ctx {
         double *iw = nullptr, *Snear = nullptr, *ndelta = nullptr, *rdelta = nullptr;
         int64_t *rptr = nullptr;
         int *rcol = nullptr;
-        bool mfb_near = false;
+        bool mfb_near = false, near_built = false;
         int mfb_grid_adj = 0, mfb_rchunks = 0, mfb_ranges = 0, mfb_tpr = 0;
         int slab_live = 0;        // blocks of the slab the last matrix-free forward wrote
         // fused team pass (mfb_fused_kernel): one evaluation per entry and step

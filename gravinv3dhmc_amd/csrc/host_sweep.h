@@ -260,6 +260,8 @@ static int build_near_table(gh_ctx *c)
     return GH_OK;
 }
 
+static bool mft_plan(gh_ctx *c);                     // host_batch.h: one chain on teams (mf_team_kernel)
+static int mft_launch(gh_ctx *c, SweepArgs &a);
 static int launch_lonsym(gh_ctx *c, SweepArgs &a);  // host_lonsym.h
 static bool lonsym_on(const gh_ctx *c);
 static int lonsym_grid(const gh_ctx *c);
@@ -323,6 +325,9 @@ static int launch_mf(gh_ctx *c, SweepArgs &a)
     if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     if (lonsym_on(c)) {
         TRY(launch_lonsym(c, a));
+    } else if ((a.mode & SW_ADJ) && (a.mode & (SW_UPD | SW_PFIN)) && c->chain_teams_ok && mft_plan(c)) {
+        // a leapfrog step of the chain: teams of workgroups (the trajectory code looks at the abort word)
+        TRY(mft_launch(c, a));
     } else if (c->mf_fused) {
         a.ld = c->ld;
         a.M = c->M;

@@ -793,6 +793,293 @@ mfb_fused_kernel(MfGeom g, BatchAdjArgs a, MfbFusArgs f, const double *__restric
     mfb_count(stats, nent, nleaf, lane);
 }
 
+// ---- ONE chain on teams: the single-chain matrix-free pass without a column's phases ---------------
+// mf_tess_fast_kernel (kernels.hip.h) walks a column in lock-step phases inside one workgroup -- constants,
+// 8 slots, barrier, scalars, update, forward -- and issues VALU 80 % of the time at 127 instructions per
+// entry.  The staging phase above runs at 97 instructions per entry with the VALU saturated, and a single
+// chain needs neither MFMAs nor the staged tile's transposition: wave w keeps its column's dot with r as
+// ONE number per tile, so a team's exchange is 16 doubles per member and tile.  Same grid and exchange as
+// mfb_fused_kernel (members x ranges, every workgroup resident; the data is the flag), one tile of lag:
+//   tile it:      evaluate (values to LDS, dot with the member's rows of r on the fly); in the middle of
+//                 the evaluations four waves request the team's parts of tile it - 1 and the operands of
+//                 its update, and right behind their own evaluations sum the parts (row scan over the
+//                 members' lanes) and apply the leapfrog update (hmc.py:114-152): x / wm to LDS
+//   barrier       (the only one per tile) publish the 16 partial dots of tile it; every wave: forward of
+//                 ITS column of tile it - 1 from the values it parked in LDS
+// The forward partials of the 16 waves meet once, at the end of the launch.  Near-field pairs as in the
+// batch (differences through two small sparse kernels).  Modes of SweepArgs with SW_ADJ.
+constexpr int MFT_MAXMEM = 40;  // members of a team at most (N <= 17920 rows)
+constexpr size_t MFT_LDS = (2 * (size_t)MfbTile<MFB_RC_FUS>::BUF + (size_t)MFB_NOBS * MfbTile<MFB_RC_FUS>::ROWS +
+                            (size_t)MfbTile<MFB_RC_FUS>::ROWS + 32 + 32 + 16) * sizeof(double);
+
+struct MftArgs {
+    int tiles_per_range;
+    u64 *gran;           // [gridDim.y][MFB_FUS_RING][MFT_MAXMEM][16][2]
+    unsigned tag0;
+    unsigned *abort_w;
+    int poll_members;    // gridDim.x (+ 1 in the time-out test)
+    int n_pp;            // entries of pp_part the host sums
+    const double *snear; // M: near-field part of the dots, or nullptr
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(1024)
+mf_team_kernel(MfGeom g, SweepArgs a, MftArgs f, const double *__restrict__ wm, const double *__restrict__ cellc,
+               MfStats *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int abort_s;
+    using TL = MfbTile<MFB_RC_FUS>;
+    double *obs_s = smem + 2 * TL::BUF;              // MFB_NOBS x ROWS
+    double *r_s = obs_s + MFB_NOBS * TL::ROWS;       // ROWS: the member's rows of r
+    double *part = r_s + TL::ROWS;                   // 2 x 16: the waves' dots of the tile just evaluated (by parity)
+    double *xs_s = part + 32;                        // 2 x 16: x / wm of the tile being finished (by parity)
+    double *ppred = xs_s + 32;                       // 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mem = blockIdx.x, cr = blockIdx.y;
+    const int mode = a.mode;
+    const int64_t ntiles = (a.M + 15) / 16;
+    const int nrb = (int)((a.ld + 63) / 64);
+    const int rb0 = mem * MFB_RC_FUS;
+    const int nb = nrb - rb0 < MFB_RC_FUS ? nrb - rb0 : MFB_RC_FUS;
+    const int64_t t0 = (int64_t)cr * f.tiles_per_range;
+    const int ntl = (int)((ntiles - t0 < f.tiles_per_range) ? ntiles - t0 : f.tiles_per_range);
+    if (tid == 0) abort_s = (__hip_atomic_load(f.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1 : 0;
+    {
+        MfbObsFetch<KIND, TL::ROWS> of;
+        of.fetch(g, (int64_t)rb0 * 64, tid);
+        of.park(obs_s, tid);
+        if (tid < TL::ROWS) {
+            const int64_t row = (int64_t)rb0 * 64 + tid;
+            r_s[tid] = row < g.N ? a.r[row] : 0.0;
+        }
+    }
+    u64 *gteam = f.gran + (size_t)cr * MFB_FUS_RING * MFT_MAXMEM * 32;
+    auto gran_of = [&](int it, int member) -> u64 * {
+        return gteam + ((size_t)(it & (MFB_FUS_RING - 1)) * MFT_MAXMEM + member) * 32;
+    };
+    double dacc[MFB_RC_FUS];
+#pragma unroll
+    for (int e = 0; e < MFB_RC_FUS; ++e) dacc[e] = 0.0;
+    double pp = 0.0;
+    unsigned nent = 0, nleaf = 0;
+    // Exchange roles (waves 0 .. 3 only; they finish their evaluations first): lane l of wave v collects, for
+    // column 4 v + (l >> 4) of the tile, the parts of the members (l & 15), (l & 15) + 16, (l & 15) + 32; a row
+    // scan adds the 16 lanes of a column (fixed order), and the row's last lane applies the update.  No LDS,
+    // no barrier between collecting and updating.
+    constexpr int GS = (MFT_MAXMEM + 15) / 16;
+    const bool gwave = wave < 4;
+    const int gcol = 4 * wave + (lane >> 4), gm0 = lane & 15;
+    const bool ulane = gwave && gm0 == 15;
+    __syncthreads();
+    if (abort_s) return;
+    for (int it = 0; it <= ntl; ++it) {
+        const bool stg = it < ntl, fin = it >= 1;
+        double *buf = smem + (size_t)(it & 1) * TL::BUF;
+        const unsigned gtag = f.tag0 + (unsigned)it;  // tile it - 1 carries tag0 + (it - 1) + 1
+        u64 ga[GS], gb[GS];
+        double u_w = 1.0, u_x = 0.0, u_g = 0.0, u_p = 0.0, u_pn = 0.0, u_hi = 0.0, u_lo = 0.0, u_sn = 0.0;
+        const int64_t uj = (t0 + it - 1) * 16 + gcol;  // the update lane's cell: (tile it - 1, column gcol)
+        const bool uok = fin && ulane && uj < a.M;
+        auto request = [&]() {
+            // (issued in the middle of the evaluations: the parts were published an evaluation phase ago and
+            // have mostly arrived by the time they are looked at -- their round trip hides behind the rest)
+            if (fin && gwave) {
+#pragma unroll
+                for (int q = 0; q < GS; ++q) {
+                    ga[q] = gb[q] = 0;
+                    if (gm0 + 16 * q < f.poll_members) ld_gran_issue(gran_of(it - 1, gm0 + 16 * q) + 2 * gcol, ga[q], gb[q]);
+                }
+            }
+            if (uok) {
+                u_w = wm ? wm[uj] : 1.0;
+                u_x = (mode & (SW_UPD | SW_FWD)) ? a.x_in[uj] : 0.0;  // (a final half step alone carries no position)
+                u_g = a.greg ? a.greg[uj] : 0.0;
+                if (mode & (SW_PFIN | SW_UPD)) u_p = a.p_in[uj];
+                if (mode & SW_SPEC) u_pn = a.pn_in[uj];
+                if (mode & SW_UPD) {
+                    u_hi = a.high[uj];
+                    u_lo = a.low[uj];
+                }
+                u_sn = f.snear ? f.snear[uj] : 0.0;
+            }
+        };
+        if (stg) {
+            int64_t j = (t0 + it) * 16 + wave;
+            if (j >= a.M) j = a.M - 1;
+            MfbCol<KIND> col;
+            mfb_col_load<KIND>(col, g, cellc, j);
+            double *st = buf + wave * TL::S;
+            double s = 0.0;
+            // (a copy of mfb_stage with the dot folded in and the requests in the middle)
+            if (nb == MFB_RC_FUS && KIND >= 2) {
+#pragma unroll
+                for (int e = 0; e < MFB_RC_FUS; ++e) {
+                    double o[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) o[q] = q < mfb_nobs<KIND>() ? obs_s[q * TL::ROWS + e * 64 + lane] : 0.0;
+                    const double v = mfb_eval<KIND>(col, g, o, nleaf);
+                    st[e * 64 + lane] = v;
+                    s = fma(v, r_s[e * 64 + lane], s);
+                    if (e == MFB_RC_FUS / 2) request();
+                }
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < nb; ++e) {
+                    double o[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) o[q] = q < mfb_nobs<KIND>() ? obs_s[q * TL::ROWS + e * 64 + lane] : 0.0;
+                    const double v = mfb_eval<KIND>(col, g, o, nleaf);
+                    st[e * 64 + lane] = v;
+                    s = fma(v, r_s[e * 64 + lane], s);
+                }
+                request();
+            }
+            nent += (unsigned)nb;
+            s = wave_sum_dpp(s);
+            if (lane == 0) part[(it & 1) * 16 + wave] = s;
+        } else {
+            request();
+        }
+        if (fin && gwave) {
+            // the team's parts of tile it - 1 (poll what has not arrived), summed over the members
+            double sum = 0.0;
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < GS; ++q) {
+                const int m = gm0 + 16 * q;
+                if (m < f.poll_members) {
+                    double val = 0.0;
+                    if (!gran_value(ga[q], gb[q], gtag, val)) {
+                        unsigned spins = 0;
+                        long long tstart = 0;
+                        while (ok && !ld_gran(gran_of(it - 1, m) + 2 * gcol, gtag, val)) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((++spins & 63u) == 0) {
+                                const long long now = wall_clock64();
+                                if (tstart == 0) tstart = now;
+                                if (__hip_atomic_load(f.abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                    now - tstart > RES_TIMEOUT_TICKS) {
+                                    __hip_atomic_store(f.abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = false;
+                                }
+                            }
+                        }
+                    }
+                    sum += val;
+                }
+            }
+            if (!ok) abort_s = 1;
+            const double tot = row16_sum_dpp(sum);  // lane 15 of every row of 16: the column's dot over all members
+            if (ulane) {
+                double xs = 0.0;
+                if (uok) {
+                    const double iwj = (u_w != 0.0) ? 1.0 / u_w : 1.0;
+                    const double t = (tot + u_sn) * iwj;
+                    const double grad = 2.0 * t + u_g;
+                    const bool wr = mem == 0;
+                    double xj = u_x;
+                    if ((mode & SW_GOUT) && wr) a.g_out[uj] = grad;
+                    if (mode & SW_PFIN) {
+                        const double pf = u_p - a.c_p * grad;
+                        if (wr) pp += pf * pf;
+                        if (!(mode & SW_SPEC) && wr) a.p_out[uj] = pf;
+                    }
+                    if (mode & SW_UPD) {
+                        const double psrc = (mode & SW_SPEC) ? u_pn : u_p;
+                        double pj = psrc - a.c_u * grad;
+                        xj = xj + a.dt * pj;
+                        if (xj > u_hi) {
+                            xj = u_hi;
+                            pj = -pj;
+                        } else if (xj < u_lo) {
+                            xj = u_lo;
+                            pj = -pj;
+                        }
+                        if (wr) {
+                            a.p_out[uj] = pj;
+                            a.x_out[uj] = xj;
+                        }
+                    }
+                    xs = xj * iwj;
+                }
+                xs_s[(it & 1) * 16 + gcol] = xs;
+            }
+        }
+        __syncthreads();  // the tile is staged, its 16 dots are in `part`, the finished tile's x / wm in `xs_s`
+        if (abort_s) return;
+        if (stg && tid < 16) st_gran(gran_of(it, mem) + 2 * tid, f.tag0 + (unsigned)it + 1u, part[(it & 1) * 16 + tid]);
+        if (fin && (mode & SW_FWD)) {
+            const double *pv = smem + (size_t)((it - 1) & 1) * TL::BUF + wave * TL::S;
+            const double xw = xs_s[(it & 1) * 16 + wave];
+#pragma unroll
+            for (int e = 0; e < MFB_RC_FUS; ++e) dacc[e] = fma(pv[e * 64 + lane], xw, dacc[e]);
+        }
+        // (ONE barrier per tile: a wave reads and re-stages only its own column of a staging buffer, and
+        // `part` / `xs_s` alternate by the tile's parity -- nobody is more than a barrier behind)
+    }
+    if (mode & SW_FWD) {
+        // the 16 waves' partials of the member's rows, in wave order
+        __syncthreads();
+        double *sum_s = smem;  // 16 x ROWS (the staging buffers are free)
+#pragma unroll
+        for (int e = 0; e < MFB_RC_FUS; ++e) sum_s[wave * TL::ROWS + e * 64 + lane] = dacc[e];
+        __syncthreads();
+        double *out = a.slab + (int64_t)cr * a.ld;
+        if (tid < TL::ROWS) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < MFB_WAVES; ++w) t += sum_s[w * TL::ROWS + tid];
+            const int64_t row = (int64_t)rb0 * 64 + tid;
+            if (tid < nb * 64 && row < a.ld) out[row] = t;
+        }
+    }
+    if ((mode & SW_PFIN) && mem == 0) {
+        __syncthreads();
+        if (ulane) ppred[gcol] = pp;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < 16; ++q) t += ppred[q];
+            a.pp_part[cr] = t;
+            if (cr == 0)
+                for (int q = (int)gridDim.y; q < f.n_pp; ++q) a.pp_part[q] = 0.0;
+        }
+    }
+    mfb_count(stats, nent, nleaf, lane);
+}
+
+// near-field differences for ONE chain: snear[j] = sum over the listed rows of column j of delta * r[row]
+__global__ void __launch_bounds__(64)
+mf1_near_adjoint_kernel(const int64_t *__restrict__ ptr, const int *__restrict__ row, const double *__restrict__ delta,
+                        const double *__restrict__ r, double *__restrict__ snear)
+{
+    const int64_t j = blockIdx.x;
+    const int64_t q0 = ptr[j], q1 = ptr[j + 1];
+    double s = 0.0;
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += 64) s += delta[q] * r[row[q]];
+    s = wave_sum_dpp(s);
+    if (threadIdx.x == 0) snear[j] = s;
+}
+
+// out[i] = sum over the listed columns of row i of delta * x[col] / wm[col]: one more row of the slab
+__global__ void __launch_bounds__(64)
+mf1_near_forward_kernel(const int64_t *__restrict__ rptr, const int *__restrict__ rcol, const double *__restrict__ rdelta,
+                        int64_t N, const double *__restrict__ x, const double *__restrict__ wm, double *__restrict__ out)
+{
+    const int64_t i = blockIdx.x;
+    double s = 0.0;
+    if (i < N)
+        for (int64_t q = rptr[i] + threadIdx.x; q < rptr[i + 1]; q += 64) {
+            const int64_t j = rcol[q];
+            const double w = wm ? wm[j] : 1.0;
+            s += rdelta[q] * ((w != 0.0) ? x[j] * (1.0 / w) : x[j]);
+        }
+    s = wave_sum_dpp(s);
+    if (threadIdx.x == 0) out[i] = s;
+}
+
 // ---- near-field list as differences ---------------------------------------------------------------
 // delta[q] = val[q] - (the root leaf the dense passes stage for that pair), column-major order
 template <int KIND>

@@ -502,6 +502,12 @@ class Engine(object):
         self._chk(self._lib.gh_batch_fused_stats(self._h, C.byref(m), C.byref(r), C.byref(l), C.byref(t)))
         return {"members": m.value, "ranges": r.value, "launches": l.value, "timeouts": t.value}
 
+    def matrix_free_team_stats(self):
+        """Team form of the single-chain matrix-free pass: grid, launches, time-outs."""
+        m, r, l, t = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int(0)
+        self._chk(self._lib.gh_matrix_free_team_stats(self._h, C.byref(m), C.byref(r), C.byref(l), C.byref(t)))
+        return {"members": m.value, "ranges": r.value, "launches": l.value, "timeouts": t.value}
+
     def batch_get_x(self, chain):
         x = np.empty(self.M)
         self._chk(self._lib.gh_batch_get_x(self._h, int(chain), ptr(x)))

@@ -298,6 +298,13 @@ int gh_batch_get_x(gh_ctx *ctx, int chain, double *x /* M */);
  * context stays on the two-pass form; gh_batch_trajectory repeats the round, gh_batch_run returns an error
  * and wants gh_batch_init again). */
 int gh_batch_fused_stats(gh_ctx *ctx, int *members, int *ranges, int64_t *launches, int *timeouts);
+/* The same team form for ONE chain on a matrix-free tesseroid context (the leapfrog steps of
+ * gh_chain_trajectory / gh_chain_run; N <= 17920 observations, the near-field list in use, the GPU not shared):
+ * a wave keeps its column's dot with r as one number per tile, so a team exchanges 16 doubles per member and
+ * tile, and the column-per-workgroup phases of the plain pass (constants, slots, barrier, scalars, update,
+ * forward) disappear.  A pass that times out (2 s) switches the form off for good; the trajectory is
+ * repeated on the column-per-workgroup pass.  Numbers as above. */
+int gh_matrix_free_team_stats(gh_ctx *ctx, int *members, int *ranges, int64_t *launches, int *timeouts);
 
 /* Posterior statistics without text I/O.  The reference appends every accepted
  * model as a '%.8f' text row to model.dat (hmc.py:328-332) and its plot scripts take np.mean /

@@ -384,3 +384,56 @@ def test_wavelet_forward_on_a_matrix_free_model(G, wavelet):
     assert relmax(outs[0][1], outs[1][1]) < 1e-10
     for m in mods.values():
         m._engine.close()
+
+
+def test_single_chain_matrix_free_on_teams_and_its_time_out(G, monkeypatch):
+    """mf_team_kernel: the leapfrog steps of ONE matrix-free tesseroid chain on teams of workgroups (a wave
+    keeps its column's dot as one number per tile; 16 doubles per member and tile cross the team) against the
+    column-per-workgroup pass (GRAVHMC_MF_TEAM=0) and the dense engine: the same chain; and a team pass that
+    gives up (test hook) -- the trajectory is repeated on the column-per-workgroup pass, the teams stay off."""
+    obs, bounds, kind, shape = _tess_problem(G)
+    N, M = obs[0].size, bounds.shape[0]
+    rng = np.random.default_rng(15)
+    rho = rng.uniform(0.0, 0.5, M)
+    trajs = [(int(rng.integers(1, 7)), rng.normal(size=M) * 0.002, float(rng.uniform())) for _ in range(8)]
+
+    def run(matrix_free, team, abort_at=None):
+        monkeypatch.setenv("GRAVHMC_MF_TEAM", team)
+        e = G.Engine(N, M)
+        e.set_matrix_free(matrix_free)
+        e.set_obs(*obs)
+        e.set_cells(bounds, kind, 1.6)
+        e.build_G()
+        d_true = e.forward(rho)
+        wm = e.weight(0.5)
+        e.set_data(d_true + 0.02 * np.abs(d_true).max() * np.random.default_rng(16).normal(size=N))
+        e.set_reg("MS", 0.05, 0.01, shape, 0.001 * wm)
+        e.chain_init(0.001 * wm, 0.0 * wm, 0.8 * wm)
+        res = []
+        for k, (L, p0, u) in enumerate(trajs):
+            if abort_at == k:
+                monkeypatch.setenv("GRAVHMC_MF_TEAM_TEST_ABORT", "1")
+            acc, o = e.chain_trajectory(p0, 0.005, L, u)
+            monkeypatch.delenv("GRAVHMC_MF_TEAM_TEST_ABORT", raising=False)
+            res.append((acc, np.array(o)))
+        st = e.matrix_free_team_stats() if matrix_free else None
+        x = e.chain_get_x()
+        e.close()
+        return res, x, st
+
+    team, xt, st_t = run(True, "1")
+    plain, xp_, st_p = run(True, "0")
+    dense, xd, _ = run(False, "0")
+    tout, xo, st_o = run(True, "1", abort_at=3)
+    assert st_t["launches"] > 0 and st_t["timeouts"] == 0 and st_t["members"] > 0, st_t
+    assert st_p["launches"] == 0, st_p
+    assert st_o["timeouts"] == 1 and st_o["members"] == 0, st_o
+    worst = 0.0
+    for other, xo_ in ((plain, xp_), (dense, xd), (tout, xo)):
+        for (a1, o1), (a2, o2) in zip(team, other):
+            assert a1 == a2
+            worst = max(worst, relmax(o1, o2))
+        worst = max(worst, relmax(xt, xo_))
+    print("single-chain matrix-free on teams %r vs column-per-workgroup pass / dense engine / after a time-out: %.2e"
+          % (st_t, worst))
+    assert worst < 1e-10
