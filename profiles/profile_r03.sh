@@ -29,6 +29,23 @@ prof() {  # tag, rocprof options..., --, bench options...   (returns non-zero if
 }
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU"
 SQ2="SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_LDS SQ_INSTS_VALU_TRANS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+if [ $which = all ] || [ $which = c4 ]; then
+  # one chain, matrix-free: the team pass (default) -- and the column-per-workgroup pass for comparison
+  A="--workload c4_global_tesseroid --matrix-free --no-cpu-baseline"
+  if prof c4mf_trace --kernel-trace --stats -- $A --steps 200 --warmup 20 \
+     && prof c4mf_sq --pmc $SQ1 --kernel-trace -- $A --steps 20 --warmup 0 \
+     && prof c4mf_sq2 --pmc $SQ2 --kernel-trace -- $A --steps 20 --warmup 0; then
+    python3 $REPO/profiles/summarize.py stats $OUT/c4mf_trace $SUM/c4_matrix_free_kernel_stats.csv
+    python3 $REPO/profiles/summarize.py pmc $SUM/c4_matrix_free_pmc_summary.json "rocprofv3 --pmc passes (SQ counters, with --kernel-trace only) of python3 bench.py $A --steps 20 --warmup 0 on MI355X; recipe profiles/profile_r03.sh; per-dispatch averages; SQ cycle counters in quad-cycles summed over the chip" $OUT/c4mf_sq $OUT/c4mf_sq2
+    cp $OUT/c4mf_trace.json $SUM/bench_c4_matrix_free_under_rocprof_trace.json
+  fi
+  export GRAVHMC_MF_TEAM=0
+  if prof c4mf0_trace --kernel-trace --stats -- $A --steps 200 --warmup 20; then
+    python3 $REPO/profiles/summarize.py stats $OUT/c4mf0_trace $SUM/c4_matrix_free_column_per_workgroup_kernel_stats.csv
+    cp $OUT/c4mf0_trace.json $SUM/bench_c4_matrix_free_column_per_workgroup_under_rocprof_trace.json
+  fi
+  unset GRAVHMC_MF_TEAM
+fi
 if [ $which = all ] || [ $which = c4b ]; then
   A="--workload c4_global_tesseroid --matrix-free --chains-per-gpu 8 --no-cpu-baseline"
   if prof c4b_trace --kernel-trace --stats -- $A --steps 100 --warmup 20 \
