@@ -295,6 +295,8 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
 #: (same script, its own workload) and summarised under `extra`, so one driver record carries them
 EXTRA_RUNS = [
     ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
+    ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
+                              "--warmup", "20"]),
     ("c3_segment_wavelet3d_tv", ["--workload", "c3_segment_wavelet3d_tv", "--steps", "20000", "--warmup", "2000"]),
     ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
                                          "--warmup", "10"]),
@@ -325,7 +327,7 @@ def extra_run(device, extra_args):
         return l["hmcsample"]
     r = l["roofline"]
     keep = ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_ms", "launches", "us_per_evaluation",
-            "near_field_table", "entries_per_s", "flop_model", "table", "table_read_GBps", "dense_G_equiv_GBps")
+            "near_field_table", "entries_per_s", "flop_model", "fp64_matrix_TFLOPs", "table", "table_read_GBps", "dense_G_equiv_GBps")
     return {"value": l["value"], "unit": l["unit"], "steps": l["steps"], "warmup": l["warmup"],
             "ms_per_step": l["ms_per_step"],
             "config": {k: l["config"].get(k) for k in ("workload", "N_obs", "M_cells", "G_bytes", "regulariser",
@@ -697,6 +699,18 @@ def main():
                           "share each read of G; two sweeps per leapfrog step of the batch)" % CPG,
                 "fp64_matrix_TFLOPs": 4.0 * N * M * 16 * prof["sweeps"] / 2 / (prof["sweep_ms"] * 1e-3) / 1e12,
                 "reference_formulation_equiv_GBps": 2 * bytes_sweep * CPG * args.steps / elapsed / 1e9})
+        if CPG > 1 and not args.matrix_free and cstat.get("resident_evaluations", 0) == 0:
+            tstat = eng.batch_fused_stats()
+            if tstat["launches"] > 0 and tstat["timeouts"] == 0:
+                # the timed launches were team passes (csrc/batchteam.hip.h): both products of all chains
+                # from ONE read of G -- a launch is a leapfrog step of the batch
+                line["roofline"].update({
+                    "kernel": ("batch_team_kernel (%d chains share ONE read of G per leapfrog step: teams of %d "
+                               "workgroups x %d ranges of column tiles, v_mfma_f64_16x16x4 for both products)"
+                               % (CPG, tstat["members"], tstat["ranges"])),
+                    "fp64_matrix_TFLOPs": 4.0 * N * M * 16 * prof["sweeps"] / (prof["sweep_ms"] * 1e-3) / 1e12,
+                    "fp64_matrix_peak_TFLOPs": 78.6,
+                    "reference_formulation_equiv_GBps": 2 * bytes_sweep * CPG * args.steps / elapsed / 1e9})
         if args.shift_invariant:
             # K[i, (c, k)] = T[c][class_i][(m_i - k) mod n]: the pass reads the table once (L2 / Infinity
             # Cache resident) and does the N*M multiply-adds of adjoint and forward out of LDS

@@ -6,6 +6,7 @@
 #include "resident.hip.h"
 #include "teamsweep.hip.h"
 #include "mfbatch.hip.h"
+#include "batchteam.hip.h"
 #include "lonsym.hip.h"
 
 #include <dlfcn.h>
@@ -1421,7 +1422,7 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
     TRY(dalloc(c, &b.pn0_part, (size_t)b.n_pp0 * CB));
     // (matrix-free team pass: the momentum every trajectory in flight started with, so that the
     // trajectories can be replayed if a pass gives up)
-    const bool keep_pstart = c->mf && b.fus_on;
+    const bool keep_pstart = b.fus_on;
     if (keep_pstart) TRY(dalloc(c, &b.Pstart, (size_t)n16));
     // two working sets: a sweep reads set run.ws, the evaluation behind it writes the other one
     double *GREGs[2] = {b.GREGw, b.GREGw2}, *Ds[2] = {b.Dw, b.Dw2}, *Rts[2] = {b.Rtw, b.Rtw2},

@@ -269,6 +269,37 @@ static int mfb_plan(gh_ctx *c)
     return GH_OK;
 }
 
+// Stored kernel: teams of workgroups that read G once per step (batch_team_kernel).  Needs every workgroup
+// resident (one per CU) and 8 .. 32 members (3137 .. 14336 rows); otherwise the two-pass kernels stay.
+static int bteam_plan(gh_ctx *c)
+{
+    gh_ctx::Batch &b = c->bt;
+    b.fus_on = false;
+    if (env_int("GRAVHMC_BATCH_TEAM", 1) == 0 || !c->G) return GH_OK;
+    const int64_t ntiles = (c->M + 15) / 16;
+    const int nrb = (int)((c->ld + 63) / 64);
+    b.fus_members = (nrb + BT_RC - 1) / BT_RC;
+    if (c->ld % 16 != 0 || b.fus_members < BT_MINMEM || b.fus_members > BT_MAXMEM || b.fus_members > c->cus) return GH_OK;
+    const int fr = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, c->cus / b.fus_members));
+    b.fus_tpr = (int)((ntiles + fr - 1) / fr);
+    b.fus_ranges = (int)((ntiles + b.fus_tpr - 1) / b.fus_tpr);
+    b.fus_nval = (256 + b.fus_members - 1) / b.fus_members;
+    const void *fn = reinterpret_cast<const void *>(batch_team_kernel);
+    int per_cu = 0;
+    if (allow_dynamic_lds(fn, BT_LDS) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BT_NW * 64, BT_LDS) != hipSuccess || per_cu < 1 ||
+        (int64_t)per_cu * c->cus < (int64_t)b.fus_members * b.fus_ranges) {
+        (void)hipGetLastError();
+        return GH_OK;
+    }
+    TRY(dalloc(c, &b.fus_gran, (size_t)b.fus_ranges * BT_RING * BT_MAXMEM * 512));
+    TRY(dalloc(c, &b.fus_granx, (size_t)b.fus_ranges * BT_RING * 512));
+    TRY(dalloc(c, &b.fus_abort, 4));
+    b.fus_tag = 0;
+    b.fus_on = true;
+    return GH_OK;
+}
+
 static int batch_time_begin(gh_ctx *c, bool &timed);
 static int batch_time_end(gh_ctx *c, bool timed);
 
@@ -361,6 +392,40 @@ static int batch_launch_adjoint(gh_ctx *c, BatchAdjArgs &a, bool fwd_follows)
                            b.mfb_near ? b.Snear : nullptr, c->prof ? c->mf_stats : nullptr);
         TRY(batch_time_end(c, timed));
         if (c->prof) c->mf_launches += 1;
+    } else if (b.fus_on) {
+        // stored kernel on teams: adjoint of all chains, update and the forward at the new positions from ONE
+        // read of G (an adjoint nothing follows costs the same read: the forward rides along unused)
+        if ((uint64_t)b.fus_tag + (uint64_t)b.fus_tpr + 2 > 0xf0000000ull) {
+            HIPCHK(c, hipMemsetAsync(b.fus_gran, 0, sizeof(u64) * (size_t)b.fus_ranges * BT_RING * BT_MAXMEM * 512, c->stream));
+            HIPCHK(c, hipMemsetAsync(b.fus_granx, 0, sizeof(u64) * (size_t)b.fus_ranges * BT_RING * 512, c->stream));
+            b.fus_tag = 0;
+        }
+        BtArgs f;
+        f.tiles_per_range = b.fus_tpr;
+        f.nval = b.fus_nval;
+        f.slab = b.slab;
+        f.gran_p = b.fus_gran;
+        f.gran_x = b.fus_granx;
+        f.tag0 = b.fus_tag;
+        f.abort_w = b.fus_abort;
+        // test hook: the members wait for a part that never comes, time out and give up
+        f.poll_members = b.fus_members + ((env_int("GRAVHMC_BATCH_TEAM_TEST_ABORT", 0) && b.fus_members < BT_MAXMEM) ? 1 : 0);
+        f.n_pp = b.n_waves;
+        f.dbg = nullptr;
+        if (env_int("GRAVHMC_MFB_TIMING", 0)) {
+            TRY(dalloc(c, &b.fus_dbg, 8));
+            f.dbg = b.fus_dbg;
+        }
+        f.dbg_mem = env_int("GRAVHMC_BT_DBG_MEM", 0);
+        f.dbg_wave = env_int("GRAVHMC_BT_DBG_WAVE", 0);
+        TRY(batch_time_begin(c, timed));
+        hipLaunchKernelGGL(batch_team_kernel, dim3((unsigned)b.fus_members, (unsigned)b.fus_ranges), dim3(BT_NW * 64), BT_LDS,
+                           c->stream, a, f);
+        TRY(batch_time_end(c, timed));
+        b.fus_tag += (unsigned)b.fus_tpr + 1u;
+        b.fus_inflight = true;
+        b.fus_launches += 1;
+        if (fwd_follows) b.fus_fwd_of = a.X_out;
     } else {
         TRY(batch_time_begin(c, timed));
         batch_adjoint_kernel<<<dim3((unsigned)(b.n_waves / 4)), dim3(256), 0, c->stream>>>(a);
@@ -402,8 +467,12 @@ static int batch_alloc(gh_ctx *c)
         const int64_t npairs = (ntiles + 1) / 2;  // a wave owns two adjacent column tiles
         const int wgs = (int)std::min<int64_t>((npairs + 3) / 4, (int64_t)c->cus * 4);
         b.n_waves = wgs * 4;
+        TRY(bteam_plan(c));
+        if (b.fus_on) {
+            b.n_waves = std::max(b.n_waves, (b.fus_members * b.fus_ranges + 3) / 4 * 4);  // rows of pp_part
+        }
     }
-    TRY(dalloc(c, &b.slab, (size_t)b.n_colblocks * L16));
+    TRY(dalloc(c, &b.slab, (size_t)std::max(b.n_colblocks, b.fus_on ? b.fus_ranges : 0) * L16));
     b.n_regblocks = (int)((c->M + 15) / 16);
     TRY(dalloc(c, &b.regpart, (size_t)b.n_regblocks * CB));
     TRY(dalloc(c, &b.pp_part, (size_t)b.n_waves * CB));
@@ -412,7 +481,9 @@ static int batch_alloc(gh_ctx *c)
     HIPCHK(c, hipHostMalloc((void **)&b.h, sizeof(double) * (size_t)(CB * 4 + (b.n_waves + 2 * b.n_pp0) * CB)));
     // the adjoint GEMM wants G in MFMA operand order; 288 GB of HBM usually has room for the
     // second copy (C2: 40 GB + 40 GB).  Without it the kernel reads the column-major matrix.
-    if (!c->mf && env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
+    // (not with the team pass: it reads the column-major matrix once per step and needs no second copy; if
+    // it ever gives up, the two-pass adjoint reads the column-major matrix as well)
+    if (!c->mf && !b.fus_on && env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
         size_t free_b = 0, total_b = 0;
         const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)2 << 30)) {
@@ -467,8 +538,8 @@ static int mfb_fused_failed(gh_ctx *c, bool *failed)
     HIPCHK(c, hipMemcpyAsync(w, b.fus_abort, sizeof w, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (w[0] == 0u) return GH_OK;
-    fprintf(stderr, "libgravhmc: the fused matrix-free batch pass timed out waiting for its workgroups; "
-                    "continuing with the two-pass kernels\n");
+    fprintf(stderr, "libgravhmc: the %s timed out waiting for its workgroups; continuing with the two-pass kernels\n",
+            c->mf ? "fused matrix-free batch pass" : "batch's team pass");
     HIPCHK(c, hipMemsetAsync(b.fus_abort, 0, 4 * sizeof(unsigned), c->stream));
     b.fus_on = false;
     b.fus_aborts += 1;
@@ -482,9 +553,15 @@ static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, d
 {
     gh_ctx::Batch &b = c->bt;
     bool timed;
+    int nblocks = b.n_colblocks;
     if (c->mf) {
         TRY(mfb_forward(c, X));
+    } else if (b.fus_fwd_of == X) {
+        // the team pass that produced X left its forward partials in the slab already
+        b.fus_fwd_of = nullptr;
+        nblocks = b.fus_ranges;
     } else {
+        b.fus_fwd_of = nullptr;
         BatchFwdArgs f;
         f.G = c->G;
         f.ld = c->ld;
@@ -500,7 +577,7 @@ static int batch_evaluate(gh_ctx *c, const double *X, double *D, double *GREG, d
     }
     const int64_t n16 = c->ld * CB;
     batch_reduce_kernel<<<dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream>>>(
-        b.slab, c->mf ? b.slab_live : b.n_colblocks, n16, D);
+        b.slab, c->mf ? b.slab_live : nblocks, n16, D);
     BatchRegArgs ra;
     ra.kind = c->reg_kind;
     ra.M = c->M;

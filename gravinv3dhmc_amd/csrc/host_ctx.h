@@ -202,10 +202,12 @@ struct gh_ctx {
         bool mfb_near = false, near_built = false;
         int mfb_grid_adj = 0, mfb_rchunks = 0, mfb_ranges = 0, mfb_tpr = 0;
         int slab_live = 0;        // blocks of the slab the last matrix-free forward wrote
-        // fused team pass (mfb_fused_kernel): one evaluation per entry and step
+        // team pass: one evaluation (mfb_fused_kernel) / one read (batch_team_kernel, stored G) per entry and step
         bool fus_on = false, fus_inflight = false;
         int fus_members = 0, fus_ranges = 0, fus_tpr = 0, fus_aborts = 0;
         ghk::u64 *fus_gran = nullptr;
+        ghk::u64 *fus_granx = nullptr;  // stored kernel on teams (batch_team_kernel): the new positions' granules
+        int fus_nval = 0;               // ... and the (cell, chain) pairs of a tile a member updates
         unsigned *fus_abort = nullptr;
         long long *fus_dbg = nullptr;  // GRAVHMC_MFB_TIMING: per-phase clocks of one workgroup
         double *Pstart = nullptr;      // M x 16: the momentum each trajectory in flight started with (gh_batch_run)

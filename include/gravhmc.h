@@ -28,13 +28,14 @@
  *     GRAVHMC_MF_PIPE=0 / GRAVHMC_MF_NEAR=0 (matrix-free: two-pass form / plain build / subdivision
  *     inside the pass instead of the near-field table), GRAVHMC_MFB_FUSED=0 (matrix-free batch: two
  *     passes instead of teams), GRAVHMC_MFB_RU=0 (no one-height specialisation), GRAVHMC_BATCH_SPEC=0,
- *     GRAVHMC_BATCH_RELAYOUT=0, GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
+ *     GRAVHMC_BATCH_RELAYOUT=0, GRAVHMC_BATCH_TEAM=0 (stored-kernel batch: two reads of G per step instead
+ *     of teams reading it once), GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
  *   arithmetic of an entry (within the path's stated 1e-10, ~1e-14 measured): GRAVHMC_MF_EXACT -- the
  *     DEFAULT of gh_set_matrix_free_exact only; that call overrides it;
  *   tuning without any effect on results: GRAVHMC_PF, _NT, _TW, _TW8, _WG_PER_CU, _MIN_COLS,
  *     _INFLIGHT_MB, GRAVHMC_MF_T, _MF_WG_PER_CU, GRAVHMC_MFB_WG_PER_CU, _MFB_RANGES, GRAVHMC_RNG_THREADS;
  *   test hooks (force a time-out path): GRAVHMC_TEAM_TEST_ABORT, GRAVHMC_RESIDENT_TEST_ABORT,
- *     GRAVHMC_MFB_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, and
+ *     GRAVHMC_MFB_TEST_ABORT, GRAVHMC_BATCH_TEAM_TEST_ABORT, GRAVHMC_MF_TEAM_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, and
  *     GRAVHMC_RESIDENT_TIMING (per-phase clocks, results intact).
  * (Python side: GRAVHMC_HOST_RNG=numpy draws with np.random itself -- same stream; GRAVHMC_LIB = path
  * of the shared library.)

@@ -1323,6 +1323,81 @@ def test_batch_run_desynchronised_chains_match_lockstep_rounds(G, monkeypatch, c
     eb.close()
 
 
+@pytest.mark.parametrize("form", ["teams_one_read", "teams_time_out", "teams_time_out_desync"])
+@pytest.mark.parametrize("case", ["twelve_members_rows_of_16_lanes", "twenty_one_members_half_waves"])
+def test_batch_on_teams_reads_G_once_and_matches_the_two_pass_batch(G, monkeypatch, case, form):
+    """batch_team_kernel (csrc/batchteam.hip.h): the workgroups holding the row chunks of a column tile
+    exchange their partial dots (reduce-scatter), update their share of the (cell, chain) pairs and
+    collect the new positions (all-gather), so that adjoint, update and forward of ALL chains come from
+    one read of G (hmc.py:114-152 per chain).  Against the two-pass MFMA batch (itself checked against
+    single-chain engines above): same decisions, results <= 1e-10, in lock-step rounds and with
+    desynchronised chains; every phase of a chain (update, final half step, idle, the speculative first
+    step of gh_batch_run) passes through the team kernel.  A time-out (test hook: the members wait for a
+    part that never comes) must leave the chains' states intact and repeat the work on the two passes."""
+    rng = np.random.default_rng(23)
+    if case == "twelve_members_rows_of_16_lanes":
+        N, M, C = 5003, 1234, 5          # 79 row blocks of 64: 12 members, 22 pairs each, partial last tile
+    else:
+        N, M, C = 9001, 1000, 16         # 141 row blocks: 21 members, 13 pairs each (the last member: none)
+    A = np.asfortranarray(rng.normal(size=(N, M)))
+    dobs, shape = rng.normal(size=N) * 20, (1, 1, M)
+    dt, sig, hi, T = 0.004, 0.02, 0.5, 3
+
+    def make(team):
+        monkeypatch.setenv("GRAVHMC_BATCH_TEAM", team)
+        e = G.Engine(N, M)
+        e.upload_G(A)
+        w = e.weight(0.5)
+        e.set_data(dobs)
+        e.set_reg("Damping", 1.0, 0.01, shape, 0.001 * w)
+        x0s = np.stack([(0.001 + 0.002 * c) * w for c in range(C)])
+        e.batch_init(x0s, 0.0 * w, hi * w)
+        return e
+
+    monkeypatch.setenv("GRAVHMC_RESIDENT", "0")
+    if form != "teams_one_read":
+        monkeypatch.setenv("GRAVHMC_BATCH_TEAM_TEST_ABORT", "1")
+    et = make("1")
+    e2 = make("0")
+    st = et.batch_fused_stats()
+    assert st["members"] == (12 if N == 5003 else 21) and st["ranges"] >= 1
+    assert e2.batch_fused_stats()["members"] == 0
+    Ls = rng.integers(1, 7, size=(C, T))
+    p0s = rng.normal(size=(C, T, M)) * sig
+    us = rng.uniform(size=(C, T))
+    n_acc = 0
+    if form == "teams_time_out_desync" or form == "teams_one_read":
+        acc_t, out_t, xs_t = et.batch_run(p0s, dt, Ls, us, want_x=True)
+        acc_2, out_2, xs_2 = e2.batch_run(p0s, dt, Ls, us, want_x=True)
+        assert np.array_equal(acc_t, acc_2)
+        assert relmax(out_t, out_2) < 1e-10
+        for c in range(C):
+            for t in range(T):
+                if acc_2[c, t]:
+                    assert relmax(xs_t[c, t], xs_2[c, t]) < 1e-10
+                    n_acc += 1
+    if form != "teams_time_out_desync":
+        for t in range(T):
+            p1 = rng.normal(size=(C, M)) * sig
+            L1 = rng.integers(1, 7, size=C)
+            u1 = rng.uniform(size=C)
+            acc_t, out_t = et.batch_trajectory(p1, dt, L1, u1)
+            acc_2, out_2 = e2.batch_trajectory(p1, dt, L1, u1)
+            assert np.array_equal(acc_t, acc_2), (case, t)
+            assert relmax(out_t, out_2) < 1e-10
+            n_acc += int(np.sum(acc_2))
+    assert n_acc > 0
+    for c in range(C):
+        assert relmax(et.batch_get_x(c), e2.batch_get_x(c)) < 1e-10
+    st = et.batch_fused_stats()
+    if form == "teams_one_read":
+        assert st["timeouts"] == 0 and st["launches"] > 0 and st["members"] > 0
+    else:
+        assert st["timeouts"] == 1 and st["members"] == 0      # off for good after the time-out
+    et.close()
+    e2.close()
+
+
 def test_batch_run_carry_over_continues_trajectories_across_calls(G, monkeypatch):
     """gh_batch_run in carry-over mode: a call ends when the first chain has used up its offer, the
     others keep their trajectory in flight and finish it in a later call.  Feeding the chains call

@@ -273,3 +273,72 @@ def test_bench_gpus_n_starts_its_ranks_as_children(monkeypatch):
     assert cmd[-5:] == ["--gpus", "4", "--steps", "5", "--shard"] and cmd[-6].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert "gravinv3dhmc_amd._lib" not in sys.modules or True   # (the parent never needs the library)
+
+
+def test_team_batch_kernel_code_never_touches_a_register_with_a_load_in_flight(tmp_path):
+    """csrc/batchteam.hip.h issues its loads as inline assembly -- invisible to the compiler's wait-count
+    bookkeeping -- and covers them with explicit s_waitcnt vmcnt(n).  The compiler therefore believes
+    the destination registers are valid at once: a copy, a spill or any other use of one of them
+    between the load and the wait that covers it would silently read stale bits.  Check the generated
+    gfx950 code: inside the loop, the registers of the G tiles are touched by nothing but the loads
+    themselves, the MFMAs and the 16-byte LDS stores that park them, and no instruction touches the
+    destination of a small exchange load before the next vmcnt wait; and nothing is spilled."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "gravinv3dhmc_amd", "csrc")
+    tu = tmp_path / "bt.hip"
+    tu.write_text("".join('#include "%s"\n' % os.path.join(csrc, h) for h in
+                          ("kernels.hip.h", "batch.hip.h", "resident.hip.h", "mfbatch.hip.h", "batchteam.hip.h")))
+    asm = tmp_path / "bt.s"
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", str(tu),
+                          "-o", str(asm), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = out.stderr[out.stderr.index("batch_team_kernel"):]
+    rep = rep[:rep.index("LDS Size")]
+    assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", rep) and re.search(r"VGPRs Spill: 0\b", rep), rep
+    text = asm.read_text()
+    body = text[text.index("_ZN3ghk17batch_team_kernelENS_12BatchAdjArgsENS_6BtArgsE:"):]
+    body = body[:body.index(".Lfunc_end")]
+    lines = body.split("\n")
+    start = next(i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l)
+    # (the loop's barriers are bt_lds_barrier()'s inline assembly; the code behind the loop has __syncthreads())
+    last_barrier = max(i for i, l in enumerate(lines)
+                       if re.match(r"\s*s_barrier", l) and any("#ASMSTART" in x for x in lines[i - 3:i]))
+
+    def regs(code):
+        found = set()
+        for m in re.finditer(r"v\[(\d+):(\d+)\]", code):
+            found.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", code):
+            found.add(int(m.group(1)))
+        return found
+
+    code = [(i, l.split(";")[0].strip()) for i, l in enumerate(lines)]
+    code = [(i, c) for i, c in code if c and not c.startswith(".")]
+    tile = set()
+    for i, c in code:
+        m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off.* nt", c)
+        if m and i >= start:
+            tile.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    assert len(tile) == 96, len(tile)                     # three sets of 4 patches x 2 x 16 bytes
+    allowed = ("v_mfma_f64_16x16x4_f64", "global_load_dwordx4", "ds_write_b128")
+    stray = [(i, c) for i, c in code if start <= i <= last_barrier and regs(c) & tile and c.split()[0] not in allowed]
+    assert not stray, stray[:5]
+    # the small loads of the exchange (8-byte loads): nothing reads or writes their destination before a wait
+    pending, early = {}, []
+    for i, c in code:
+        if i < start or i > last_barrier:
+            continue
+        op = c.split()[0]
+        if op == "s_waitcnt" and "vmcnt" in c:
+            pending = {}
+            continue
+        m = re.match(r"global_load_dwordx2 v\[(\d+):(\d+)\]", c)
+        if not m and regs(c) & set(pending):
+            early.append((i, c))
+        if m:
+            pending.update({r: i for r in range(int(m.group(1)), int(m.group(2)) + 1)})
+    assert not early, early[:5]
