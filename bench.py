@@ -297,6 +297,8 @@ EXTRA_RUNS = [
     ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
     ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                               "--warmup", "20"]),
+    ("c2_uniform_16_chains_one_read_of_G", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
+                                            "--warmup", "20", "--batch-team", "on"]),
     ("c3_segment_wavelet3d_tv", ["--workload", "c3_segment_wavelet3d_tv", "--steps", "20000", "--warmup", "2000"]),
     ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
                                          "--warmup", "10"]),
@@ -456,6 +458,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2_uniform_100x100x50",
                     choices=list(WORKLOADS) + list(EXTRA))
+    ap.add_argument("--batch-team", choices=["auto", "on", "off"], default="auto",
+                    help="several chains per GPU on the stored kernel: teams of workgroups that read G once per "
+                         "leapfrog step (csrc/batchteam.hip.h) / two reads with a second copy of G / the library's choice")
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="independent chains batched on each GPU against ONE copy of G through the "
                          "fp64 MFMA path (1..16); value then counts the steps of all chains")
@@ -484,6 +489,8 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share GPU 0 (rehearsal of the N>1 launch path on a 1-GPU box)")
     args = ap.parse_args()
+    if args.batch_team != "auto":
+        os.environ["GRAVHMC_BATCH_TEAM"] = "1" if args.batch_team == "on" else "0"
 
     if args.hmcsample > 0:
         print(json.dumps({"hmcsample": hmcsample_block(int(os.environ.get("LOCAL_RANK", "0")), args.workload,

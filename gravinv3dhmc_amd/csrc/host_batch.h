@@ -275,7 +275,7 @@ static int bteam_plan(gh_ctx *c)
 {
     gh_ctx::Batch &b = c->bt;
     b.fus_on = false;
-    if (env_int("GRAVHMC_BATCH_TEAM", 1) == 0 || !c->G) return GH_OK;
+    if (!c->G) return GH_OK;
     const int64_t ntiles = (c->M + 15) / 16;
     const int nrb = (int)((c->ld + 63) / 64);
     b.fus_members = (nrb + BT_RC - 1) / BT_RC;
@@ -467,7 +467,14 @@ static int batch_alloc(gh_ctx *c)
         const int64_t npairs = (ntiles + 1) / 2;  // a wave owns two adjacent column tiles
         const int wgs = (int)std::min<int64_t>((npairs + 3) / 4, (int64_t)c->cus * 4);
         b.n_waves = wgs * 4;
-        TRY(bteam_plan(c));
+        // One read of G per step on teams (batch_team_kernel) or two reads with a second, operand-ordered copy of
+        // G: measured equally fast (C2, 16 chains: 12.9 ms per step either way) -- the teams where
+        // HBM has no room for the copy, or on request (GRAVHMC_BATCH_TEAM = 1 / 0).
+        size_t free_b = 0, total_b = 0;
+        const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
+        const bool copy_fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)4 << 30);
+        const int want = env_int("GRAVHMC_BATCH_TEAM", -1);
+        if (want == 1 || (want < 0 && !copy_fits)) TRY(bteam_plan(c));
         if (b.fus_on) {
             b.n_waves = std::max(b.n_waves, (b.fus_members * b.fus_ranges + 3) / 4 * 4);  // rows of pp_part
         }

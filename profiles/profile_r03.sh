@@ -89,6 +89,23 @@ if [ $which = all ] || [ $which = c2 ]; then
     cp $OUT/c2_trace.json $SUM/bench_c2_under_rocprof_trace.json
   fi
 fi
+if [ $which = all ] || [ $which = c2b ]; then
+  # C2 with 16 chains per GPU on the stored kernel: teams reading G once per step, and the two-pass batch
+  A="--workload c2_uniform_100x100x50 --chains-per-gpu 16 --no-cpu-baseline --no-extra --batch-team on"
+  if prof c2b_trace --kernel-trace --stats -- $A --steps 40 --warmup 10 \
+     && prof c2b_sq --pmc $SQ1 --kernel-trace -- $A --steps 10 --warmup 0 \
+     && prof c2b_sq2 --pmc $SQ2 --kernel-trace -- $A --steps 10 --warmup 0 \
+     && prof c2b_fetch --pmc FETCH_SIZE --kernel-trace -- $A --steps 10 --warmup 0; then
+    python3 $REPO/profiles/summarize.py stats $OUT/c2b_trace $SUM/c2_16chains_one_read_kernel_stats.csv
+    python3 $REPO/profiles/summarize.py pmc $SUM/c2_16chains_one_read_pmc_summary.json "rocprofv3 --pmc passes (SQ counters; FETCH_SIZE in its own pass; with --kernel-trace only) of python3 bench.py $A --steps 10 --warmup 0 on MI355X; recipe profiles/profile_r03.sh; per-dispatch averages; SQ cycle counters in quad-cycles summed over the chip; FETCH_SIZE in KB as rocprofv3 reports it" $OUT/c2b_sq $OUT/c2b_sq2 $OUT/c2b_fetch
+    cp $OUT/c2b_trace.json $SUM/bench_c2_16chains_one_read_under_rocprof_trace.json
+  fi
+  A="--workload c2_uniform_100x100x50 --chains-per-gpu 16 --no-cpu-baseline --no-extra --batch-team off"
+  if prof c2b2_trace --kernel-trace --stats -- $A --steps 40 --warmup 10; then
+    python3 $REPO/profiles/summarize.py stats $OUT/c2b2_trace $SUM/c2_16chains_two_passes_kernel_stats.csv
+    cp $OUT/c2b2_trace.json $SUM/bench_c2_16chains_two_passes_under_rocprof_trace.json
+  fi
+fi
 if [ $which = all ] || [ $which = c1 ]; then
   A="--workload c1_uniform_20x30x10 --no-cpu-baseline"
   if prof c1_trace --kernel-trace --stats -- $A --steps 20000 --warmup 2000 \
