@@ -65,6 +65,7 @@ struct BtArgs {
     int n_pp;            // rows of pp_part the host sums
     long long *dbg;      // optional: accumulated phase times (100 MHz ticks) of lane 0 of wave dbg_wave of member dbg_mem, range 0
     int dbg_mem, dbg_wave;
+    int dbg_break;       // timing experiments that BREAK results (GRAVHMC_BT_BREAK): 1 no requests for G inside the loop, 2 forward MFMAs on constants instead of LDS operands, 4 no parking
 };
 
 template <int V> struct BtIC { static constexpr int value = V; };
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
         constexpr int S0 = decltype(SC)::value, SP = (S0 + 2) % 3;
         const bool stg = it < ntl, f1 = it >= 1 && it - 1 < ntl, f2 = it >= 2;
         request(it);
-        if (f1) {
+        if (f1 && !(f.dbg_break & 4)) {
             double *buf = smem + (size_t)((it - 1) & 1) * BT_BUF + lo * BT_S + 2 * k;
 #pragma unroll
             for (int i = 0; i < BT_PPW; ++i)
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
         }
         // ---- adjoint MFMAs on the registers of tile it: this member's part of S (one accumulator per patch:
         // consecutive MFMAs are independent)
-        const bool tl = it + 2 < ntl;
+        const bool tl = it + 2 < ntl && !(f.dbg_break & 1);
         if (stg) {
             // (two accumulators: consecutive MFMAs are independent.)  The first wave of every SIMD (four patches):
             // behind every second MFMA one request for the tile two iterations ahead, into the set just parked.
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
                 const double *sa = pbuf + (4 * u + k) * BT_S + lo;
 #pragma unroll
                 for (int i = 0; i < BT_PPW; ++i) {
-                    if (pin[i]) accf[i] = mfma_f64(f2 ? sa[16 * (wave + BT_NW * i)] : 0.0, b, accf[i]);
+                    if (pin[i]) accf[i] = mfma_f64((f2 && !(f.dbg_break & 2)) ? sa[16 * (wave + BT_NW * i)] : 1.0, b, accf[i]);
                     const int n = u * BT_PPW + i;
                     if ((n & 1) && (n >> 1) < 2 * (BT_PPW - 1)) {
                         const int piece = n >> 1;                  // 0 .. 5

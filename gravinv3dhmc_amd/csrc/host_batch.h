@@ -418,6 +418,7 @@ static int batch_launch_adjoint(gh_ctx *c, BatchAdjArgs &a, bool fwd_follows)
         }
         f.dbg_mem = env_int("GRAVHMC_BT_DBG_MEM", 0);
         f.dbg_wave = env_int("GRAVHMC_BT_DBG_WAVE", 0);
+        f.dbg_break = env_int("GRAVHMC_BT_BREAK", 0);
         TRY(batch_time_begin(c, timed));
         hipLaunchKernelGGL(batch_team_kernel, dim3((unsigned)b.fus_members, (unsigned)b.fus_ranges), dim3(BT_NW * 64), BT_LDS,
                            c->stream, a, f);

@@ -36,7 +36,7 @@
  *   tuning without any effect on results: GRAVHMC_PF, _NT, _TW, _TW8, _WG_PER_CU, _MIN_COLS,
  *     _INFLIGHT_MB, GRAVHMC_MF_T, _MF_WG_PER_CU, GRAVHMC_MFB_WG_PER_CU, _MFB_RANGES, GRAVHMC_RNG_THREADS;
  *   test hooks (force a time-out path): GRAVHMC_TEAM_TEST_ABORT, GRAVHMC_RESIDENT_TEST_ABORT,
- *     GRAVHMC_MFB_TEST_ABORT, GRAVHMC_BATCH_TEAM_TEST_ABORT, GRAVHMC_MF_TEAM_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, and
+ *     GRAVHMC_MFB_TEST_ABORT, GRAVHMC_BATCH_TEAM_TEST_ABORT, GRAVHMC_MF_TEAM_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, GRAVHMC_BT_BREAK, and
  *     GRAVHMC_RESIDENT_TIMING (per-phase clocks, results intact).
  * (Python side: GRAVHMC_HOST_RNG=numpy draws with np.random itself -- same stream; GRAVHMC_LIB = path
  * of the shared library.)
