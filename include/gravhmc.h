@@ -37,7 +37,8 @@
  *     _INFLIGHT_MB, GRAVHMC_MF_T, _MF_WG_PER_CU, GRAVHMC_MFB_WG_PER_CU, _MFB_RANGES, GRAVHMC_RNG_THREADS;
  *   test hooks (force a time-out path): GRAVHMC_TEAM_TEST_ABORT, GRAVHMC_RESIDENT_TEST_ABORT,
  *     GRAVHMC_MFB_TEST_ABORT, GRAVHMC_BATCH_TEAM_TEST_ABORT, GRAVHMC_MF_TEAM_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, GRAVHMC_BT_BREAK, and
- *     GRAVHMC_RESIDENT_TIMING (per-phase clocks, results intact).
+ *     GRAVHMC_RESIDENT_TIMING, GRAVHMC_MFB_TIMING (+ GRAVHMC_BT_DBG_MEM / _WAVE: whose), GRAVHMC_LONSYM_TIMING
+ *     (per-phase clocks, results intact).
  * (Python side: GRAVHMC_HOST_RNG=numpy draws with np.random itself -- same stream; GRAVHMC_LIB = path
  * of the shared library.)
  */
