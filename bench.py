@@ -295,6 +295,8 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
 #: (same script, its own workload) and summarised under `extra`, so one driver record carries them
 EXTRA_RUNS = [
     ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
+    ("c1_uniform_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--steps", "4000",
+                              "--warmup", "400"]),
     ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                               "--warmup", "20"]),
     ("c2_uniform_16_chains_one_read_of_G", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
@@ -576,7 +578,7 @@ def main():
         def run_rounds(total_steps, first):
             """Every chain runs total_steps leapfrog steps in trajectories of L (the last one
             shorter), through the sampler's path (HMCSampleBatch): gh_batch_run in carry-over mode,
-            four trajectories per chain offered per call -- a finishing chain's last sweep takes the
+            up to eight trajectories per chain offered per call -- a finishing chain's last sweep takes the
             first step of the next one it has been offered -- further rounds drawn meanwhile."""
             plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
             queue = [[] for _ in range(CPG)]           # per chain: (n, p0, u) not started yet
@@ -590,11 +592,13 @@ def main():
                         queue[k].append((plan[drawn], p0s[k], us[k]))
                     drawn += 1
 
-            for _ in range(4):
+            # (trajectories offered per chain and call: the sampler's rule, inversion/hmc.py HMCSampleBatch)
+            Tmax = int(max(2, min(8, (256 << 20) // (8 * M * CPG))))
+            for _ in range(Tmax):
                 draw_into_queue()
             nacc, done = 0, [0] * CPG
             while min(done) < len(plan):
-                T = min(4, min(len(q) for q in queue))
+                T = min(Tmax, min(len(q) for q in queue))
                 if T == 0:                             # nothing left to offer: finish what is in flight
                     acc, _, _, ns, nd = eng.batch_run([[] for _ in range(CPG)], dt, np.zeros((CPG, 0)),
                                                       np.zeros((CPG, 0)), carry=True)
@@ -602,7 +606,7 @@ def main():
                     fut = pool.submit(eng.batch_run, [[tr[1] for tr in q[:T]] for q in queue], dt,
                                       [[tr[0] for tr in q[:T]] for q in queue],
                                       [[tr[2] for tr in q[:T]] for q in queue], False, True)
-                    while min(len(q) for q in queue) < 8 and drawn < len(plan):
+                    while min(len(q) for q in queue) < 2 * Tmax and drawn < len(plan):
                         draw_into_queue()
                     acc, _, _, ns, nd = fut.result()
                 for k in range(CPG):
@@ -611,11 +615,11 @@ def main():
                     nacc += int(acc[k, :int(nd[k])].sum())
             return nacc, len(plan)
 
-        # a sampler in steady state has its next rounds drawn while the GPU was busy: the first four
+        # a sampler in steady state has its next rounds drawn while the GPU was busy: the first offer
         # are drawn before the clock starts, the rest overlaps as usual
         if args.warmup > 0:
             run_rounds(args.warmup, [draw_round(L)])
-        first = [draw_round(L) for _ in range(4)]
+        first = [draw_round(L) for _ in range(int(max(2, min(8, (256 << 20) // (8 * M * CPG)))))]
         eng.synchronize()
         barrier()
         eng.profile_enable(True)
