@@ -299,8 +299,8 @@ EXTRA_RUNS = [
                               "--warmup", "400"]),
     ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                               "--warmup", "20"]),
-    ("c2_uniform_16_chains_one_read_of_G", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
-                                            "--warmup", "20", "--batch-team", "on"]),
+    ("c2_uniform_16_chains_two_reads_of_G", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
+                                             "--warmup", "20", "--batch-team", "off"]),
     ("c3_segment_wavelet3d_tv", ["--workload", "c3_segment_wavelet3d_tv", "--steps", "20000", "--warmup", "2000"]),
     ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
                                          "--warmup", "10"]),

@@ -269,6 +269,29 @@ static int mfb_plan(gh_ctx *c)
     return GH_OK;
 }
 
+// The adjoint GEMM of the two-pass batch wants G in MFMA operand order; 288 GB of HBM usually has room for the
+// second copy (C2: 40 GB + 40 GB).  Without it the kernel reads the column-major matrix.
+static int batch_relayout(gh_ctx *c)
+{
+    gh_ctx::Batch &b = c->bt;
+    if (c->mf || b.Gb || !c->G || !env_int("GRAVHMC_BATCH_RELAYOUT", 1)) return GH_OK;
+    const int64_t ntiles = (c->M + 15) / 16;
+    size_t free_b = 0, total_b = 0;
+    const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)2 << 30)) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, need_b) == hipSuccess) {
+            c->allocs.push_back(ptr);
+            b.Gb = static_cast<double *>(ptr);
+            batch_relayout_kernel<<<dim3(1 << 16), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, (int)(c->ld / 16), ntiles, b.Gb);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return GH_OK;
+}
+
 // Stored kernel: teams of workgroups that read G once per step (batch_team_kernel).  Needs every workgroup
 // resident (one per CU) and 8 .. 32 members (3137 .. 14336 rows); otherwise the two-pass kernels stay.
 static int bteam_plan(gh_ctx *c)
@@ -468,14 +491,11 @@ static int batch_alloc(gh_ctx *c)
         const int64_t npairs = (ntiles + 1) / 2;  // a wave owns two adjacent column tiles
         const int wgs = (int)std::min<int64_t>((npairs + 3) / 4, (int64_t)c->cus * 4);
         b.n_waves = wgs * 4;
-        // One read of G per step on teams (batch_team_kernel) or two reads with a second, operand-ordered copy of
-        // G: measured equally fast (C2, 16 chains: 12.9 ms per step either way) -- the teams where
-        // HBM has no room for the copy, or on request (GRAVHMC_BATCH_TEAM = 1 / 0).
-        size_t free_b = 0, total_b = 0;
-        const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
-        const bool copy_fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)4 << 30);
-        const int want = env_int("GRAVHMC_BATCH_TEAM", -1);
-        if (want == 1 || (want < 0 && !copy_fits)) TRY(bteam_plan(c));
+        // One read of G per step on teams (batch_team_kernel) where the problem fits them, else -- or with
+        // GRAVHMC_BATCH_TEAM=0 -- two reads and a second, operand-ordered copy of G.  Measured at C2 with 16
+        // chains on three boxes: 1 173 / 1 200 / 1 232 chain-steps/s on the teams against 1 191 / 1 184 / 1 203,
+        // with 40 GB of HBM instead of 80.
+        if (env_int("GRAVHMC_BATCH_TEAM", 1) != 0) TRY(bteam_plan(c));
         if (b.fus_on) {
             b.n_waves = std::max(b.n_waves, (b.fus_members * b.fus_ranges + 3) / 4 * 4);  // rows of pp_part
         }
@@ -487,26 +507,8 @@ static int batch_alloc(gh_ctx *c)
     b.n_pp0 = (int)std::min<int64_t>(512, (c->M + 15) / 16);
     TRY(dalloc(c, &b.pp0_part, (size_t)b.n_pp0 * CB));
     HIPCHK(c, hipHostMalloc((void **)&b.h, sizeof(double) * (size_t)(CB * 4 + (b.n_waves + 2 * b.n_pp0) * CB)));
-    // the adjoint GEMM wants G in MFMA operand order; 288 GB of HBM usually has room for the
-    // second copy (C2: 40 GB + 40 GB).  Without it the kernel reads the column-major matrix.
-    // (not with the team pass: it reads the column-major matrix once per step and needs no second copy; if
-    // it ever gives up, the two-pass adjoint reads the column-major matrix as well)
-    if (!c->mf && !b.fus_on && env_int("GRAVHMC_BATCH_RELAYOUT", 1)) {
-        size_t free_b = 0, total_b = 0;
-        const size_t need_b = sizeof(double) * (size_t)ntiles * 16 * (size_t)c->ld;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need_b + ((size_t)2 << 30)) {
-            void *ptr = nullptr;
-            if (hipMalloc(&ptr, need_b) == hipSuccess) {
-                c->allocs.push_back(ptr);
-                b.Gb = static_cast<double *>(ptr);
-                batch_relayout_kernel<<<dim3(1 << 16), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, (int)(c->ld / 16),
-                                                                                  ntiles, b.Gb);
-                HIPCHK(c, hipGetLastError());
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-    }
+    // (the two-pass batch's second copy of G: not with the team pass -- if that ever gives up, the copy is made then)
+    if (!b.fus_on) TRY(batch_relayout(c));
     TRY(dalloc(c, &c->tmpM, (size_t)c->M));
     TRY(dalloc(c, &c->low, (size_t)c->M));
     TRY(dalloc(c, &c->high, (size_t)c->M));
@@ -553,6 +555,7 @@ static int mfb_fused_failed(gh_ctx *c, bool *failed)
     b.fus_aborts += 1;
     b.fus_fwd_of = nullptr;
     *failed = true;
+    TRY(batch_relayout(c));  // (stored kernel: the two-pass adjoint's copy of G, not made while the teams ran)
     return GH_OK;
 }
 

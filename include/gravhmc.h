@@ -28,8 +28,8 @@
  *     GRAVHMC_MF_PIPE=0 / GRAVHMC_MF_NEAR=0 (matrix-free: two-pass form / plain build / subdivision
  *     inside the pass instead of the near-field table), GRAVHMC_MFB_FUSED=0 (matrix-free batch: two
  *     passes instead of teams), GRAVHMC_MFB_RU=0 (no one-height specialisation), GRAVHMC_BATCH_SPEC=0,
- *     GRAVHMC_BATCH_RELAYOUT=0, GRAVHMC_BATCH_TEAM=1 / 0 (stored-kernel batch: teams reading G once per step /
- *     two reads with a second copy of G; default: the teams only where HBM has no room for the copy),
+ *     GRAVHMC_BATCH_RELAYOUT=0, GRAVHMC_BATCH_TEAM=0 (stored-kernel batch: two reads of G per step with a second
+ *     copy of G instead of teams reading it once),
  *     GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
  *   arithmetic of an entry (within the path's stated 1e-10, ~1e-14 measured): GRAVHMC_MF_EXACT -- the
  *     DEFAULT of gh_set_matrix_free_exact only; that call overrides it;
