@@ -212,8 +212,15 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
         const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
         return (double *)(((unsigned long long)hi32 << 32) | lo32);
     };
-    double *const Xo = uniform_ptr(a.X_out), *const Po = uniform_ptr(a.P_out), *const Go = uniform_ptr(a.G_out);
-    const double dt = a.dt;
+    // (...and kept in vector registers behind an opaque barrier: as scalar values the compiler re-reads them from
+    // the kernel-argument segment inside the loop when scalar registers run short -- a memory round trip in front
+    // of every update)
+    double *Xo = uniform_ptr(a.X_out), *Po = uniform_ptr(a.P_out), *Go = uniform_ptr(a.G_out);
+    double dt = a.dt;
+    unsigned tag0 = f.tag0;
+    const double *greg_p = a.GREG, *pn_p = a.Pn;
+    asm volatile("" : "+v"(Xo), "+v"(Po), "+v"(Go), "+v"(dt), "+v"(tag0));
+    const bool has_greg = greg_p != nullptr, has_pn = pn_p != nullptr;
     d4 accf[BT_PPW];
 #pragma unroll
     for (int i = 0; i < BT_PPW; ++i) accf[i] = d4{0.0, 0.0, 0.0, 0.0};
@@ -238,7 +245,6 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
         unsigned spins = 0;
         long long tstart = 0;
         while (!ld_gran(g, tag, val)) {
-            if (clk) tph_s[7] += 1;  // (polls of the clocked lane)
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0) {
                 const long long now = wall_clock64();
@@ -262,18 +268,31 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
     // in flight where its register is preset).
     u64 ga = 0, gb = 0, xa = 0, xb = 0;
     double unv = 0.0;  // lane q < 6 of a pair's lanes: the q-th operand of the pair's update (x, p, greg, pn, high, low)
+    // (what a lane's addresses do not share with the iteration, formed once: pointers taken from the kernel
+    // arguments inside the loop are scalar loads from the argument segment -- a memory round trip each)
+    const u64 *const gp_lane = gpt + (size_t)gmc * 512 + 2 * gvc;   // + slot * BT_MAXMEM * 512
+    const u64 *const gx_lane = gxt + 2 * tid;                        // + slot * 512
+    // the operand this lane fetches for its pair: base (at cell 0), stride per cell
+    const double *un_base;
+    int un_cell_stride;
+    {
+        const int c16 = gvc & 15;
+        const double *xin = a.X_in + c16, *pin_ = a.P_in + c16;
+        un_base = gm == 0 ? xin : gm == 1 ? pin_ : gm == 2 ? (a.GREG ? a.GREG + c16 : xin)
+                : gm == 3 ? (a.Pn ? a.Pn + c16 : xin) : gm == 4 ? a.high : a.low;
+        un_cell_stride = gm < 4 ? CB : 1;
+    }
+    const int64_t Mcells = a.M;
     auto request = [&](int itn) {
         const bool f1n = itn >= 1 && itn - 1 < ntl, f2n = itn >= 2 && itn <= ntl + 1;
         if (f1n && gwave) {
             const int64_t uj = (t0 + itn - 1) * 16 + (gvc >> 4);   // the pair's cell
-            const int64_t ujc = uj < a.M ? uj : 0;
-            bt_ld_gran_asm(gran_p_of(itn - 1, gmc) + 2 * gvc, ga, gb);
-            const int64_t idx = ujc * CB + (gvc & 15);
-            const double *src = gm == 0 ? a.X_in + idx : gm == 1 ? a.P_in + idx : gm == 2 ? (a.GREG ? a.GREG + idx : a.X_in + idx)
-                              : gm == 3 ? (a.Pn ? a.Pn + idx : a.X_in + idx) : gm == 4 ? a.high + ujc : a.low + ujc;
+            const int64_t ujc = uj < Mcells ? uj : 0;
+            bt_ld_gran_asm(gp_lane + (size_t)((itn - 1) & (BT_RING - 1)) * (BT_MAXMEM * 512), ga, gb);
+            const double *src = un_base + ujc * un_cell_stride;
             asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(unv) : "v"(src));
         }
-        if (f2n && xwave) bt_ld_gran_asm(gran_x_of(itn - 2) + 2 * tid, xa, xb);
+        if (f2n && xwave) bt_ld_gran_asm(gx_lane + (size_t)((itn - 2) & (BT_RING - 1)) * 512, xa, xb);
     };
     // One iteration; SC: the register set of tile it (it % 3).  false: the team gave up.
     //   small requests | park tile it - 1 in LDS | adjoint MFMAs of tile it | exchange: new positions of tile
@@ -285,6 +304,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
         constexpr int S0 = decltype(SC)::value, SP = (S0 + 2) % 3;
         const bool stg = it < ntl, f1 = it >= 1 && it - 1 < ntl, f2 = it >= 2;
         request(it);
+
         if (f1 && !(f.dbg_break & 4)) {
             double *buf = smem + (size_t)((it - 1) & 1) * BT_BUF + lo * BT_S + 2 * k;
 #pragma unroll
@@ -294,6 +314,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
                     *reinterpret_cast<d2 *>(buf + 16 * (wave + BT_NW * i) + 8) = ts[SP][i][1];
                 }
         }
+        mark(0);
         // ---- adjoint MFMAs on the registers of tile it: this member's part of S (one accumulator per patch:
         // consecutive MFMAs are independent)
         const bool tl = it + 2 < ntl && !(f.dbg_break & 1);
@@ -322,10 +343,11 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
                         }
                         __builtin_amdgcn_sched_barrier(0);  // (keep the order: the scheduler strings one accumulator's MFMAs together)
                     }
+            mark(1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[wave * 256 + q * 64 + lane] = acc0[q] + acc1[q];
         }
-        mark(0);
+
         // ---- exchange.  Everything but this iteration's requests for G has arrived -- said explicitly, before
         // anything is looked at or stored (a store's acknowledgement counts like a load): the tile requested an
         // iteration ago, which the next iteration multiplies, and the small loads issued at the start.
@@ -333,18 +355,16 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
             bt_wait_but(2 * BT_PPW);   // (the eight requests of a moment ago)
         else
             bt_wait_all();
-        mark(1);
         bool ok = true;
         if (f2 && xwave) {
             double val = 0.0;
-            ok = settle(gran_x_of(it - 2) + 2 * tid, xa, xb, f.tag0 + (unsigned)it - 1u, val);
+            ok = settle(gran_x_of(it - 2) + 2 * tid, xa, xb, tag0 + (unsigned)it - 1u, val);
             xs_s[tid] = val;
         }
-        mark(2);
         if (!ok) abort_s = 1;
-        mark(4);
+        mark(2);
         bt_lds_barrier();
-        mark(5);
+        mark(3);
         if (abort_s) return false;
         if (stg && xwave && xlive) {
             // pair tid = (column tid >> 4, chain tid & 15); acc[q] of lane (lo, k) is column k + 4 q, chain lo
@@ -353,8 +373,9 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
             double sp = 0.0;
 #pragma unroll
             for (int w = 0; w < BT_NW; ++w) sp += red[w * 256 + ridx];
-            st_gran(gran_p_of(it, mem) + 2 * tid, f.tag0 + (unsigned)it + 1u, sp);
+            st_gran(gran_p_of(it, mem) + 2 * tid, tag0 + (unsigned)it + 1u, sp);
         }
+        mark(4);
         // ---- this member's pairs of tile it - 1: sums over the team, updates, new positions.  BEHIND the barrier:
         // what the barrier waits for is the waves' accumulators and the positions in LDS -- with the sums in front
         // of it, a round of the team (publish, become visible, load, update) sets the pace of the iterations.
@@ -362,7 +383,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
         double val = 0.0;
         double uo[6];
         if (f1 && gwave) {
-            if (gask) ok2 = settle(gran_p_of(it - 1, gmc) + 2 * gvc, ga, gb, f.tag0 + (unsigned)it, val);
+            if (gask) ok2 = settle(gran_p_of(it - 1, gmc) + 2 * gvc, ga, gb, tag0 + (unsigned)it, val);
             const int pair0 = lane & (wide ? 32 : 48);   // first lane of this lane's pair
 #pragma unroll
             for (int q = 0; q < 6; ++q) uo[q] = __shfl(unv, pair0 + q, WAVE);
@@ -379,7 +400,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
                     const int64_t idx = uj * CB + c;
                     const int ph = (int)chs[0][c];
                     const double cu = chs[1][c], cp = chs[2][c];
-                    const double gr = 2.0 * tot + (a.GREG ? uo[2] : 0.0);
+                    const double gr = 2.0 * tot + (has_greg ? uo[2] : 0.0);
                     double xo = uo[0], po = uo[1];
                     if (ph == PH_GOUT) {
                         Go[idx] = gr;
@@ -388,7 +409,7 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
                             if (ph == PH_PFIN_SPEC) {
                                 const double pf = po - cp * gr;
                                 pp += pf * pf;
-                                po = a.Pn ? uo[3] : 0.0;
+                                po = has_pn ? uo[3] : 0.0;
                             }
                             double pj = po - cu * gr;
                             double xj = xo + dt * pj;
@@ -411,11 +432,11 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
                     }
                     xn = xo;
                 }
-                st_gran(gran_x_of(it - 1) + 2 * gv, f.tag0 + (unsigned)it, xn);
+                st_gran(gran_x_of(it - 1) + 2 * gv, tag0 + (unsigned)it, xn);
             }
         }
         if (!ok2) abort_s = 1;   // (seen behind the next barrier)
-        mark(3);
+        mark(5);
         // ---- forward MFMAs on the tile parked an iteration ago; the second wave of every SIMD requests its six
         // pieces of the tile two iterations ahead between them (they have the rest of this iteration and the
         // next one's adjoint MFMAs to arrive: the next exchange waits for everything)
@@ -440,8 +461,9 @@ __global__ void __launch_bounds__(BT_NW * 64) batch_team_kernel(BatchAdjArgs a, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        bt_lds_barrier();  // (tile it - 1 is parked into the buffer this forward read ... two iterations from now; red, xs_s free)
         mark(6);
+        bt_lds_barrier();  // (tile it - 1 is parked into the buffer this forward read ... two iterations from now; red, xs_s free)
+        mark(7);
         return true;
     };
     bool alive = true;

@@ -40,5 +40,5 @@ for rnd in range(3):
     print("round", rnd, "%.1f ms = %.2f ms per step" % (dt * 1e3, dt * 1e3 / (L + 1)), fs)
     dv, prev = v - prev, v
     ntile = (M + 15) // 16 / max(1, fs["ranges"]) * (L + 1)
-    names = ["req+park+adjoint+tile requests", "explicit wait", "settle xs", "publish+sums+updates", "-", "B1 wait", "forward+B3", "POLLS(count x100)"]
+    names = ["requests+park", "adjoint MFMAs+tile requests (issue)", "red+wait+settle xs", "B1 wait", "publish parts", "sums+updates", "forward MFMAs (+tile requests)", "B3 wait"]
     print({n: round(x / ntile, 3) for n, x in zip(names, dv)}, "us per tile; sum", round(dv.sum() / ntile, 2))
