@@ -493,7 +493,7 @@ static int batch_alloc(gh_ctx *c)
         b.n_waves = wgs * 4;
         // One read of G per step on teams (batch_team_kernel) where the problem fits them, else -- or with
         // GRAVHMC_BATCH_TEAM=0 -- two reads and a second, operand-ordered copy of G.  Measured at C2 with 16
-        // chains on three boxes: 1 173 / 1 200 / 1 232 chain-steps/s on the teams against 1 191 / 1 184 / 1 203,
+        // chains on three boxes: 1 300 ... 1 360 chain-steps/s on the teams against 1 176 ... 1 195 (same box: +10 %),
         // with 40 GB of HBM instead of 80.
         if (env_int("GRAVHMC_BATCH_TEAM", 1) != 0) TRY(bteam_plan(c));
         if (b.fus_on) {
