@@ -394,7 +394,8 @@ def hmcsample_block(device, workload, nsamples=60):
         el, nacc, ntraj, prof = run_single_chain(eng, M, 0.001, dt, 12, steps, 24, 100)
         out["run_chain_steps_per_s"] = steps / el
         out["sampler_vs_run_chain"] = out["binary_sink"]["leapfrog_steps_per_s"] / out["run_chain_steps_per_s"]
-        out["text_sink_cost_s_per_sample"] = (out["text_sink"]["seconds"] - out["binary_sink"]["seconds"]) / nsamples
+        # (the difference of two 4.7 s runs is within their noise at C2: never reported below zero)
+        out["text_sink_cost_s_per_sample"] = max(0.0, out["text_sink"]["seconds"] - out["binary_sink"]["seconds"]) / nsamples
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     eng.close()
@@ -429,6 +430,8 @@ def c1_block(device, want_cpu):
                      if cstat["resident_evaluations"] else "sweep_kernel per launch",
            "us_per_evaluation_in_kernel": prof["sweep_ms"] * 1e3 / max(1, prof["sweeps"]),
            "reference_formulation_equiv_GBps": 2 * N * M * 8 * steps / elapsed / 1e9}
+    if cstat["resident_evaluations"]:
+        out["roofline"] = resident_roofline(N, M, 1, prof, ntraj, cstat)
     if want_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(mesh, xp, yp, zp, dobs, target_s=6.0, max_cells=M)
@@ -438,19 +441,99 @@ def c1_block(device, want_cpu):
     return out
 
 
+#: aggregate LDS read bandwidth of the chip (MI355X_MICROARCH.md, LDS: "~150 TB/s for ds_read_b64/b128" with
+#: every CU streaming) and the fp64 matrix peak (dense, 78.6 TFLOP/s)
+LDS_PEAK_GBPS = 150000.0
+FP64_MATRIX_PEAK_TFLOPS = 78.6
+
+
+def resident_roofline(N, M, chains, prof, ntraj, cstat):
+    """The roofline block of a run that stayed on the chip (G resident in LDS and registers: no HBM traffic
+    to price).  One chain: both products of an evaluation read the resident operator once -- 2 N M 8 bytes
+    out of LDS / registers -- against the chip's aggregate LDS bandwidth; the floor that actually binds is
+    the exchange (three dependent hops between workgroups per evaluation, ~1 us each).  Several chains in
+    lock-step (resident_batch_kernel): the products are 16-wide fp64 MFMA GEMMs, 4 N M 16 flop per lock-step
+    of the batch, against the fp64 matrix peak."""
+    evals = max(1, prof["sweeps"])
+    us = prof["sweep_ms"] * 1e3 / evals
+    lockstep = cstat.get("resident_batch_launches", 0) > 0
+    if lockstep:
+        flop = 4.0 * N * M * 16
+        ach = flop / (us * 1e-6) / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "kernel": "resident_batch_kernel (%d chains in lock-step: G in LDS / registers, both products of all "
+                          "chains as v_mfma_f64_16x16x4, one three-hop exchange of N x %d doubles per lock-step; %d "
+                          "trajectories in %d launches)" % (chains, chains, ntraj, cstat["resident_batch_launches"]),
+                "launches": cstat["resident_batch_launches"], "avg_ms": None, "lock_steps": prof["sweeps"],
+                "us_per_lock_step": us, "flop_model": "4 N M 16 flop per lock-step (two 16-wide fp64 GEMMs; the MFMA "
+                                                      "computes 16 chains whatever the batch holds)",
+                "exchange_floor": "three dependent hops between workgroups per lock-step"}
+    byts = 2.0 * N * M * 8
+    ach = byts / (us * 1e-6) / 1e9
+    return {"bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBPS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBPS,
+            "traffic": None,
+            "kernel": "resident_chain_kernel (%s%d trajectories in %d launches)"
+                      % ("%d chains taking turns, " % chains if chains > 1 else "", ntraj, cstat["resident_launches"]),
+            "launches": cstat["resident_launches"], "avg_ms": None, "evaluations": prof["sweeps"],
+            "us_per_evaluation": us,
+            "algorithmic_bytes_per_evaluation": byts,
+            "byte_model": "2 N M 8: forward and adjoint each read the resident operator once (LDS; the adjoint's "
+                          "copy sits in registers where it fits), priced against the aggregate LDS bandwidth",
+            "exchange_floor": "three dependent hops between workgroups per evaluation (~3 of the us above): the "
+                              "bound that binds; the LDS fraction says how far the local work is from mattering"}
+
+
+def config_values(line):
+    """Every BASELINE configuration's number in one flat map of the line itself (the driver's record keeps the
+    top-level keys of the line but not the content of `extra`): tag -> [value in leapfrog (chain-)steps/s,
+    roofline fraction of that run's dominant kernel]."""
+    def pair(d):
+        if not isinstance(d, dict) or "value" not in d:
+            return None
+        r = d.get("roofline") or {}
+        f = r.get("frac", d.get("frac"))
+        return [round(float(d["value"]), 1), None if f is None else round(float(f), 4)]
+    out = {"c2": pair(line)}
+    short = {"c1_uniform_20x30x10": "c1", "c1_uniform_16_chains": "c1_16", "c2_uniform_16_chains": "c2_16",
+             "c2_uniform_16_chains_two_reads_of_G": "c2_16_2rd", "c3_segment_wavelet3d_tv": "c3",
+             "c3_segment_wavelet3d_tv_16_chains": "c3_16",
+             "c4_global_tesseroid_matrix_free": "c4_mf", "c4_global_tesseroid_dense": "c4_dense",
+             "c4_global_tesseroid_shift_invariant": "c4_si",
+             "c4_global_tesseroid_shift_invariant_8_chains": "c4_si8",
+             "c4_global_tesseroid_matrix_free_8_chains": "c4_mf8", "c5_share_of_one_gpu_of_8": "c5_share",
+             "c5_share_row_blocks": "c5_rows"}
+    for tag, d in (line.get("extra") or {}).items():
+        if tag in short:
+            out[short[tag]] = pair(d)
+    hs = (line.get("extra") or {}).get("c2_hmcsample")
+    if isinstance(hs, dict) and "binary_sink" in hs:
+        out["c2_sampler"] = [round(hs["binary_sink"]["leapfrog_steps_per_s"], 1),
+                             round(hs.get("sampler_vs_run_chain", 0.0), 3)]
+    return out
+
+
 def launch_ranks(n, argv):
     """One process per GPU through torch.distributed.run on 127.0.0.1 (a free port), the command the
     driver itself uses for N > 1; stdout / stderr pass through, the return code is the launcher's."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.run(cmd, env=env).returncode
+    rc = 1
+    for attempt in range(2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        t0 = time.time()
+        rc = subprocess.run(cmd, env=env).returncode
+        # Between close() and the launcher's bind another process may take the port: a launch that dies
+        # within seconds (the rendezvous could not bind) is tried once more on a fresh port.
+        if rc == 0 or time.time() - t0 > 20.0:
+            break
+    return rc
 
 
 def main():
@@ -690,18 +773,8 @@ def main():
         if cstat.get("resident_evaluations", 0) > 0:
             # G never left the chip: the figure below is what the reference formulation would have
             # had to read per second, not HBM traffic
-            line["roofline"].update({
-                "bound": "on-chip latency (G resident in LDS, N-vector exchanges between workgroups)",
-                "achieved": None, "frac": None, "traffic": None, "peak": None,
-                "kernel": "resident_chain_kernel (%d trajectories in %d launches)"
-                          % (ntraj, cstat["resident_launches"]),
-                "launches": cstat["resident_launches"], "avg_ms": None,
-                "evaluations": prof["sweeps"], "us_per_evaluation": sweep_ms * 1e3,
-                "lds_equiv_GBps": achieved})
+            line["roofline"].update(resident_roofline(N, M, CPG, prof, ntraj, cstat))
         if CPG > 1 and cstat.get("resident_evaluations", 0) > 0:
-            # small problem: the chains took turns inside the resident chain kernel
-            line["roofline"]["kernel"] = ("resident_chain_kernel (%d chains x %d trajectories in %d launches)"
-                                          % (CPG, ntraj, cstat["resident_launches"]))
             line["roofline"]["reference_formulation_equiv_GBps"] = \
                 2 * bytes_sweep * CPG * args.steps / elapsed / 1e9
         elif CPG > 1:
@@ -814,6 +887,7 @@ def main():
                     line["extra"][tag] = extra_run(dev, xargs)
                 except Exception as e:
                     line["extra"][tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["config_values"] = config_values(line)
         print(json.dumps(line))
     ranks.close()
 

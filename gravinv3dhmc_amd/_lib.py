@@ -116,6 +116,16 @@ def load():
             raise GravHmcError(
                 "libgravhmc.so is not built (%s). Run `python -m gravinv3dhmc_amd.build` "
                 "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+        if "GRAVHMC_BATCH_TEAM" not in os.environ and not os.environ.get("GRAVHMC_LIB"):
+            # batch_team_kernel covers its inline-assembly loads with hand-counted waits: the library keeps
+            # that form only when the code THIS build's compiler generated for it passed the scan
+            # (isa_check.py, run by build()); otherwise the two-pass batch kernels take its place
+            from . import isa_check
+            if not isa_check.team_form_cleared():
+                import sys
+                sys.stderr.write("gravinv3dhmc_amd: the generated code of batch_team_kernel was not cleared by the "
+                                 "build's scan (%s): using the two-pass batch kernels\n" % isa_check.STAMP)
+                os.environ["GRAVHMC_BATCH_TEAM"] = "0"
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)

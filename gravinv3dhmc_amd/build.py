@@ -27,7 +27,10 @@ def stale():
 
 def build(force=False, verbose=False):
     """Build the shared library if it is missing or older than its sources."""
+    from . import isa_check
     if not force and not stale():
+        if not os.path.exists(isa_check.STAMP):
+            isa_check.stamp(hipcc())
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-value", SRC, "-o", LIB + ".tmp", "-ldl"]
@@ -35,6 +38,11 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    # the generated code of the kernel with hand-counted waits, checked with the compiler that built it
+    bad = isa_check.stamp(hipcc())
+    if bad:
+        print("gravinv3dhmc_amd.build: batch_team_kernel's generated code has findings (the team form of the "
+              "stored-kernel batch stays off):\n  " + "\n  ".join(bad[:5]))
     return LIB
 
 

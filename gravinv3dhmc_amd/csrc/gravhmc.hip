@@ -161,6 +161,10 @@ int gh_set_matrix_free(gh_ctx *c, int enable)
 {
     if (!c) return GH_ERR_ARG;
     if (c->have_G || c->slab) return fail(c, GH_ERR_ARG, "gh_set_matrix_free: call before gh_build_G");
+    if (c->ls) {
+        c->mf_before_ls = enable != 0;  // (takes effect when the shift-invariant store is switched off)
+        return GH_OK;
+    }
     c->mf = enable != 0;  // (the passes are partitioned in gh_build_G, once the cell kind is known)
     return GH_OK;
 }
@@ -169,11 +173,15 @@ int gh_set_shift_invariant(gh_ctx *c, int enable)
 {
     if (!c) return GH_ERR_ARG;
     if (c->have_G || c->slab) return fail(c, GH_ERR_ARG, "gh_set_shift_invariant: call before gh_build_G");
+    // (the store is a flavour of the matrix-free mode -- G is never stored -- so enabling it sets c->mf;
+    // disabling it puts c->mf back to what gh_set_matrix_free last asked for)
+    if (c->ls) c->mf = c->mf_before_ls;
     delete c->ls;
     c->ls = nullptr;
     if (enable) {
         c->ls = new LonSymHost();
-        c->mf = true;  // a flavour of the matrix-free mode: G is never stored
+        c->mf_before_ls = c->mf;
+        c->mf = true;
     }
     return GH_OK;
 }

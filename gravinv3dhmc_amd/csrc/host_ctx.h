@@ -32,6 +32,7 @@ struct gh_ctx {
     double *G = nullptr;
     int64_t warn_cells = 0, leaves = 0;
     bool mf = false;          // matrix-free: entries are re-evaluated, G is never stored
+    bool mf_before_ls = false;  // what gh_set_matrix_free asked for, while the shift-invariant store holds mf
     bool dense_ok = true;     // N fits the register-resident sweep (<= 16384 rows)
     double *tconv = nullptr;  // tesseroid obs converted to (lon rad, sin lat, cos lat, radius)
     int64_t mf_cells_per_chunk = 0;

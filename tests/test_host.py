@@ -277,68 +277,37 @@ def test_bench_gpus_n_starts_its_ranks_as_children(monkeypatch):
 
 def test_team_batch_kernel_code_never_touches_a_register_with_a_load_in_flight(tmp_path):
     """csrc/batchteam.hip.h issues its loads as inline assembly -- invisible to the compiler's wait-count
-    bookkeeping -- and covers them with explicit s_waitcnt vmcnt(n).  The compiler therefore believes
-    the destination registers are valid at once: a copy, a spill or any other use of one of them
-    between the load and the wait that covers it would silently read stale bits.  Check the generated
-    gfx950 code: inside the loop, the registers of the G tiles are touched by nothing but the loads
-    themselves, the MFMAs and the 16-byte LDS stores that park them, and no instruction touches the
-    destination of a small exchange load before the next vmcnt wait; and nothing is spilled."""
+    bookkeeping -- and covers them with explicit s_waitcnt vmcnt(n).  gravinv3dhmc_amd/isa_check.py scans the
+    generated gfx950 code for what that makes possible (a spill or any other touch of a register with a load
+    in flight, prologue requests included; an exchange load's destination used before a wait that covers
+    it); build() runs the same scan with the compiler that built the library and the library drops the team
+    form when it does not pass."""
     import shutil
-    import subprocess
+    from gravinv3dhmc_amd import isa_check
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    csrc = os.path.join(ROOT, "gravinv3dhmc_amd", "csrc")
-    tu = tmp_path / "bt.hip"
-    tu.write_text("".join('#include "%s"\n' % os.path.join(csrc, h) for h in
-                          ("kernels.hip.h", "batch.hip.h", "resident.hip.h", "mfbatch.hip.h", "batchteam.hip.h")))
-    asm = tmp_path / "bt.s"
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", str(tu),
-                          "-o", str(asm), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rep = out.stderr[out.stderr.index("batch_team_kernel"):]
-    rep = rep[:rep.index("LDS Size")]
-    assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", rep) and re.search(r"VGPRs Spill: 0\b", rep), rep
-    text = asm.read_text()
-    body = text[text.index("_ZN3ghk17batch_team_kernelENS_12BatchAdjArgsENS_6BtArgsE:"):]
-    body = body[:body.index(".Lfunc_end")]
-    lines = body.split("\n")
-    start = next(i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l)
-    # (the loop's barriers are bt_lds_barrier()'s inline assembly; the code behind the loop has __syncthreads())
-    last_barrier = max(i for i, l in enumerate(lines)
-                       if re.match(r"\s*s_barrier", l) and any("#ASMSTART" in x for x in lines[i - 3:i]))
+    assert isa_check.check(hipcc, tmp_path) == []
+    # the scan's own logic on a synthetic body: a wait that leaves the load in flight does not cover it
+    rep = "batch_team_kernel ScratchSize [bytes/lane]: 0 VGPRs Spill: 0 LDS Size"
+    tiles = "".join("\tglobal_load_dwordx4 v[%d:%d], v[2:3], off nt\n" % (100 + 4 * k, 103 + 4 * k) for k in range(24))
 
-    def regs(code):
-        found = set()
-        for m in re.finditer(r"v\[(\d+):(\d+)\]", code):
-            found.update(range(int(m.group(1)), int(m.group(2)) + 1))
-        for m in re.finditer(r"\bv(\d+)\b", code):
-            found.add(int(m.group(1)))
-        return found
+    def body(wait):
+        return (isa_check.SYMBOL + ":\n\tv_mov_b32 v1, 0\n; Loop Header: Depth=1\n" + tiles +
+                "\tglobal_load_dwordx2 v[10:11], v[2:3], off sc1\n\tglobal_load_dwordx2 v[12:13], v[2:3], off sc1\n" +
+                "\ts_waitcnt vmcnt(%d)\n\tv_add_f64 v[20:21], v[10:11], v[10:11]\n" % wait +
+                "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\t;;#ASMEND\n.Lfunc_end0:\n")
+    assert isa_check.scan(body(1), rep) == []
+    assert len(isa_check.scan(body(2), rep)) == 1      # vmcnt(2) leaves both 8-byte loads in flight
+    spilled = rep.replace("Spill: 0", "Spill: 3")
+    assert any("spills" in b for b in isa_check.scan(body(1), spilled))
 
-    code = [(i, l.split(";")[0].strip()) for i, l in enumerate(lines)]
-    code = [(i, c) for i, c in code if c and not c.startswith(".")]
-    tile = set()
-    for i, c in code:
-        m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off.* nt", c)
-        if m and i >= start:
-            tile.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    assert len(tile) == 96, len(tile)                     # three sets of 4 patches x 2 x 16 bytes
-    allowed = ("v_mfma_f64_16x16x4_f64", "global_load_dwordx4", "ds_write_b128")
-    stray = [(i, c) for i, c in code if start <= i <= last_barrier and regs(c) & tile and c.split()[0] not in allowed]
-    assert not stray, stray[:5]
-    # the small loads of the exchange (8-byte loads): nothing reads or writes their destination before a wait
-    pending, early = {}, []
-    for i, c in code:
-        if i < start or i > last_barrier:
-            continue
-        op = c.split()[0]
-        if op == "s_waitcnt" and "vmcnt" in c:
-            pending = {}
-            continue
-        m = re.match(r"global_load_dwordx2 v\[(\d+):(\d+)\]", c)
-        if not m and regs(c) & set(pending):
-            early.append((i, c))
-        if m:
-            pending.update({r: i for r in range(int(m.group(1)), int(m.group(2)) + 1)})
-    assert not early, early[:5]
+
+def test_build_stamps_the_isa_scan_and_the_library_honours_it(tmp_path, monkeypatch):
+    from gravinv3dhmc_amd import isa_check
+    monkeypatch.setattr(isa_check, "STAMP", str(tmp_path / "stamp.json"))
+    assert not isa_check.team_form_cleared()           # no stamp: not cleared
+    (tmp_path / "stamp.json").write_text('{"hipcc": "x", "findings": ["line 3 touches ..."]}')
+    assert not isa_check.team_form_cleared()
+    (tmp_path / "stamp.json").write_text('{"hipcc": "x", "findings": []}')
+    assert isa_check.team_form_cleared()
