@@ -50,9 +50,8 @@ CASES = {
 def test_matrix_free_batch_matches_single_chain_matrix_free(G, monkeypatch, case, form):
     """form: the fused team pass (one evaluation per entry and step), the two-pass kernels
     (GRAVHMC_MFB_FUSED=0), or a team pass that gives up (test hook: its members wait for a part that never
-    comes) -- the round is then repeated with the two-pass kernels: same chains."""
-    if form.startswith("teams_time_out") and case != "tess_fast_leaf_near_table":
-        pytest.skip("the time-out paths are exercised once each (2 s)")
+    comes) -- the round is then repeated with the two-pass kernels: same chains.  The two time-out paths
+    (lock-step round, desynchronised run) are exercised for every one of the four kernel kinds (2 s each)."""
     problem, exact, near, reg = CASES[case]
     monkeypatch.setenv("GRAVHMC_MF_EXACT", exact)
     monkeypatch.setenv("GRAVHMC_MF_NEAR", near)

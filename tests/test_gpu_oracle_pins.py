@@ -1,0 +1,271 @@
+"""Round-3 kernel families pinned to the ORACLE (oracle/gravhmc_oracle.c: the C restatement of
+gravmag/_prism.pyx:265-290, gravmag/_tesseroid_numba.py:32-157,207-222, inversion/potential.py:688-845 and
+inversion/hmc.py:85-177), not to other HIP kernels: the matrix-free batch passes (`mfb_*`, both forms), the
+single chain on teams (`mf_team_kernel`), the shift-invariant store (`lonsym_sweep_kernel`), the stored-kernel
+batch on teams (`batch_team_kernel`) at the C2 shape, and oracle columns of G at the full sizes of C2 and of
+the C5 share."""
+import numpy as np
+import pytest
+
+from helpers import relmax
+from test_gpu_mfbatch import CASES, _global_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(built_lib):
+    import gravinv3dhmc_amd as g
+    return g
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _oracle_kernel(orc, obs, bounds, kind):
+    if kind == 1:
+        return orc.tess_gz_kernel(obs[0], obs[1], obs[2], bounds)
+    return orc.prism_gz_kernel(obs[0], obs[1], obs[2], bounds)
+
+
+@pytest.mark.parametrize("form", ["teams_one_evaluation", "two_passes"])
+@pytest.mark.parametrize("case", list(CASES))
+def test_matrix_free_batch_and_team_chain_against_oracle_trajectories(G, orc, monkeypatch, case, form):
+    """Every chain of a matrix-free batch (mfb_fused_kernel on teams / mfb_adjoint + mfb_forward) and the
+    single matrix-free chain (mf_team_kernel where the near-field list exists, mf_fused_kernel otherwise)
+    against `oracle.Problem.leapfrog` on the oracle's own kernel matrix: potentials and Hamiltonians
+    <= 1e-10, positions <= 1e-10, identical Metropolis decisions."""
+    problem, exact, near, reg = CASES[case]
+    monkeypatch.setenv("GRAVHMC_MF_EXACT", exact)
+    monkeypatch.setenv("GRAVHMC_MF_NEAR", near)
+    monkeypatch.setenv("GRAVHMC_MFB_FUSED", "0" if form == "two_passes" else "1")
+    obs, bounds, kind, shape = problem(G)
+    N, M = obs[0].size, bounds.shape[0]
+    rng = np.random.default_rng(7)
+    rho = rng.uniform(0.0, 0.5, M)
+    K = _oracle_kernel(orc, obs, bounds, kind)
+    Aw, wm = orc.col_weight(K)
+    d_true = K @ rho
+    dobs = d_true + 0.02 * np.abs(d_true).max() * rng.normal(size=N)
+    alpha, beta = 0.05, 0.01
+    P = orc.Problem(Aw, dobs, 0.001 * wm, reg, alpha, beta, wm=wm, shape=shape)
+
+    def make():
+        e = G.Engine(N, M)
+        e.set_matrix_free(True)
+        e.set_obs(*obs)
+        e.set_cells(bounds, kind, 1.6)
+        e.build_G()
+        w = e.weight(0.5)
+        assert relmax(w, wm) < 1e-11
+        e.set_data(dobs)
+        e.set_reg(reg, alpha, beta, shape, 0.001 * wm)
+        return e
+
+    eb, es = make(), make()
+    assert relmax(eb.forward(wm * rho), d_true) < 1e-10      # (the engine is weighted: Aw (wm rho) = K rho)
+    C, dt, sig = 4, 0.005, 0.002
+    low, high = 0.0 * wm, 0.8 * wm
+    x0s = np.stack([(0.001 + 0.05 * c) * wm for c in range(C)])
+    eb.batch_init(x0s, low, high)
+    es.chain_init(x0s[1], low, high)
+    xo = [x0s[c].copy() for c in range(C)]
+    worst_b = worst_s = 0.0
+    n_acc = n_rej = 0
+    for it in range(3):
+        Ls = rng.integers(1, 6, size=C)
+        p0s = rng.normal(size=(C, M)) * sig
+        us = rng.uniform(size=C) * (0.05 if it == 1 else 1.0)
+        acc, out5 = eb.batch_trajectory(p0s, dt, Ls, us)
+        a1, o1 = es.chain_trajectory(p0s[1], dt, int(Ls[1]), float(us[1]))
+        for c in range(C):
+            xo[c], ao, oo, _ = P.leapfrog(xo[c], p0s[c], dt, int(Ls[c]), low, high, float(us[c]))
+            assert bool(acc[c]) == ao, (case, form, it, c, out5[c], oo)
+            worst_b = max(worst_b, relmax(out5[c], oo), relmax(eb.batch_get_x(c), xo[c]))
+            n_acc += ao
+            n_rej += not ao
+            if c == 1:      # the single chain runs the oracle's chain 1
+                assert bool(a1) == ao, (case, form, it, o1, oo)
+                worst_s = max(worst_s, relmax(o1, oo), relmax(es.chain_get_x(), xo[1]))
+    fs, ts = eb.batch_fused_stats(), es.matrix_free_team_stats()
+    print("matrix-free [%s, %s] vs ORACLE trajectories: batch of %d chains worst %.2e (accepted %d, rejected %d), "
+          "single chain %.2e; batch team form %r, single-chain team form %r"
+          % (case, form, C, worst_b, n_acc, n_rej, worst_s, fs, ts))
+    assert worst_b < 1e-10 and worst_s < 1e-10 and n_acc > 0
+    if form == "teams_one_evaluation":
+        assert fs["launches"] > 0 and fs["timeouts"] == 0
+    if kind == 1 and near == "1":
+        assert ts["launches"] > 0 and ts["timeouts"] == 0      # mf_team_kernel ran the single chain
+    for e in (eb, es):
+        e.close()
+
+
+@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size"])
+def test_shift_invariant_store_against_the_oracle(G, orc, case):
+    """lonsym_sweep_kernel's table against the oracle's tesseroid kernel itself.  coarse: the whole dense K
+    (forward, weights, adjoint, potential + gradient for a cell-local and a stencil regulariser, a chain
+    against oracle.Problem.leapfrog).  C4 at full size: 68 oracle rows x 72000 cells (64 random
+    observations, two polar rows, two more) against K[i, :] = wm * (Aw^T e_i) read through the table."""
+    rng = np.random.default_rng(13)
+    if case == "coarse_odd_sizes":
+        mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
+        h[::3] = 45000.0
+        perm = rng.permutation(lon.size)
+        lon, lat, h = lon[perm], lat[perm], h[perm]
+    else:
+        mesh, lon, lat, h = _global_model(G, 3.0, 3.0, -300000, 5000.0)
+    N, M = lon.size, mesh.size
+    bounds = mesh.cell_bounds()
+    t = G.Engine(N, M)
+    t.set_shift_invariant(True)
+    t.set_obs(lon, lat, h)
+    t.set_cells(bounds, 1, 1.6)
+    t.build_G()
+    assert t.shift_invariant_info()["n_lon"] == mesh.shape[2]
+    if case == "c4_full_size":
+        wt = t.weight(0.5)
+        rows = np.r_[rng.choice(N, 64, replace=False), [0, 60, 60 * 61 + 30, N - 1]]
+        Ko = orc.tess_gz_kernel(lon[rows], lat[rows], h[rows], bounds)
+        e_row = 0.0
+        for q, i in enumerate(rows):
+            ei = np.zeros(N)
+            ei[i] = 1.0
+            Ki = t.adjoint(ei) * wt
+            e_row = max(e_row, float(np.abs(Ki - Ko[q]).max() / np.abs(Ko[q]).max()))
+            assert (np.abs(Ki - Ko[q]) / np.maximum(np.abs(Ko[q]), 1e-300)).max() < 1e-9, i
+        cols = np.r_[0, 1, 119, 36000, 71880, 71999]
+        Kc = orc.tess_gz_kernel(lon, lat, h, bounds[cols])
+        e_w = relmax(wt[cols], np.sqrt((Kc ** 2).sum(0)))
+        print("shift-invariant store at C4 size vs the ORACLE: 68 rows x 72000 cells %.2e of a row's largest entry, "
+              "6 column norms %.2e" % (e_row, e_w))
+        assert e_row < 1e-10 and e_w < 1e-11
+        t.close()
+        return
+    K = orc.tess_gz_kernel(lon, lat, h, bounds)
+    rho = rng.uniform(0.0, 0.5, M)
+    d_true = K @ rho
+    e_fwd = relmax(t.forward(rho), d_true)
+    Aw, wm = orc.col_weight(K)
+    e_w = relmax(t.weight(0.5), wm)
+    r = rng.normal(size=N)
+    e_adj = relmax(t.adjoint(r), Aw.T @ r)
+    dobs = d_true + 0.02 * np.abs(d_true).max() * rng.normal(size=N)
+    x = rng.uniform(0, 0.8, M) * wm
+    worst = 0.0
+    for reg in ("Damping", "TV"):
+        t.set_data(dobs)
+        t.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wm)
+        P = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.05, 0.01, wm=wm, shape=mesh.shape)
+        a, b = t.misfit_and_grad(x), P.misfit_and_grad(x)
+        worst = max(worst, abs(a[0] - b[0]) / abs(b[0]), relmax(a[1], b[1]), relmax(a[2], b[2]))
+    print("shift-invariant store [coarse] vs the ORACLE's dense kernel: forward %.2e weights %.2e adjoint %.2e "
+          "potential/gradient %.2e" % (e_fwd, e_w, e_adj, worst))
+    assert e_fwd < 1e-10 and e_w < 1e-11 and e_adj < 1e-10 and worst < 1e-10
+    low, high = 0.0 * wm, 0.8 * wm
+    t.chain_init(0.001 * wm, low, high)
+    xo = 0.001 * wm
+    for _ in range(5):
+        L, p0, u = int(rng.integers(2, 7)), rng.normal(size=M) * 0.001, float(rng.uniform())
+        a1, o1 = t.chain_trajectory(p0, 0.005, L, u)
+        xo, ao, oo, _ = P.leapfrog(xo, p0, 0.005, L, low, high, u)
+        assert bool(a1) == ao and relmax(o1, oo) < 1e-10
+    assert relmax(t.chain_get_x(), xo) < 1e-10
+    t.close()
+
+
+def _prism_columns_against_oracle(eng, orc, xp, yp, zp, bounds, cols, tag):
+    """forward(e_j) of the unweighted stored kernel = column j of G, against the oracle's entries; then
+    the weights against the oracle's column norms."""
+    Ko = orc.prism_gz_kernel(xp, yp, zp, bounds[cols])
+    worst = 0.0
+    for q, j in enumerate(cols):
+        e = np.zeros(eng.M)
+        e[j] = 1.0
+        worst = max(worst, relmax(eng.forward(e), Ko[:, q]))
+    wm = eng.weight(0.5)
+    e_w = relmax(wm[cols], np.sqrt((Ko ** 2).sum(0)))
+    print("%s: %d columns of G vs the ORACLE (%d x %d entries): %.2e; their norms %.2e"
+          % (tag, len(cols), Ko.shape[0], len(cols), worst, e_w))
+    assert worst < 1e-10 and e_w < 1e-11
+    return wm
+
+
+def test_c2_full_size_oracle_columns_and_team_batch_of_16_chains(G, orc):
+    """BASELINE configs[1] at full size (10^4 x 5*10^5, 40 GB): eight columns of G (first, middle, last cells)
+    against the oracle's prism entries -- the headline workload touches oracle values -- and
+    batch_team_kernel at exactly that shape (teams of 23 workgroups x 11 ranges of column tiles, 16 chains:
+    the library's default there): chains 3 and 12 re-run on the single-chain sweep path, identical
+    decisions, <= 1e-10."""
+    nx = ny = 100
+    nz = 50
+    mesh = G.mesher.PrismMesh((0, 100.0 * nx, 0, 100.0 * ny, 0, 100.0 * nz), (100, 100, 100))
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 100.0 * ny, ny), np.linspace(0, 100.0 * nx, nx))]
+    zp = np.zeros_like(xp)
+    N, M = xp.size, mesh.size
+    bounds = mesh.cell_bounds()
+    rng = np.random.default_rng(21)
+
+    def make():
+        e = G.Engine(N, M)
+        e.set_obs(xp, yp, zp)
+        e.set_cells(bounds, 0)
+        e.build_G()
+        return e
+
+    eb = make()
+    cols = np.r_[0, 1, 2, M // 2, M // 2 + 1, M - 3, M - 2, M - 1]
+    wm = _prism_columns_against_oracle(eb, orc, xp, yp, zp, bounds, cols, "C2 full size")
+    es = make()
+    assert np.array_equal(es.weight(0.5), wm)
+    rho = np.zeros(mesh.shape)
+    rho[10:25, 40:60, 40:60] = 1.0
+    d_true = eb.forward(wm * rho.ravel())
+    dobs = d_true + 0.02 * np.abs(d_true).max() * rng.normal(size=N)
+    for e in (eb, es):
+        e.set_data(dobs)
+        e.set_reg("Damping", 1.0, 0.01, mesh.shape, 0.001 * wm)
+    C, dt = 16, 0.002
+    low, high = 0.0 * wm, 1.0 * wm
+    x0s = np.stack([(0.001 + 0.002 * c) * wm for c in range(C)])
+    eb.batch_init(x0s, low, high)
+    rounds = []
+    for it in range(2):
+        Ls = rng.integers(2, 5, size=C)
+        p0s = rng.normal(size=(C, M)) * 0.001
+        us = rng.uniform(size=C)
+        acc, out5 = eb.batch_trajectory(p0s, dt, Ls, us)
+        rounds.append((Ls, p0s[[3, 12]].copy(), us, np.array(acc), np.array(out5)))
+    fs = eb.batch_fused_stats()
+    assert fs["members"] == 23 and fs["ranges"] == 11 and fs["launches"] > 0 and fs["timeouts"] == 0, fs
+    worst = 0.0
+    for q, c in enumerate((3, 12)):
+        es.chain_init(x0s[c], low, high)
+        for (Ls, p2, us, acc, out5) in rounds:
+            a1, o1 = es.chain_trajectory(p2[q], dt, int(Ls[c]), float(us[c]))
+            assert bool(a1) == bool(acc[c]), (c, o1, out5[c])
+            worst = max(worst, relmax(out5[c], o1))
+        worst = max(worst, relmax(eb.batch_get_x(c), es.chain_get_x()))
+    print("C2 full size, batch_team_kernel (23 members x 11 ranges, 16 chains) vs the single-chain sweep: %.2e" % worst)
+    assert worst < 1e-10
+    for e in (eb, es):
+        e.close()
+
+
+def test_c5_share_full_size_oracle_columns(G, orc):
+    """The 96 GB share one of 8 GPUs holds of BASELINE configs[4] (200 x 200 observations, the first 3*10^5
+    cells of the 200 x 200 x 60 mesh; teamsweep_kernel territory): eight columns of G against the oracle."""
+    mesh = G.mesher.PrismMesh((0, 20000.0, 0, 20000.0, 0, 6000.0), (100, 100, 100))
+    yp, xp = [a.ravel() for a in np.meshgrid(np.linspace(0, 20000.0, 200), np.linspace(0, 20000.0, 200))]
+    zp = np.zeros_like(xp)
+    bounds = mesh.cell_bounds()[: mesh.size // 8]
+    N, M = xp.size, bounds.shape[0]
+    eng = G.Engine(N, M)
+    eng.set_obs(xp, yp, zp)
+    eng.set_cells(bounds, 0)
+    eng.build_G()
+    cols = np.r_[0, 1, 2, M // 2, M // 2 + 1, M - 3, M - 2, M - 1]
+    _prism_columns_against_oracle(eng, orc, xp, yp, zp, bounds, cols, "C5 share (4*10^4 x 3*10^5)")
+    eng.close()
