@@ -178,18 +178,26 @@ def test_shift_invariant_store_against_the_oracle(G, orc, case):
 
 def _prism_columns_against_oracle(eng, orc, xp, yp, zp, bounds, cols, tag):
     """forward(e_j) of the unweighted stored kernel = column j of G, against the oracle's entries; then
-    the weights against the oracle's column norms."""
+    the weights against the oracle's column norms.  Two measures: the entry error against the largest
+    entry of the kernel (what a forward product G rho sees; bound 1e-12) and against the largest entry of
+    the column itself (bound 1e-8: a cell 50 cell sizes deep seen from 10 km away is the sum of 24 terms of
+    magnitude x log(y + r) ~ 1e5 that cancel to ~1e-2 before the factor G * SI2MGAL, _prism.pyx:265-290 --
+    the one- or two-ulp differences between the device's log / atan2 and glibc's are amplified by that
+    cancellation; the reference's own entries carry the same absolute uncertainty)."""
     Ko = orc.prism_gz_kernel(xp, yp, zp, bounds[cols])
-    worst = 0.0
+    kmax = float(np.abs(Ko).max())
+    worst_abs = worst_col = 0.0
     for q, j in enumerate(cols):
         e = np.zeros(eng.M)
         e[j] = 1.0
-        worst = max(worst, relmax(eng.forward(e), Ko[:, q]))
+        d = eng.forward(e)
+        worst_abs = max(worst_abs, float(np.abs(d - Ko[:, q]).max()) / kmax)
+        worst_col = max(worst_col, relmax(d, Ko[:, q]))
     wm = eng.weight(0.5)
     e_w = relmax(wm[cols], np.sqrt((Ko ** 2).sum(0)))
-    print("%s: %d columns of G vs the ORACLE (%d x %d entries): %.2e; their norms %.2e"
-          % (tag, len(cols), Ko.shape[0], len(cols), worst, e_w))
-    assert worst < 1e-10 and e_w < 1e-11
+    print("%s: %d columns of G vs the ORACLE (%d x %d entries): %.2e of the largest entry, %.2e of the own "
+          "column's largest entry; their norms %.2e" % (tag, len(cols), Ko.shape[0], len(cols), worst_abs, worst_col, e_w))
+    assert worst_abs < 1e-12 and worst_col < 1e-8 and e_w < 1e-11
     return wm
 
 
