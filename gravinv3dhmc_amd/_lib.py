@@ -36,6 +36,8 @@ PROTOTYPES = {
                                        C.POINTER(C.c_int)]),
     "gh_matrix_free_team_stats": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_int)]),
+    "gh_batch_resident_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "gh_set_shift_invariant": (C.c_int, [_ctx, C.c_int]),
     "gh_shift_invariant_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_int64)]),

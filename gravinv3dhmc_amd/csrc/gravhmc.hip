@@ -4,6 +4,7 @@
 #include "kernels.hip.h"
 #include "batch.hip.h"
 #include "resident.hip.h"
+#include "resbatch.hip.h"
 #include "teamsweep.hip.h"
 #include "mfbatch.hip.h"
 #include "batchteam.hip.h"
@@ -34,6 +35,7 @@ using namespace ghk;
 #include "host_wavelet.h"
 #include "host_eval.h"
 #include "host_resident.h"
+#include "host_resbatch.h"
 #include "host_batch.h"
 
 // ------------------------------------------------------------------------- C-ABI
@@ -1189,6 +1191,8 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
         r.b_state = false;
         c->bt.C = C;
         c->bt.ready = true;
+        // two or more chains: all of them in lock-step, one exchange per step of the whole batch (resbatch.hip.h)
+        (void)resbatch_plan(c, C);
         return GH_OK;
     }
     return batch_init_mfma(c, C, x0s);
@@ -1210,6 +1214,16 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
     for (int k = 0; k < C; ++k) {
         if (L[k] < 1) return fail(c, GH_ERR_ARG, "gh_batch_trajectory: L must be >= 1");
         Lmax = std::max(Lmax, L[k]);
+    }
+    if (c->rs.b_on && c->rs.ls.on) {
+        for (int k = 0; k < C; ++k)
+            if (c->rs.ls.active[k])
+                return fail(c, GH_ERR_ARG, "gh_batch_trajectory: gh_batch_run left trajectories in flight (drain them with T = 0)");
+        int rc = resbatch_state(c);
+        if (rc == GH_OK) rc = resbatch_launch(c, 1, L, nullptr, p0s, us, dt, false, accepted, out5s, nullptr, nullptr, nullptr);
+        if (rc == GH_OK) return GH_OK;
+        if (rc != GH_RESIDENT_ABORTED) return rc;
+        c->rs.ls.on = false;  // (nothing was in flight: the chains take turns from here on)
     }
     if (c->rs.b_on) {
         gh_ctx::Resident &r = c->rs;
@@ -1349,20 +1363,48 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
     const size_t M = (size_t)c->M;
     for (int k = 0; k < C * T; ++k)
         if (L[k] < 1 || !p0s[k]) return fail(c, GH_ERR_ARG, "gh_batch_run: L must be >= 1 and every momentum row given");
-    if (c->rs.b_on && T == 0) {
+    // trajectories the lock-step kernel had in flight when it gave up: replayed in front of the new lists
+    std::vector<int> pre_ch, pre_L;
+    std::vector<double> pre_us, pre_p0;
+    if (c->rs.b_on && c->rs.ls.on) {
+        gh_ctx::Resident::LockStep &b = c->rs.ls;
+        bool any_active = false;
+        for (int ch = 0; ch < C; ++ch) any_active = any_active || b.active[ch];
+        if (!n_done && any_active)
+            return fail(c, GH_ERR_ARG, "gh_batch_run: trajectories in flight from a carry-over call (drain them with T = 0)");
+        if (T == 0 && !any_active) {
+            for (int ch = 0; ch < C; ++ch) n_started[ch] = n_done[ch] = 0;
+            return GH_OK;
+        }
+        int rc = resbatch_state(c);
+        if (rc == GH_OK)
+            rc = resbatch_launch(c, T, L, p0s, nullptr, us, dt, n_done != nullptr, accepted, out5s, x_out, n_started, n_done);
+        if (rc == GH_OK) return GH_OK;
+        if (rc != GH_RESIDENT_ABORTED) return rc;
+        b.on = false;
+        TRY(resbatch_inflight(c, pre_ch, pre_L, pre_us, pre_p0));
+    }
+    if (c->rs.b_on && T == 0 && pre_ch.empty()) {
         for (int ch = 0; ch < C; ++ch) n_started[ch] = n_done[ch] = 0;  // nothing is ever left in flight there
         return GH_OK;
     }
     if (c->rs.b_on) {
         // small problem: the chains take turns inside the resident chain kernel, trajectory t of
-        // every chain before trajectory t + 1 of any
+        // every chain before trajectory t + 1 of any (in front of them what the lock-step kernel left in flight)
         gh_ctx::Resident &r = c->rs;
-        const int K = C * T;
-        std::vector<int> chain_of((size_t)K), Lk((size_t)K), acc((size_t)K);
+        const int P = (int)pre_ch.size(), K = P + C * T;
+        std::vector<int> chain_of((size_t)K), Lk((size_t)K), acc((size_t)K), has_pre((size_t)C, 0);
         std::vector<double> pk((size_t)K * M), uk((size_t)K), o5((size_t)K * 5);
+        for (int k = 0; k < P; ++k) {
+            chain_of[k] = pre_ch[k];
+            Lk[k] = pre_L[k];
+            uk[k] = pre_us[k];
+            memcpy(pk.data() + (size_t)k * M, pre_p0.data() + (size_t)k * M, M * sizeof(double));
+            has_pre[(size_t)pre_ch[k]] = 1;
+        }
         for (int t = 0; t < T; ++t)
             for (int ch = 0; ch < C; ++ch) {
-                const int k = t * C + ch, src = ch * T + t;
+                const int k = P + t * C + ch, src = ch * T + t;
                 chain_of[k] = ch;
                 Lk[k] = L[src];
                 uk[k] = us[src];
@@ -1386,20 +1428,25 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
         if (rc == GH_OK) {
             r.b_state = true;
             const int Tout = n_done ? T + 1 : T;
-            for (int t = 0; t < T; ++t)
-                for (int ch = 0; ch < C; ++ch) {
-                    const int k = t * C + ch, dst = ch * Tout + t;
-                    accepted[dst] = acc[k];
-                    memcpy(out5s + (size_t)dst * 5, o5.data() + (size_t)k * 5, 5 * sizeof(double));
-                    if (x_out && acc[k])
-                        HIPCHK(c, hipMemcpyAsync(x_out + (size_t)dst * M, r.xacc + (size_t)k * M, M * sizeof(double),
-                                                 hipMemcpyDeviceToHost, c->stream));
-                }
+            for (int k = 0; k < K; ++k) {
+                const int ch = chain_of[k];
+                const int i = k < P ? 0 : (k - P) / C + has_pre[(size_t)ch];
+                const int dst = ch * Tout + i;
+                accepted[dst] = acc[k];
+                memcpy(out5s + (size_t)dst * 5, o5.data() + (size_t)k * 5, 5 * sizeof(double));
+                if (x_out && acc[k])
+                    HIPCHK(c, hipMemcpyAsync(x_out + (size_t)dst * M, r.xacc + (size_t)k * M, M * sizeof(double),
+                                             hipMemcpyDeviceToHost, c->stream));
+            }
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (int ch = 0; ch < C && n_done; ++ch) n_started[ch] = n_done[ch] = T;
+            for (int ch = 0; ch < C && n_done; ++ch) {
+                n_started[ch] = T;
+                n_done[ch] = T + has_pre[(size_t)ch];
+            }
             return GH_OK;
         }
         if (rc != GH_RESIDENT_ABORTED) return rc;
+        if (P > 0) return fail(c, GH_ERR_HIP, "gh_batch_run: the resident kernels timed out with trajectories in flight");
         std::vector<double> xs((size_t)C * M);
         TRY(d2h(c, xs.data(), r.bx, xs.size()));
         r.b_on = false;
@@ -1745,6 +1792,19 @@ int gh_matrix_free_team_stats(gh_ctx *c, int *members, int *ranges, int64_t *lau
     return GH_OK;
 }
 
+int gh_batch_resident_stats(gh_ctx *c, int64_t *launches, int64_t *lock_steps, int64_t *chain_steps, int64_t *lost_steps,
+                            int *timeouts)
+{
+    if (!c) return GH_ERR_ARG;
+    const gh_ctx::Resident::LockStep &b = c->rs.ls;
+    if (launches) *launches = b.launches;
+    if (lock_steps) *lock_steps = b.lock_steps;
+    if (chain_steps) *chain_steps = b.chain_steps;
+    if (lost_steps) *lost_steps = b.lost;
+    if (timeouts) *timeouts = b.aborts;
+    return GH_OK;
+}
+
 int gh_batch_get_x(gh_ctx *c, int chain, double *x)
 {
     if (!c || !x) return fail(c, GH_ERR_ARG, "gh_batch_get_x: null pointer");
@@ -1774,8 +1834,15 @@ int gh_debug_resident_timing(gh_ctx *c, long long out32[32], int64_t *launches, 
     if (launches) *launches = c->rs.launches;
     if (evals) *evals = c->rs.evals;
     for (int i = 0; i < 32; ++i) out32[i] = 0;
-    if (!c->rs.dbg) return GH_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->rs.ls.dbg && c->rs.ls.launches > 0) {
+        // chains in lock-step (resbatch.hip.h): its clocks, launches and lock-steps
+        if (launches) *launches = c->rs.ls.launches;
+        if (evals) *evals = c->rs.ls.lock_steps;
+        HIPCHK(c, hipMemcpy(out32, c->rs.ls.dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+        return GH_OK;
+    }
+    if (!c->rs.dbg) return GH_OK;
     HIPCHK(c, hipMemcpy(out32, c->rs.dbg, 32 * sizeof(long long), hipMemcpyDeviceToHost));
     return GH_OK;
 }

@@ -256,6 +256,24 @@ struct gh_ctx {
         bool granules_dirty = false;  // an aborted launch left tags behind: clear before the next launch
         long long *dbg = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        // the chains in LOCK-STEP (resbatch.hip.h): planned per gh_batch_init
+        struct LockStep {
+            bool on = false;
+            int ks = 0, nt = 0, C = 0;
+            size_t lds = 0;
+            ghk::u32x4 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr;
+            ghk::u64 *xccg = nullptr;
+            double *xpub = nullptr, *xs = nullptr, *ps = nullptr, *pst = nullptr, *cst = nullptr;
+            double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
+            int *L = nullptr, *accepted = nullptr, *n_io = nullptr;
+            int cap = 0;                 // list elements the device lists hold
+            unsigned tag = 0, ltag = 0;
+            bool dirty = false;          // an aborted launch left tags behind
+            bool active[16] = {};        // chain has a trajectory in flight (carry-over mode)
+            int64_t launches = 0, lock_steps = 0, lost = 0, chain_steps = 0;
+            int aborts = 0;
+            long long *dbg = nullptr;
+        } ls;
     } rs;
     int64_t prof_res_evals = 0;
 

@@ -173,10 +173,12 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
         TRY(dalloc(c, &r.abort_w, 4));
         TRY(dalloc(c, &r.n_run, 4));
         if (env_int("GRAVHMC_RESIDENT_TIMING", 0)) TRY(dalloc(c, &r.dbg, 32));
-        HIPCHK(c, hipEventCreate(&r.ev0));
-        HIPCHK(c, hipEventCreate(&r.ev1));
+        if (!r.ev0) {
+            HIPCHK(c, hipEventCreate(&r.ev0));
+            HIPCHK(c, hipEventCreate(&r.ev1));
+        }
     }
-    if (K > r.Kcap) {
+    if (K > r.Kcap || !r.L) {
         // grown rarely (the host batches a fixed number of trajectories per call); the old blocks
         // stay in the context's allocation list until gh_destroy
         const int cap = std::max(K, 32);
@@ -207,10 +209,13 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
         r.granules_dirty = false;
     }
     HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.p0s, q.p0s, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.us, q.us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(r.L, q.L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    if (q.chain_of)
+    // (K = 0: only the potential and gradient at the chains' current samples are evaluated)
+    if (K > 0) {
+        HIPCHK(c, hipMemcpyAsync(r.p0s, q.p0s, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(r.us, q.us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(r.L, q.L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
+    if (q.chain_of && K > 0)
         HIPCHK(c, hipMemcpyAsync(r.chain, q.chain_of, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
     ResArgs a{};
     a.G = c->G;
@@ -276,8 +281,10 @@ static int resident_launch(gh_ctx *c, const ResLaunch &q, int *accepted, double 
     unsigned h_sync[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(h_sync, r.abort_w, sizeof h_sync, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_run, r.n_run, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(accepted, r.accepted, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out5s, r.out5s, (size_t)K * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (K > 0) {
+        HIPCHK(c, hipMemcpyAsync(accepted, r.accepted, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out5s, r.out5s, (size_t)K * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (h_sync[0] != 0u) {
         // A workgroup waited 2 s for the others: they were not all resident (another process holding

@@ -260,8 +260,10 @@ class Engine(object):
         self._chk(self._lib.gh_chain_resident_stats(self._h, C.byref(la), C.byref(ev)))
         q, tl, to, late = C.c_int(0), C.c_int64(0), C.c_int(0), C.c_int64(0)
         self._chk(self._lib.gh_team_sweep_stats(self._h, C.byref(q), C.byref(tl), C.byref(to), C.byref(late)))
+        rb = self.batch_resident_stats()
         return {"spec_hits": a.value, "spec_misses": b.value,
-                "resident_launches": la.value, "resident_evaluations": ev.value,
+                "resident_launches": la.value, "resident_evaluations": ev.value + rb["lock_steps"],
+                "resident_batch_launches": rb["launches"], "resident_batch_lock_steps": rb["lock_steps"],
                 "team_members": q.value, "team_launches": tl.value, "team_timeouts": to.value,
                 "team_late_parts": late.value}
 
@@ -501,6 +503,15 @@ class Engine(object):
         m, r, l, t = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int(0)
         self._chk(self._lib.gh_batch_fused_stats(self._h, C.byref(m), C.byref(r), C.byref(l), C.byref(t)))
         return {"members": m.value, "ranges": r.value, "launches": l.value, "timeouts": t.value}
+
+    def batch_resident_stats(self):
+        """Chains in lock-step inside the resident batch kernel (csrc/resbatch.hip.h): launches, lock-steps,
+        evaluations of all chains, lock-steps lost to rejected speculative first steps, time-outs."""
+        l, s, cs, lo, t = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        self._chk(self._lib.gh_batch_resident_stats(self._h, C.byref(l), C.byref(s), C.byref(cs), C.byref(lo),
+                                                    C.byref(t)))
+        return {"launches": l.value, "lock_steps": s.value, "chain_steps": cs.value, "lost_steps": lo.value,
+                "timeouts": t.value}
 
     def matrix_free_team_stats(self):
         """Team form of the single-chain matrix-free pass: grid, launches, time-outs."""

@@ -291,6 +291,19 @@ int gh_batch_trajectory(gh_ctx *ctx, const double *p0s, double dt, const int *L,
 int gh_batch_run(gh_ctx *ctx, int T, const int *L, const double *const *p0_rows, const double *us,
                  double dt, int *accepted, double *out5s, double *x_out, int *n_started, int *n_done);
 int gh_batch_get_x(gh_ctx *ctx, int chain, double *x /* M */);
+/* Two or more chains on a problem small enough for the resident chain kernel with every column in LDS
+ * (<= 32 cells per CU, N <= 640: BASELINE configs[0] and [2]) do not take turns: ALL chains advance in
+ * lock-step inside one launch per gh_batch_run / gh_batch_trajectory call (csrc/resbatch.hip.h) -- one
+ * three-hop exchange per step of the whole batch instead of one per chain, both products of all chains
+ * as fp64 MFMA GEMMs (the reference runs its chains as separate MPI ranks: inversion/hmc.py:367-369; per
+ * chain the arithmetic is inversion/hmc.py:85-177 with inversion/potential.py:698,708).  A chain whose
+ * trajectory ended takes the first step of its next one speculatively while its Metropolis sums travel; a
+ * rejected proposal costs that chain one lock-step.  launches, lock-steps and evaluations of all chains
+ * ("chain-steps") so far, lock-steps lost to rejected speculation, timeouts (a launch that gave up waiting
+ * for its workgroups: the chains take turns in the resident chain kernel from then on, trajectories in
+ * flight are replayed there).  GRAVHMC_RESIDENT_BATCH=0 switches the form off. */
+int gh_batch_resident_stats(gh_ctx *ctx, int64_t *launches, int64_t *lock_steps, int64_t *chain_steps,
+                            int64_t *lost_steps, int *timeouts);
 /* Batched chains on a MATRIX-FREE context (gh_set_matrix_free): every entry a pass evaluates serves all
  * chains (example/global/run_main.sh:16 runs its chains as separate ranks, each re-evaluating the whole
  * tesseroid kernel, gravmag/_tesseroid_numba.py:32-71).  Two forms: an adjoint/update pass and a forward

@@ -530,3 +530,6 @@ ORC_API int orc_leapfrog(const orc_problem *P, double *x, const double *p0, doub
 }
 
 ORC_API int orc_sizeof_problem(void) { return (int)sizeof(orc_problem); }
+
+/* test-infrastructure knob: the size of the OpenMP teams (oracle.py passes the cores the cgroup really grants) */
+ORC_API void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
