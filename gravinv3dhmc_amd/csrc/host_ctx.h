@@ -261,8 +261,9 @@ struct gh_ctx {
             bool on = false;
             int ks = 0, nt = 0, C = 0;
             size_t lds = 0;
-            ghk::u32x4 *slabg = nullptr, *xslabg = nullptr, *dclg = nullptr;
-            ghk::u64 *xccg = nullptr;
+            ghk::u32x4 *xslabg = nullptr, *dclg = nullptr;
+            double *slabd = nullptr;
+            ghk::u64 *xccg = nullptr, *flagg = nullptr;
             double *xpub = nullptr, *xs = nullptr, *ps = nullptr, *pst = nullptr, *cst = nullptr;
             double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
             int *L = nullptr, *accepted = nullptr, *n_io = nullptr;

@@ -5,19 +5,21 @@
 typedef void (*resbatch_fn_t)(ResBatchArgs);
 
 template <int KS>
-static resbatch_fn_t resbatch_for_ks(int nt)
+static resbatch_fn_t resbatch_for_ks(int nt, bool greg)
 {
-    return nt <= 1 ? resident_batch_kernel<KS, 1> : resident_batch_kernel<KS, 2>;
+    if (greg) return nt <= 1 ? resident_batch_kernel<KS, 1, true> : resident_batch_kernel<KS, 2, true>;
+    return nt <= 1 ? resident_batch_kernel<KS, 1, false> : resident_batch_kernel<KS, 2, false>;
 }
 
-// ks: k-steps (4 rows) per wave of the adjoint, 32 ks >= ld; compiled for ld <= 640
-static resbatch_fn_t resbatch_for(int ks, int nt)
+// ks: k-steps (4 rows) per wave of the adjoint, 32 ks >= ld; compiled for ld <= 640.  greg: the adjoint's
+// operand in registers (compressed forward: LDS holds another matrix)
+static resbatch_fn_t resbatch_for(int ks, int nt, bool greg)
 {
     switch (ks) {
-    case 5: return resbatch_for_ks<5>(nt);
-    case 10: return resbatch_for_ks<10>(nt);
-    case 15: return resbatch_for_ks<15>(nt);
-    case 20: return resbatch_for_ks<20>(nt);
+    case 5: return resbatch_for_ks<5>(nt, greg);
+    case 10: return resbatch_for_ks<10>(nt, greg);
+    case 15: return resbatch_for_ks<15>(nt, greg);
+    case 20: return resbatch_for_ks<20>(nt, greg);
     }
     return nullptr;
 }
@@ -34,9 +36,9 @@ static bool resbatch_plan(gh_ctx *c, int C)
     b.ks = (int)((c->ld + 159) / 160) * 5;
     b.nt = (r.cpw + 15) / 16;
     b.C = C;
-    b.lds = resbatch_lds_doubles(c->ld, r.cpw, c->have_fix) * sizeof(double);
+    b.lds = resbatch_lds_doubles(c->ld, r.cpw, c->have_fix, c->wv.on) * sizeof(double);
     if (b.lds > (size_t)r.lds_max) return false;
-    resbatch_fn_t f = resbatch_for(b.ks, b.nt);
+    resbatch_fn_t f = resbatch_for(b.ks, b.nt, c->wv.on);
     if (!f) return false;
     int per_cu = 0;
     if (allow_dynamic_lds(reinterpret_cast<const void *>(f), b.lds) != hipSuccess ||
@@ -46,7 +48,8 @@ static bool resbatch_plan(gh_ctx *c, int C)
         return false;
     }
     const size_t M = (size_t)c->M, ldx = (size_t)c->ld + RB_XROWS;
-    if (dalloc(c, &b.slabg, (size_t)(r.nwg + 8) * ldx * 16) != GH_OK || dalloc(c, &b.xslabg, 2 * (size_t)RES_CLUSTERS * ldx * 16) != GH_OK ||
+    if (dalloc(c, &b.slabd, (size_t)(r.nwg + 8) * ldx * 16) != GH_OK || dalloc(c, &b.flagg, (size_t)r.nwg + 8) != GH_OK ||
+        dalloc(c, &b.xslabg, 2 * (size_t)RES_CLUSTERS * ldx * 16) != GH_OK ||
         dalloc(c, &b.dclg, (size_t)RES_CLUSTERS * ldx * 16) != GH_OK || dalloc(c, &b.xccg, (size_t)r.nwg + 8) != GH_OK ||
         dalloc(c, &b.xpub, 2 * 16 * M) != GH_OK || dalloc(c, &b.xs, 16 * M) != GH_OK || dalloc(c, &b.ps, 16 * M) != GH_OK ||
         dalloc(c, &b.pst, 16 * M) != GH_OK || dalloc(c, &b.cst, 16 * RB_CST) != GH_OK || dalloc(c, &b.n_io, 128) != GH_OK ||
@@ -111,7 +114,7 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
     for (int k = 0; k < K; ++k) steps += L[k] + 1;
     steps += 64 * 17;  // (what is in flight; generous)
     if (b.dirty || (uint64_t)b.tag + (uint64_t)steps + 2 > 0xf0000000ull || b.ltag > 0xf0000000u) {
-        HIPCHK(c, hipMemsetAsync(b.slabg, 0, (size_t)(r.nwg + 8) * ldx * 16 * sizeof(ghk::u32x4), c->stream));
+        HIPCHK(c, hipMemsetAsync(b.flagg, 0, ((size_t)r.nwg + 8) * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(b.xslabg, 0, 2 * (size_t)RES_CLUSTERS * ldx * 16 * sizeof(ghk::u32x4), c->stream));
         HIPCHK(c, hipMemsetAsync(b.dclg, 0, (size_t)RES_CLUSTERS * ldx * 16 * sizeof(ghk::u32x4), c->stream));
         HIPCHK(c, hipMemsetAsync(b.xccg, 0, ((size_t)r.nwg + 8) * sizeof(ghk::u64), c->stream));
@@ -170,7 +173,8 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
     a.out5s = b.out5s;
     a.xacc = x_out ? b.xacc : nullptr;
     a.n_io = b.n_io;
-    a.slabg = b.slabg;
+    a.slabd = b.slabd;
+    a.flagg = b.flagg;
     a.xslabg = b.xslabg;
     a.dclg = b.dclg;
     a.xccg = b.xccg;
@@ -179,9 +183,9 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
     a.ltag = b.ltag + 1u;
     a.abort_w = r.abort_w;
     a.dbg = b.dbg;
-    resbatch_fn_t f = resbatch_for(b.ks, b.nt);
+    resbatch_fn_t f = resbatch_for(b.ks, b.nt, c->wv.on);
     // (gh_set_data may have added or removed the fixed part of the data term since the batch was planned)
-    b.lds = resbatch_lds_doubles(c->ld, r.cpw, c->have_fix) * sizeof(double);
+    b.lds = resbatch_lds_doubles(c->ld, r.cpw, c->have_fix, c->wv.on) * sizeof(double);
     if (b.lds > (size_t)r.lds_max) return fail(c, GH_ERR_UNSUPPORTED, "resident batch kernel: the problem no longer fits the LDS");
     HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(f), b.lds));
     if (c->prof) HIPCHK(c, hipEventRecord(r.ev0, c->stream));

@@ -81,7 +81,9 @@ struct ResBatchArgs {
     int *n_io;         // [c] list elements started, [16 + c] results, [32] lock-steps, [48 + c] lock-steps chain c
                        // lost to a rejected speculation, [64 + c] trajectory in flight, [80 + c] evaluations of chain c
     // exchange buffers (tags continue across launches)
-    u32x4 *slabg;      // nwg x ldx x C granule pairs: forward partials + scalar rows
+    double *slabd;     // nwg x ldx x 16 forward partials + scalar rows of the workgroups (chain k4 + 4 q of a row at
+                       // position 4 k4 + q), published by ONE flag word per workgroup and lock-step
+    u64 *flagg;        // nwg: tag of the lock-step whose partial is complete in slabd
     u32x4 *xslabg;     // 2 x 8 x ldx x C cluster sums, double-buffered by lock-step parity
     u32x4 *dclg;       // 8 x ldx x C finished sums, one copy per cluster
     u64 *xccg;         // nwg {launch tag, XCC id}
@@ -91,16 +93,22 @@ struct ResBatchArgs {
     long long *dbg;    // optional 2 x 16 phase clocks
 };
 
-// LDS column stride: the two column groups a ds_read_b64 half-wave covers must fall into different halves
-// of the 64 banks -> stride = 16 (mod 32) doubles
-__host__ __device__ inline int rb_ldp(int ld) { return (ld % 32 == 16) ? ld : ld + 16; }
+// LDS column stride.  Adjoint operand in registers (GREG): the two column groups a ds_read_b64 half-wave of
+// the forward covers must fall into different halves of the 64 banks -> stride = 16 (mod 32) doubles.
+// (one copy of G serving both products: stride = 18 (mod 32) -- the adjoint's operand reads, 16 columns x 2 rows
+// per half-wave, are then conflict-free, the forward's, 2 columns x 16 rows, 2-way at most)
+__host__ __device__ inline int rb_ldp(int ld, bool greg)
+{
+    const int want = greg ? 16 : 18;
+    return ld + ((want - ld % 32) + 32) % 32;
+}
 
 // (the waves' partial adjoint products: one slot of 64 doubles per wave and group of 4 columns; the fixed
 // part of the data term only where there is one)
-static inline size_t resbatch_lds_doubles(int64_t ld, int cols_per_wg, bool have_fix)
+static inline size_t resbatch_lds_doubles(int64_t ld, int cols_per_wg, bool have_fix, bool greg)
 {
     const size_t cpw4 = ((size_t)cols_per_wg + 3) & ~(size_t)3;
-    return cpw4 * (size_t)rb_ldp((int)ld) + (size_t)RB_WAVES * (cpw4 / 4) * 64 + cpw4 * 16 + (have_fix ? 2 : 1) * (size_t)ld + 128 +
+    return cpw4 * (size_t)rb_ldp((int)ld, greg) + (size_t)RB_WAVES * (cpw4 / 4) * 64 + cpw4 * 16 + (have_fix ? 2 : 1) * (size_t)ld + 128 +
            128 + 384 + 64 + 2 + 16;
 }
 
@@ -122,6 +130,24 @@ __device__ __forceinline__ void rb_store(__amdgpu_buffer_rsrc_t rs, unsigned off
         __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)off, 0, 0);
     else
         __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)off, 0, 16);  // sc1
+}
+
+// two doubles, 16 bytes, untagged (the forward partials: complete once their workgroup's flag carries the tag)
+__device__ __forceinline__ void rb_store2(__amdgpu_buffer_rsrc_t rs, unsigned off, double x, double y, bool local)
+{
+    const u64 bx = (u64)__double_as_longlong(x), by = (u64)__double_as_longlong(y);
+    const u32x4 w = u32x4{(unsigned)bx, (unsigned)(bx >> 32), (unsigned)by, (unsigned)(by >> 32)};
+    if (local)
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)off, 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)off, 0, 16);  // sc1
+}
+
+__device__ __forceinline__ d2 rb_load2(__amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);  // sc1: L2-served
+    return d2{__longlong_as_double((long long)(((u64)w.y << 32) | (u64)w.x)),
+              __longlong_as_double((long long)(((u64)w.w << 32) | (u64)w.z))};
 }
 
 // NB granule pairs per lane (offsets off[u], valid while u < n), all requested together with sc1 loads
@@ -169,8 +195,11 @@ __device__ __forceinline__ bool rb_poll(unsigned *abort_w, __amdgpu_buffer_rsrc_
 }
 
 // KS: k-steps (4 rows each) a wave contracts in the adjoint: 32 KS >= ld.  NT: 16-column tiles of the
-// workgroup's columns (cols_per_wg <= 16 NT).
-template <int KS, int NT>
+// workgroup's columns (cols_per_wg <= 16 NT).  GREG: the adjoint's operand (the wave's rows of the columns of
+// a.G) lives in registers -- needed when the forward operator in LDS is another matrix (compressed forward);
+// otherwise both products read the ONE copy in LDS (80 VGPRs less: no spills; an MFMA of 64 cycles needs 512
+// bytes of it, the LDS delivers 256 per cycle).
+template <int KS, int NT, bool GREG>
 __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -179,7 +208,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
     const int w = blockIdx.x;
     const int ld = (int)a.ld, ldx = ld + RB_XROWS;
     const int cpw = a.cols_per_wg, cpw4 = (cpw + 3) & ~3, KF = cpw4 >> 2;
-    const int ldp = rb_ldp(ld);
+    const int ldp = rb_ldp(ld, GREG);
     const int64_t M = a.M;
     const int64_t j0 = (int64_t)w * cpw;
     const int nc = (int)((M - j0 < cpw) ? (M - j0) : cpw);
@@ -225,14 +254,16 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
     }
     if (tid == 0) *flag_s = 1;
     const int rb0 = wave * 4 * KS;  // first row of the wave's share of the adjoint
-    double gt[NT][KS];
+    double gt[GREG ? NT : 1][GREG ? KS : 1];
+    if (GREG) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int col = 16 * t + lo4, row = rb0 + 4 * s + k4;
-            gt[t][s] = (col < nc && row < ld) ? a.G[(j0 + col) * a.ld + row] : 0.0;
-        }
+            for (int s = 0; s < KS; ++s) {
+                const int col = 16 * t + lo4, row = rb0 + 4 * s + k4;
+                gt[GREG ? t : 0][GREG ? s : 0] = (col < nc && row < ld) ? a.G[(j0 + col) * a.ld + row] : 0.0;
+            }
+    }
 
     // ---- clusters and placement (resident.hip.h)
     const int ncl = nwg < RES_CLUSTERS ? nwg : RES_CLUSTERS;
@@ -266,7 +297,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
     }
 
     const __amdgpu_buffer_rsrc_t rs_slab =
-        __builtin_amdgcn_make_buffer_rsrc(a.slabg, 0, (int)((size_t)(nwg + 8) * ldx * C * 16), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(a.slabd, 0, (int)((size_t)(nwg + 8) * ldx * 16 * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_xs = __builtin_amdgcn_make_buffer_rsrc(a.xslabg, 0, 2 * RES_CLUSTERS * ldx * C * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dcl = __builtin_amdgcn_make_buffer_rsrc(a.dclg, 0, RES_CLUSTERS * ldx * C * 16, 0x00020000);
 
@@ -281,6 +312,8 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
     int mode = IDLE, s_done = 0, Lc = 0, q_next = 0, n_done = 0;
     bool spec = false;
     double uc = 0.0, pp0 = 0.0, udL = 0.0, U0 = 0.0, U1 = 0.0, U2 = 0.0;
+    int Ln = 0;        // length and variate of the next list element (fetched ahead, with its momentum)
+    double un = 0.0;
     double sh_r = 0.0, sh_pp1 = 0.0, sh_pp0 = 0.0;  // this cell's terms of the three sums, for the next exchange
     if (ct < C) {
         U0 = a.u_cur[3 * ct];
@@ -349,7 +382,12 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
             sh_pp0 = p0k * p0k;
         }
     }
-    p0n = list_p0(q_next);
+    auto fetch_next = [&]() {
+        p0n = list_p0(q_next);
+        Ln = (ct < C && q_next < T) ? a.L[ct * T + q_next] : 0;
+        un = (ct < C && q_next < T) ? a.us[ct * T + q_next] : 0.0;
+    };
+    fetch_next();
 
     // the cells' terms of the three sums -> per-wave shares in LDS (summed over the waves by the next forward)
     auto post_shares = [&]() {
@@ -404,26 +442,20 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
                     for (int ks = 0; ks < 8; ++ks)
                         av[ks] = (ks < KF) ? Gs[(size_t)(4 * ks + k4) * ldp + 16 * rt + lo4] : 0.0;
                     __builtin_amdgcn_sched_barrier(0);
+                    // (D'[chain][row] = sum_k X[k][chain] G[row][k]: the lane of row lo4 gets the chains k4 + 4 q,
+                    // four neighbours of the slab's row -> two 16-byte stores)
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks)
-                        if (ks < KF) acc[i] = mfma_f64(av[ks], bx[ks], acc[i]);
+                        if (ks < KF) acc[i] = mfma_f64(bx[ks], av[ks], acc[i]);
                 }
             }
-            if (stencil) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            if (lo4 < C) {
 #pragma unroll
-                for (int i = 0; i < RT; ++i) {
-                    const int rt = wave + RB_WAVES * i;
-                    if (16 * rt < ld) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int row = 16 * rt + k4 + 4 * q;
-                            rb_store(rs_slab, (unsigned)((((size_t)w * ldx + row) * C + lo4) * 16), rb_pack(tag, acc[i][q]), local);
-                        }
-                    }
+            for (int i = 0; i < RT; ++i) {
+                const int rt = wave + RB_WAVES * i;
+                if (16 * rt < ld) {
+                    const unsigned off = (unsigned)((((size_t)w * ldx + 16 * rt + lo4) * 16 + 4 * k4) * 8);
+                    rb_store2(rs_slab, off, acc[i][0], acc[i][1], local);
+                    rb_store2(rs_slab, off + 16, acc[i][2], acc[i][3], local);
                 }
             }
             if (wave == 0) {
@@ -434,44 +466,84 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
 #pragma unroll
                     for (int v = 0; v < RB_WAVES; ++v) sv += shw[(v * 3 + q) * 16 + lo4];
                 }
-                if (lo4 < C) rb_store(rs_slab, (unsigned)((((size_t)w * ldx + ld + q) * C + lo4) * 16), rb_pack(tag, sv), local);
+                const unsigned off = (unsigned)((((size_t)w * ldx + ld + q) * 16 + (lo4 & 3) * 4 + (lo4 >> 2)) * 8);
+                const u64 b = (u64)__double_as_longlong(sv);
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 w2v = u32x2{(unsigned)b, (unsigned)(b >> 32)};
+                if (local)
+                    __builtin_amdgcn_raw_buffer_store_b64(w2v, rs_slab, (int)off, 0, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b64(w2v, rs_slab, (int)off, 0, 16);
+            }
+            // the partial is complete in memory (for the stencil regularisers: the model too) -> ONE flag word
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                // (only the workgroups of the own cluster read it: through the shared L2 where the placement allows)
+                if (local)
+                    __hip_atomic_store(a.flagg + w, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_store(a.flagg + w, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         tick(1);
         // ---- hops 1 + 2: the owner of row chunk `crank` sums it over its cluster, then over the clusters
         if (crank < nch) {
+            // the members' flags: every wave looks for itself, its loads of their partials follow its own poll
+            {
+                const bool got = res_poll(a.abort_w, [&]() -> bool {
+                    bool ok = true;
+                    if (lane < cn)
+                        ok = __hip_atomic_load(a.flagg + cg + RES_CLUSTERS * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u64)tag;
+                    return ok;
+                });
+                if (!got) *flag_s = 0;
+                asm volatile("" ::: "memory");
+            }
+            tick(2);
             const int r0 = crank * ch;
             const int nr = (ldx - r0 < ch) ? (ldx - r0) : ch;
-            const int npair = nr > 0 ? nr * C : 0;
-            for (int pb = wave * 64; pb < npair; pb += RB_THREADS) {
-                const int p = pb + lane;
-                const bool act = p < npair;
-                const int row = r0 + (act ? p / C : 0), chn = act ? p % C : 0;
-                const unsigned rc16 = (unsigned)(((size_t)row * C + chn) * 16);
-                double csum = 0.0;
-                for (int m0 = 0; m0 < cn; m0 += 8) {
-                    unsigned off[8];
-                    double v[8];
+            const int nitems = nr > 0 ? nr * 8 : 0;   // (row, pair of slab positions)
+            const int mt = (cn + 2) / 3;              // members per third of the cluster
+            // work unit = item x third of the members: lanes 3 i, 3 i + 1, 3 i + 2 of a wave (lane 63 idle)
+            for (int base = 0; base < nitems; base += 21 * RB_WAVES) {
+                const int it = base + wave * 21 + lane / 3, g = lane % 3;
+                const bool act = lane < 63 && it < nitems;
+                const int row = r0 + (act ? it >> 3 : 0), h = it & 7;
+                const unsigned rp = (unsigned)((((size_t)row) * 16 + 2 * h) * 8);
+                d2 v[11];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        off[u] = (unsigned)((size_t)(cg + RES_CLUSTERS * (m0 + u)) * ldx * C * 16) + rc16;
-                    const int n = act ? (cn - m0 < 8 ? cn - m0 : 8) : 0;
-                    if (!rb_poll<8>(a.abort_w, rs_slab, tag, n, off, v)) *flag_s = 0;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) csum += v[u];
+                for (int u = 0; u < 11; ++u) {
+                    const int m = g * mt + u;
+                    v[u] = d2{0.0, 0.0};
+                    if (act && u < mt && m < cn) v[u] = rb_load2(rs_slab, (unsigned)((size_t)(cg + RES_CLUSTERS * m) * ldx * 16 * 8) + rp);
                 }
-                tick(3);
-                const unsigned xoff = (unsigned)((size_t)par * RES_CLUSTERS * ldx * C * 16);
-                if (act) rb_store(rs_xs, xoff + (unsigned)((size_t)cg * ldx * C * 16) + rc16, rb_pack(tag, csum), false);
-                unsigned off[8];
-                double v[8];
+                d2 sg = d2{0.0, 0.0};
 #pragma unroll
-                for (int u = 0; u < 8; ++u) off[u] = xoff + (unsigned)((size_t)u * ldx * C * 16) + rc16;
-                if (!rb_poll<8>(a.abort_w, rs_xs, tag, act ? ncl : 0, off, v)) *flag_s = 0;
+                for (int u = 0; u < 11; ++u) {
+                    sg.x += v[u].x;
+                    sg.y += v[u].y;
+                }
+                // the thirds in a fixed order, (0 + 1) + 2; lane g = 0 of the item carries on with the chain at slab
+                // position 2 h, lane g = 1 with the one at 2 h + 1 (position p holds chain p / 4 + 4 (p % 4))
+                const double up_x = __shfl(sg.x, lane + 1, 64), up2_x = __shfl(sg.x, lane + 2, 64);
+                const double dn_y = __shfl(sg.y, lane - 1, 64), up_y = __shfl(sg.y, lane + 1, 64);
+                const double csum = g == 0 ? (sg.x + up_x) + up2_x : (dn_y + sg.y) + up_y;
+                tick(3);
+                const int ps = 2 * h + g, chn = ps / 4 + 4 * (ps % 4);
+                const bool own = act && g < 2 && chn < C;
+                const unsigned xoff = (unsigned)((size_t)par * RES_CLUSTERS * ldx * C * 16);
+                const unsigned rc = (unsigned)(((size_t)row * C + (own ? chn : 0)) * 16);
+                if (own) rb_store(rs_xs, xoff + (unsigned)((size_t)cg * ldx * C * 16) + rc, rb_pack(tag, csum), false);
+                unsigned off[8];
+                double vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) off[u] = xoff + (unsigned)((size_t)u * ldx * C * 16) + rc;
+                if (!rb_poll<8>(a.abort_w, rs_xs, tag, own ? ncl : 0, off, vv)) *flag_s = 0;
                 double tot = 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) tot += v[u];
-                if (act) rb_store(rs_dcl, (unsigned)((size_t)cg * ldx * C * 16) + rc16, rb_pack(tag, tot), local);
+                for (int u = 0; u < 8; ++u) tot += vv[u];
+                if (own) rb_store(rs_dcl, (unsigned)((size_t)cg * ldx * C * 16) + rc, rb_pack(tag, tot), local);
                 tick(4);
             }
         }
@@ -553,10 +625,35 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
             d4 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+            if (GREG) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+                for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma_f64(gt[t][s], rf[s], acc[t]);
+                    for (int t = 0; t < NT; ++t) acc[t] = mfma_f64(gt[GREG ? t : 0][GREG ? s : 0], rf[s], acc[t]);
+            } else {
+                // operand from the LDS copy: column 16 t + lo4 (zero columns beyond cpw4 are not stored: clamp and
+                // mask), rows of the k-step; five k-steps of reads in flight in front of their MFMAs
+                const int c0 = lo4 < cpw4 ? lo4 : 0, c1 = 16 + lo4 < cpw4 ? 16 + lo4 : 0;
+                const bool z0 = lo4 >= cpw4, z1 = 16 + lo4 >= cpw4;
+                const double *g0 = Gs + (size_t)c0 * ldp + rb0 + k4, *g1 = Gs + (size_t)c1 * ldp + rb0 + k4;
+#pragma unroll
+                for (int sb = 0; sb < KS; sb += 5) {
+                    double a0[5], a1[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const bool in = sb + u < KS && rb0 + 4 * (sb + u) < ld;
+                        a0[u] = (in && !z0) ? g0[4 * (sb + u)] : 0.0;
+                        if (NT > 1) a1[u] = (in && !z1) ? g1[4 * (sb + u)] : 0.0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 5; ++u)
+                        if (sb + u < KS) {
+                            acc[0] = mfma_f64(a0[u], rf[sb + u], acc[0]);
+                            if (NT > 1) acc[NT > 1 ? 1 : 0] = mfma_f64(a1[u], rf[sb + u], acc[NT > 1 ? 1 : 0]);
+                        }
+                }
+            }
             // (register q of tile t holds the columns 16 t + 4 q + (lane >> 4): group 4 t + q)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -579,6 +676,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
             }
             sh_r = sh_pp1 = sh_pp0 = 0.0;
             bool evaluate = (mode == RUN);
+            tick(13);
             if (mode == DECIDE) {
                 const double Unew = udL + a.alpha * tR;
                 const double Hcur = 0.5 * pp0 + U0, Hnew = 0.5 * tP1 + Unew;
@@ -604,10 +702,10 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
                 n_done += 1;
                 if (spec) {
                     // the next trajectory's first step was taken from the proposal
-                    Lc = a.L[ct * T + q_next];
-                    uc = a.us[ct * T + q_next];
+                    Lc = Ln;
+                    uc = un;
                     q_next += 1;
-                    p0n = list_p0(q_next);
+                    fetch_next();
                     s_done = 0;
                     mode = RUN;
                     if (acc) {
@@ -625,6 +723,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
                 }
                 spec = false;
             }
+            tick(5);
             if (evaluate) {
                 evals += 1;
                 // regulariser gradient of the own cell at xs (potential.py:719-810)
@@ -681,6 +780,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
                     }
                 }
             }
+            tick(8);
             if (cell) Xs[jt * 16 + ct] = xs;
             post_shares();
         }
