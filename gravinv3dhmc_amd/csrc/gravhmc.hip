@@ -91,6 +91,7 @@ void gh_destroy(gh_ctx *c)
     }
     if (c->sh.hbuf) hipHostFree(c->sh.hbuf);
     if (c->bt.h) hipHostFree(c->bt.h);
+    if (c->rs.ls.h_stage) hipHostFree(c->rs.ls.h_stage);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_scal) hipHostFree(c->h_scal);
     for (hipEvent_t ev : c->ev) hipEventDestroy(ev);

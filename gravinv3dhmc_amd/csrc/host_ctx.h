@@ -267,6 +267,8 @@ struct gh_ctx {
             double *xpub = nullptr, *xs = nullptr, *ps = nullptr, *pst = nullptr, *cst = nullptr;
             double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr;
             int *L = nullptr, *accepted = nullptr, *n_io = nullptr;
+            double *h_stage = nullptr;       // pinned staging of the momentum rows
+            size_t h_stage_n = 0;
             int cap = 0;                 // list elements the device lists hold
             unsigned tag = 0, ltag = 0;
             bool dirty = false;          // an aborted launch left tags behind

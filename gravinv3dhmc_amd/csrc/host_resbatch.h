@@ -122,13 +122,33 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
         b.dirty = false;
     }
     HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
+    // Momenta: device rows trajectory-major (t * C + ch), gathered into ONE pinned staging buffer (a few host
+    // threads: 6 MB at C1 with 16 chains x 8 trajectories) and sent with one copy -- 128 separate copies of
+    // pageable rows cost more than the kernel they feed.
+    if ((size_t)K * M > b.h_stage_n) {
+        if (b.h_stage) HIPCHK(c, hipHostFree(b.h_stage));
+        b.h_stage = nullptr;
+        b.h_stage_n = (size_t)std::max(K, 32) * M;
+        HIPCHK(c, hipHostMalloc((void **)&b.h_stage, b.h_stage_n * sizeof(double)));
+    }
     if (K > 0) {
-        if (p0flat) {
-            HIPCHK(c, hipMemcpyAsync(b.p0s, p0flat, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        auto stage_rows = [&](int k0, int k1) {
+            for (int k = k0; k < k1; ++k) {
+                const int t = k / C, ch = k % C;
+                memcpy(b.h_stage + (size_t)k * M, p0flat ? p0flat + ((size_t)ch * T + t) * M : p0rows[(size_t)ch * T + t],
+                       M * sizeof(double));
+            }
+        };
+        const int nthr = (size_t)K * M * sizeof(double) >= ((size_t)1 << 20) ? std::min(4, K) : 1;
+        if (nthr > 1) {
+            std::vector<std::thread> pool;
+            for (int i = 1; i < nthr; ++i) pool.emplace_back(stage_rows, (int)((int64_t)K * i / nthr), (int)((int64_t)K * (i + 1) / nthr));
+            stage_rows(0, K / nthr);
+            for (std::thread &th : pool) th.join();
         } else {
-            for (int k = 0; k < K; ++k)
-                HIPCHK(c, hipMemcpyAsync(b.p0s + (size_t)k * M, p0rows[k], M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            stage_rows(0, K);
         }
+        HIPCHK(c, hipMemcpyAsync(b.p0s, b.h_stage, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(b.us, us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(b.L, L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
@@ -218,7 +238,10 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int ch = 0; ch < C; ++ch) {
         const int nd = h_n[16 + ch];
-        for (int i = 0; i < nd && i < a.Tout; ++i) {
+        if (nd > a.Tout || h_n[ch] > T)
+            return fail(c, GH_ERR_HIP, "resident batch kernel: chain %d reports %d results in %d slots (%d of %d started)", ch, nd,
+                        a.Tout, h_n[ch], T);
+        for (int i = 0; i < nd; ++i) {
             const size_t slot = (size_t)ch * a.Tout + i;
             accepted[slot] = acc[slot];
             memcpy(out5s + slot * 5, o5.data() + slot * 5, 5 * sizeof(double));

@@ -59,9 +59,9 @@ struct ResBatchArgs {
     double alpha, beta;
     const double *mwapr, *wm2;
     int C;             // chains
-    int T;             // trajectories offered per chain; element (c, t) of the lists at c * T + t
+    int T;             // trajectories offered per chain; element (c, t) of L / us at c * T + t
     const int *L;
-    const double *p0s; // (C T) x M
+    const double *p0s; // (T C) x M momenta, trajectory-major: row t * C + c
     const double *us;
     double dt;
     int stop_any;      // 1: end when a chain has nothing left to start (carry-over); 0: run all lists to their end
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
         xs = xj;
     };
     auto list_p0 = [&](int q) -> double {
-        return (cell && q < T) ? a.p0s[((int64_t)ct * T + q) * M + jg] : 0.0;
+        return (cell && q < T) ? a.p0s[((int64_t)q * C + ct) * M + jg] : 0.0;
     };
     // a chain with nothing in flight starts the first element of its list
     if (ct < C && mode == IDLE && T > 0) {
@@ -382,12 +382,18 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
             sh_pp0 = p0k * p0k;
         }
     }
+    // The next list element (momentum, length, variate) is fetched two evaluations before the running
+    // trajectory ends: early enough to hide the latency of the fetch, and nothing a lock-step waits for.
+    // (Sending the later rows on a copy stream BESIDE the running kernel was tried: a copy the runtime performs
+    // with a shader cannot start while this kernel holds every CU's registers -- the kernel then waits for rows
+    // that wait for the kernel.  All rows are in place before the launch.)
+    bool fetched = false;
     auto fetch_next = [&]() {
         p0n = list_p0(q_next);
         Ln = (ct < C && q_next < T) ? a.L[ct * T + q_next] : 0;
         un = (ct < C && q_next < T) ? a.us[ct * T + q_next] : 0.0;
+        fetched = true;
     };
-    fetch_next();
 
     // the cells' terms of the three sums -> per-wave shares in LDS (summed over the waves by the next forward)
     auto post_shares = [&]() {
@@ -419,6 +425,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
             const bool none_active = (b_run | b_dec) == 0;
             if (none_active || (a.stop_any && T > 0 && b_starved != 0 && b_dec == 0)) break;
         }
+        if (!fetched && (mode != RUN || Lc - s_done <= 2)) fetch_next();
         // (stencil regularisers: the neighbours read this model once they have d, which depends on a partial
         // of every workgroup -- the stores are drained, behind the forward products that hide their latency,
         // before any partial of this workgroup is published)
@@ -705,7 +712,8 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
                     Lc = Ln;
                     uc = un;
                     q_next += 1;
-                    fetch_next();
+                    fetched = false;
+                    if (Lc <= 2) fetch_next();  // (a trajectory this short may see its last evaluation in this very lock-step)
                     s_done = 0;
                     mode = RUN;
                     if (acc) {
