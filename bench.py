@@ -647,67 +647,64 @@ def main():
         # ---- several chains per GPU: one RandomState per chain (seed 100 + global chain index,
         # the stream np.random.seed gives the reference's rank), lock-step rounds of L steps
         from concurrent.futures import ThreadPoolExecutor
-        rs = [np.random.RandomState(args.seed + rank * CPG + k) for k in range(CPG)]
-        pool = ThreadPoolExecutor(max_workers=CPG)
+        from gravinv3dhmc_amd.inversion.rng import LegacyDraws
+        pool = ThreadPoolExecutor(max_workers=CPG + 1)
         x0s = np.stack([0.001 * wm for _ in range(CPG)])
         eng.batch_init(x0s, low, high)
+        # (trajectories offered per chain and call: the sampler's rule, inversion/hmc.py HMCSampleBatch)
+        Tmax = int(max(2, min(8, (256 << 20) // (8 * M * CPG))))
 
-        def draw_round(n):
-            def one(r):
-                return r.randn(M) * Sigma, r.rand()
-            res = list(pool.map(one, rs))
-            return [p for p, _ in res], [u for _, u in res], n
+        class Rounds(object):
+            """Every chain runs total_steps leapfrog steps in trajectories of L (the last one shorter), through
+            the sampler's path (HMCSampleBatch): gh_batch_run in carry-over mode, up to Tmax trajectories per
+            chain offered per call -- a finishing chain's last step takes the first step of the next one it
+            has been offered -- the following offers drawn meanwhile, each chain from its own legacy stream
+            (bit for bit np.random.RandomState(seed + chain): randn(M) * Sigma, rand() per trajectory) by the
+            library's generator, one thread per chain."""
 
-        def run_rounds(total_steps, first):
-            """Every chain runs total_steps leapfrog steps in trajectories of L (the last one
-            shorter), through the sampler's path (HMCSampleBatch): gh_batch_run in carry-over mode,
-            up to eight trajectories per chain offered per call -- a finishing chain's last sweep takes the
-            first step of the next one it has been offered -- further rounds drawn meanwhile."""
-            plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
-            queue = [[] for _ in range(CPG)]           # per chain: (n, p0, u) not started yet
-            drawn = 0
+            def __init__(self, total_steps, seed0):
+                self.plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
+                self.draws = [LegacyDraws(M, (L, L), Sigma, fixed_L=self.plan, seed=seed0 + k) for k in range(CPG)]
+                self.queue = [[] for _ in range(CPG)]      # per chain: (n, p0, u) drawn, not started yet
+                self.top_up()                              # a sampler in steady state has its next offer drawn
 
-            def draw_into_queue():
-                nonlocal drawn
-                if drawn < len(plan):
-                    p0s, us, n = first[drawn] if drawn < len(first) else draw_round(plan[drawn])
+            def top_up(self):
+                def one(k):
+                    n = 2 * Tmax - len(self.queue[k])
+                    if n > 0:
+                        Ls, p0s, us = self.draws[k].take_block(n)
+                        self.queue[k].extend((int(Ls[i]), p0s[i], float(us[i])) for i in range(len(Ls)))
+                list(pool.map(one, range(CPG)))
+
+            def run(self):
+                queue, nacc, done = self.queue, 0, [0] * CPG
+                while min(done) < len(self.plan):
+                    T = min(Tmax, min(len(q) for q in queue))
+                    if T == 0:                             # nothing left to offer: finish what is in flight
+                        acc, _, _, ns, nd = eng.batch_run([[] for _ in range(CPG)], dt, np.zeros((CPG, 0)),
+                                                          np.zeros((CPG, 0)), carry=True)
+                    else:
+                        fut = pool.submit(eng.batch_run, [[tr[1] for tr in q[:T]] for q in queue], dt,
+                                          [[tr[0] for tr in q[:T]] for q in queue],
+                                          [[tr[2] for tr in q[:T]] for q in queue], False, True)
+                        self.top_up()                      # (the offers after this one, while the GPU runs)
+                        acc, _, _, ns, nd = fut.result()
                     for k in range(CPG):
-                        queue[k].append((plan[drawn], p0s[k], us[k]))
-                    drawn += 1
+                        del queue[k][:int(ns[k])]
+                        done[k] += int(nd[k])
+                        nacc += int(acc[k, :int(nd[k])].sum())
+                for d in self.draws:
+                    d.release()
+                return nacc, len(self.plan)
 
-            # (trajectories offered per chain and call: the sampler's rule, inversion/hmc.py HMCSampleBatch)
-            Tmax = int(max(2, min(8, (256 << 20) // (8 * M * CPG))))
-            for _ in range(Tmax):
-                draw_into_queue()
-            nacc, done = 0, [0] * CPG
-            while min(done) < len(plan):
-                T = min(Tmax, min(len(q) for q in queue))
-                if T == 0:                             # nothing left to offer: finish what is in flight
-                    acc, _, _, ns, nd = eng.batch_run([[] for _ in range(CPG)], dt, np.zeros((CPG, 0)),
-                                                      np.zeros((CPG, 0)), carry=True)
-                else:
-                    fut = pool.submit(eng.batch_run, [[tr[1] for tr in q[:T]] for q in queue], dt,
-                                      [[tr[0] for tr in q[:T]] for q in queue],
-                                      [[tr[2] for tr in q[:T]] for q in queue], False, True)
-                    while min(len(q) for q in queue) < 2 * Tmax and drawn < len(plan):
-                        draw_into_queue()
-                    acc, _, _, ns, nd = fut.result()
-                for k in range(CPG):
-                    del queue[k][:int(ns[k])]
-                    done[k] += int(nd[k])
-                    nacc += int(acc[k, :int(nd[k])].sum())
-            return nacc, len(plan)
-
-        # a sampler in steady state has its next rounds drawn while the GPU was busy: the first offer
-        # are drawn before the clock starts, the rest overlaps as usual
         if args.warmup > 0:
-            run_rounds(args.warmup, [draw_round(L)])
-        first = [draw_round(L) for _ in range(int(max(2, min(8, (256 << 20) // (8 * M * CPG)))))]
+            Rounds(args.warmup, args.seed + 1000 + rank * CPG).run()
+        rounds = Rounds(args.steps, args.seed + rank * CPG)
         eng.synchronize()
         barrier()
         eng.profile_enable(True)
         t0 = time.perf_counter()
-        naccept, ntraj = run_rounds(args.steps, first)
+        naccept, ntraj = rounds.run()
         eng.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()

@@ -21,7 +21,11 @@ class LegacyDraws(object):
     """Iterator of (L, p0, u) in the reference's stream order, with a block interface for
     Engine.run_chain (``take_block``)."""
 
-    def __init__(self, M, Lrange, Sigma, fixed_L=None, limit=None):
+    def __init__(self, M, Lrange, Sigma, fixed_L=None, limit=None, seed=None):
+        """seed=None: adopt (and on release() hand back) the state of NumPy's GLOBAL legacy generator, as
+        HamitonianMC.sample uses it.  seed=int: an independent stream, bit for bit the one
+        ``np.random.RandomState(seed)`` produces (a chain of HMCSampleBatch: the reference's rank seeds its
+        global generator with seed + rank, hmc.py:369); release() then only frees it."""
         self._lib = _lib.load()
         self.M = int(M)
         self.Lmin, self.Lmax = int(Lrange[0]), int(Lrange[1])
@@ -31,9 +35,11 @@ class LegacyDraws(object):
         self._plan = None if fixed_L is None else list(fixed_L)   # trajectory lengths given, no randint
         self._left = limit if self._plan is None else len(self._plan)
         self._h = C.c_void_p()
-        if self._lib.gh_rng_create(C.byref(self._h), 0) != 0:
+        self._own = seed is not None
+        if self._lib.gh_rng_create(C.byref(self._h), int(seed) if self._own else 0) != 0:
             raise RuntimeError("gh_rng_create failed")
-        self.adopt()
+        if not self._own:
+            self.adopt()
         self._row = None
 
     # -- exchange with np.random --------------------------------------------------------
@@ -50,6 +56,10 @@ class LegacyDraws(object):
     def release(self):
         """Hand the stream back to np.random and free the native generator."""
         if not self._h:
+            return
+        if self._own:
+            self._lib.gh_rng_destroy(self._h)
+            self._h = C.c_void_p()
             return
         key = np.zeros(624, dtype=np.uint32)
         pos, has_gauss, cached = C.c_int(), C.c_int(), C.c_double()
