@@ -9,6 +9,7 @@
 #include "mfbatch.hip.h"
 #include "batchteam.hip.h"
 #include "lonsym.hip.h"
+#include "lonsymh.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -82,6 +83,8 @@ int gh_create(gh_ctx **out, int device, int64_t N, int64_t M)
 void gh_destroy(gh_ctx *c)
 {
     if (!c) return;
+    for (gh_ctx *k : c->kids) gh_destroy(k);
+    c->kids.clear();
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->sh.comm) {
@@ -1157,6 +1160,96 @@ int gh_posterior_read(gh_ctx *c, int64_t *n_in_window, int64_t *n_total, double 
     return GH_OK;
 }
 
+// ---- a batch of chains on the shift-invariant store (BASELINE configs[3]: "8 chains"; the reference runs them
+// as MPI ranks, example/global/run_main.sh:16, each with its own 4.25 GB kernel).  A step of ONE chain on the
+// table keeps a fraction of the chip busy for ~60 us, most of it latency: the chains are C light contexts
+// that share the parent's tables (T, T^: read-only) and problem vectors, each with its own stream, chain
+// state and work buffers, driven by one host thread each -- their passes overlap on the GPU.
+static int kids_make(gh_ctx *c, int C, const double *x0s, const double *low, const double *high)
+{
+    for (gh_ctx *k : c->kids) gh_destroy(k);
+    c->kids.clear();
+    for (int i = 0; i < C; ++i) {
+        gh_ctx *k = nullptr;
+        const int rc0 = gh_create(&k, c->device, c->N, c->M);
+        if (rc0 != GH_OK) return fail(c, rc0, "gh_batch_init: %s", gh_last_error(nullptr));
+        c->kids.push_back(k);
+        k->cell_kind = c->cell_kind;
+        k->ratio = c->ratio;
+        k->have_obs = k->have_cells = k->have_G = true;
+        k->mf = true;
+        k->weighted = c->weighted;
+        k->wm = c->wm;
+        k->wm2 = c->wm2;
+        k->dobs_c = c->dobs_c;
+        k->gfix = c->gfix;
+        k->gfix_sum = c->gfix_sum;
+        k->mwapr = c->mwapr;
+        k->have_data = c->have_data;
+        k->have_fix = c->have_fix;
+        k->have_reg = c->have_reg;
+        k->reg_kind = c->reg_kind;
+        for (int q = 0; q < 3; ++q) k->shape[q] = c->shape[q];
+        k->alpha = c->alpha;
+        k->beta = c->beta;
+        k->ls = new LonSymHost(*c->ls);  // (the tables are the parent's; the pass's work buffers are its own)
+        k->ls->Rhat = k->ls->Dpart = nullptr;
+        k->ls->dbg = nullptr;
+        if (k->ls->harm) {
+            int rc = dalloc(k, &k->ls->Rhat, (size_t)k->ls->na * (size_t)k->ls->nf);
+            if (rc == GH_OK) rc = dalloc(k, &k->ls->Dpart, (size_t)k->ls->hgrid * (size_t)k->ls->na * (size_t)k->ls->nf);
+            if (rc != GH_OK) return fail(c, rc, "gh_batch_init: %s", gh_last_error(k));
+        }
+        int rc = configure_mf(k);
+        if (rc == GH_OK) rc = dalloc(k, &k->mf_stats, 1);
+        if (rc == GH_OK) rc = gh_chain_init(k, x0s + (size_t)i * (size_t)c->M, low, high);
+        if (rc != GH_OK) return fail(c, rc, "gh_batch_init (chain %d): %s", i, gh_last_error(k));
+    }
+    c->bt.C = C;
+    c->bt.ready = true;
+    c->bt.run = gh_ctx::Batch::Run();
+    return GH_OK;
+}
+
+// T trajectories of every chain (lists chain-major), each chain on its own thread and stream; results of
+// chain i in slots i * Tout + t.  Nothing stays in flight.
+static int kids_run(gh_ctx *c, int T, const int *L, const double *const *p0rows, const double *p0flat, const double *us,
+                    double dt, int *accepted, double *out5s, double *x_out, int Tout)
+{
+    const int C = (int)c->kids.size();
+    const size_t M = (size_t)c->M;
+    std::vector<int> rcs((size_t)C, GH_OK);
+    auto work = [&](int i) {
+        gh_ctx *k = c->kids[(size_t)i];
+        if (hipSetDevice(k->device) != hipSuccess) {
+            rcs[(size_t)i] = GH_ERR_HIP;
+            return;
+        }
+        for (int t = 0; t < T; ++t) {
+            const size_t src = (size_t)i * T + t, dst = (size_t)i * Tout + t;
+            const double *p0 = p0flat ? p0flat + src * M : p0rows[src];
+            const double *pn = (t + 1 < T) ? (p0flat ? p0flat + (src + 1) * M : p0rows[src + 1]) : nullptr;
+            int acc = 0;
+            double o5[5];
+            int rc = chain_trajectory_impl(k, p0, dt, L[src], us[src], pn, &acc, o5);
+            if (rc == GH_OK && x_out && acc) rc = gh_chain_get_x(k, x_out + dst * M);
+            if (rc != GH_OK) {
+                rcs[(size_t)i] = rc;
+                return;
+            }
+            accepted[dst] = acc;
+            memcpy(out5s + dst * 5, o5, 5 * sizeof(double));
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < C; ++i) pool.emplace_back(work, i);
+    work(0);
+    for (std::thread &th : pool) th.join();
+    for (int i = 0; i < C; ++i)
+        if (rcs[(size_t)i] != GH_OK) return fail(c, rcs[(size_t)i], "chain %d: %s", i, gh_last_error(c->kids[(size_t)i]));
+    return GH_OK;
+}
+
 int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const double *high)
 {
     if (!c || !x0s || !low || !high) return fail(c, GH_ERR_ARG, "gh_batch_init: null pointer");
@@ -1166,6 +1259,7 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     if (c->sh.kind != 0)
         return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the unsharded kernel only");
     HIPCHK(c, hipSetDevice(c->device));
+    if (lonsym_on(c)) return kids_make(c, C, x0s, low, high);
     // (the wavelet-compressed forward only where the resident chain kernel takes the batch: the MFMA
     // batch has no compressed forward)
     if (c->wv.on && !(resident_usable(c) && resident_lds_doubles(c->ld, c->rs.cpw, C, c->rs.lds_cols, c->rs.split) *
@@ -1216,6 +1310,7 @@ int gh_batch_trajectory(gh_ctx *c, const double *p0s, double dt, const int *L, c
         if (L[k] < 1) return fail(c, GH_ERR_ARG, "gh_batch_trajectory: L must be >= 1");
         Lmax = std::max(Lmax, L[k]);
     }
+    if (!c->kids.empty()) return kids_run(c, 1, L, nullptr, p0s, us, dt, accepted, out5s, nullptr, 1);
     if (c->rs.b_on && c->rs.ls.on) {
         for (int k = 0; k < C; ++k)
             if (c->rs.ls.active[k])
@@ -1364,6 +1459,12 @@ int gh_batch_run(gh_ctx *c, int T, const int *L, const double *const *p0s, const
     const size_t M = (size_t)c->M;
     for (int k = 0; k < C * T; ++k)
         if (L[k] < 1 || !p0s[k]) return fail(c, GH_ERR_ARG, "gh_batch_run: L must be >= 1 and every momentum row given");
+    if (!c->kids.empty()) {
+        // shift-invariant store: every chain runs its T trajectories on its own stream; nothing stays in flight
+        TRY(kids_run(c, T, L, p0s, nullptr, us, dt, accepted, out5s, x_out, n_done ? T + 1 : T));
+        for (int ch = 0; ch < C && n_done; ++ch) n_started[ch] = n_done[ch] = T;
+        return GH_OK;
+    }
     // trajectories the lock-step kernel had in flight when it gave up: replayed in front of the new lists
     std::vector<int> pre_ch, pre_L;
     std::vector<double> pre_us, pre_p0;
@@ -1811,6 +1912,7 @@ int gh_batch_get_x(gh_ctx *c, int chain, double *x)
     if (!c || !x) return fail(c, GH_ERR_ARG, "gh_batch_get_x: null pointer");
     TRY(need(c, c->bt.ready && chain >= 0 && chain < c->bt.C, "gh_batch_get_x: no such chain"));
     HIPCHK(c, hipSetDevice(c->device));
+    if (!c->kids.empty()) return gh_chain_get_x(c->kids[(size_t)chain], x);
     if (c->rs.b_on) return d2h(c, x, c->rs.bx + (size_t)chain * (size_t)c->M, (size_t)c->M);
     batch_extract_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(c->bt.Xc, chain, c->M,
                                                                                            c->tmpM);
@@ -2021,6 +2123,7 @@ int gh_profile_enable(gh_ctx *c, int enable)
         for (auto &e : c->ev) HIPCHK(c, hipEventCreate(&e));
         c->ev_bytes.assign(c->ev.size() / 2, 0);
     }
+    for (gh_ctx *k : c->kids) TRY(gh_profile_enable(k, enable));
     c->prof = enable != 0;
     c->prof_stride = (c->ld * c->M * 8 < (int64_t)(1 << 30)) ? 16 : 1;
     c->prof_seen = 0;
@@ -2073,6 +2176,16 @@ int gh_profile_read(gh_ctx *c, double *sweep_ms, int64_t *sweep_launches, int64_
         HIPCHK(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
         ms += t;
         timed += 1;
+    }
+    for (gh_ctx *k : c->kids) {
+        // (a batch on the shift-invariant store: the timed passes of all chains -- they overlap on the GPU, the
+        // sum of their durations is not wall time)
+        double kms = 0.0;
+        int64_t kn = 0, kb = 0;
+        TRY(gh_profile_read(k, &kms, &kn, &kb));
+        ms += kms;
+        timed += kn;
+        maxb = std::max(maxb, kb);
     }
     if (sweep_ms) *sweep_ms = ms;
     if (sweep_launches) *sweep_launches = timed;

@@ -69,6 +69,10 @@ struct gh_ctx {
     // per-step evaluations; a flavour of the matrix-free mode (gh_set_shift_invariant)
     LonSymHost *ls = nullptr;
 
+    // chains of a batch on the shift-invariant store: light contexts of their own (stream, chain state, work
+    // buffers) that share this context's tables and problem vectors; run concurrently, one host thread each
+    std::vector<gh_ctx *> kids;
+
     // sweep configuration
     int TW = 0, EPT2 = 0, PF = 1;
     int n_panels = 1;        // row panels of the dense sweep (N > 16384 rows: > 1, two reads of G per step)
@@ -95,6 +99,7 @@ struct gh_ctx {
     // one-launch epilogue (reduce_finish_kernel): sums of the slab rows from the sweep, |r|^2 partials
     double *dsum = nullptr;
     bool dsum_live = false;   // the last forward launch delivered dsum for all slab_live rows
+    int dsum_n = 0;           // > 0: dsum holds this many partial sums (not one per slab row)
     double gfix_sum = 0.0;
     bool NT = false;
     int n_teams = 0, grid = 0;

@@ -92,6 +92,7 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         fa.ld = c->ld;
         fa.N = c->N;
         fa.dsum = c->dsum;
+        fa.n_dsum = c->dsum_n > 0 ? c->dsum_n : fa.n_rows_slab;
         fa.gfix_sum = gfix ? c->gfix_sum : 0.0;
         fa.gfix = gfix;
         fa.dobs_c = c->dobs_c;
@@ -184,7 +185,7 @@ static int ensure_work(gh_ctx *c)
     }
     c->n_dpart = (int)((c->ld + 31) / 32);
     if (c->ld >= 2048 && ((c->TW > 1 && c->n_panels == 1 && !c->mf) || lonsym_on(c)) && env_int("GRAVHMC_EPILOGUE1", 1) != 0) {
-        TRY(dalloc(c, &c->dsum, (size_t)c->grid));
+        TRY(dalloc(c, &c->dsum, (size_t)std::max(c->grid, 128)));
         for (int i = 0; i < 4; ++i) TRY(dalloc(c, &c->st[i].part, (size_t)c->n_dpart + (size_t)((c->M + 255) / 256)));
     }
     c->n_regpart = (int)((c->M + 255) / 256);

@@ -11,6 +11,11 @@ struct LonSymHost {
         *m_of = nullptr;
     int n_xslots = 0;
     long long *dbg = nullptr;  // GRAVHMC_LONSYM_TIMING: per-phase clocks of one workgroup
+    // the same store in the longitude-harmonic domain (lonsymh.hip.h): default where it applies
+    bool harm = false;
+    int nf = 0, hgrid = 0;
+    ghk::d2 *That = nullptr, *tw = nullptr, *Rhat = nullptr, *Dpart = nullptr;
+    size_t hlds = 0;
     size_t lds = 0;
     int grid = 0, items = 1, W = 8, thr = 1024;  // items: work items per wave, W: longitudes per work item (instantiation of the kernel)
     std::string why;  // why the geometry does not qualify (gh_last_error text)
@@ -212,12 +217,62 @@ static int lonsym_build(gh_ctx *c)
     HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsym_fn(h.items, h.W, h.thr)), h.lds));
     h.grid = (int)std::min<int64_t>(nc, c->cus);
     if (env_int("GRAVHMC_LONSYM_TIMING", 0)) TRY(dalloc(c, &h.dbg, 8));
+    // The harmonic form (lonsymh.hip.h): n / 2 + 1 frequencies in the lanes of a wave, the classes in four
+    // groups of at most LH_AK, R^ and the transforms' scratch in LDS.  GRAVHMC_LONSYM_HARMONIC=0: the direct
+    // correlations of lonsym.hip.h (also the fallback for geometries beyond these limits).
+    h.harm = false;
+    h.nf = (int)n / 2 + 1;
+    h.hlds = lonsymh_lds_doubles((int)n, h.nf, (int)na) * sizeof(double);
+    if (env_int("GRAVHMC_LONSYM_HARMONIC", 1) != 0 && h.nf <= 64 && na <= 4 * LH_AK && n <= 1024 && h.hlds <= 160 * 1024 - 512 &&
+        allow_dynamic_lds(reinterpret_cast<const void *>(lonsymh_sweep_kernel), h.hlds) == hipSuccess) {
+        // (one workgroup per CU at most -- its T^ rows and accumulators take the CU's registers -- every one with
+        // the same number of cell rows)
+        const int rp = (int)((nc + (int64_t)c->cus - 1) / (int64_t)c->cus);
+        h.hgrid = (int)((nc + rp - 1) / rp);
+        TRY(dalloc(c, &h.tw, (size_t)n, false));
+        TRY(dalloc(c, &h.That, (size_t)nc * (size_t)na * (size_t)h.nf, false));
+        TRY(dalloc(c, &h.Rhat, (size_t)na * (size_t)h.nf));
+        TRY(dalloc(c, &h.Dpart, (size_t)h.hgrid * (size_t)na * (size_t)h.nf));
+        lonsymh_twiddle_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>((int)n, h.tw);
+        lonsymh_table_kernel<<<dim3((unsigned)(nc * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        h.harm = true;
+    } else {
+        (void)hipGetLastError();
+    }
     h.on = true;
     return GH_OK;
 }
 
+static LonHarmGeom lonsymh_geom(const gh_ctx *c)
+{
+    const LonSymHost &h = *c->ls;
+    LonHarmGeom g;
+    g.n = h.n;
+    g.nf = h.nf;
+    g.na = h.na;
+    g.nc = h.nc;
+    g.That = h.That;
+    g.tw = h.tw;
+    g.Rhat = h.Rhat;
+    g.Dpart = h.Dpart;
+    g.slot_first = h.slot_first;
+    g.n_xslots = h.n_xslots;
+    g.xslot = h.xslot;
+    g.xptr = h.xptr;
+    g.xobs = h.xobs;
+    g.N = c->N;
+    g.dbg = h.dbg;
+    return g;
+}
+
+static bool lonsym_harmonic(const gh_ctx *c) { return c->ls && c->ls->on && c->ls->harm; }
+
 static bool lonsym_on(const gh_ctx *c) { return c->ls && c->ls->on; }
-static int lonsym_grid(const gh_ctx *c) { return c->ls->grid; }
+static int lonsym_classes(const gh_ctx *c) { return c->ls->na; }
+// (workgroups of the pass = rows of the partial sums of p'p the trajectory code reads back)
+static int lonsym_grid(const gh_ctx *c) { return c->ls->harm ? c->ls->hgrid : c->ls->grid; }
 static int64_t lonsym_table_bytes(const gh_ctx *c) { return c->ls->ldT * c->ls->nc * (int64_t)sizeof(double); }
 
 static int launch_lonsym(gh_ctx *c, SweepArgs &a)
@@ -225,6 +280,16 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
     const LonSymHost &h = *c->ls;
     a.ld = c->ld;
     a.M = c->M;
+    if (h.harm) {
+        // harmonic domain: R^ in front of the pass, the finished slab row (and the classes' sums) behind it
+        const LonHarmGeom g = lonsymh_geom(c);
+        if (a.mode & SW_ADJ) lonsymh_rhat_kernel<<<dim3((unsigned)h.na), dim3(256), 0, c->stream>>>(g, a.r);
+        hipLaunchKernelGGL(lonsymh_sweep_kernel, dim3((unsigned)h.hgrid), dim3(LH_THREADS), h.hlds, c->stream, g, a,
+                           c->weighted ? c->wm : nullptr);
+        if (a.mode & SW_FWD)
+            lonsymh_post_kernel<<<dim3((unsigned)h.na), dim3(512), 0, c->stream>>>(g, h.hgrid, c->ld, a.slab, a.dsum);
+        return GH_OK;
+    }
     hipLaunchKernelGGL(lonsym_fn(h.items, h.W, h.thr), dim3((unsigned)h.grid), dim3((unsigned)h.thr), h.lds, c->stream, lonsym_geom(c), a,
                        c->weighted ? c->wm : nullptr);
     return GH_OK;

@@ -264,6 +264,8 @@ static bool mft_plan(gh_ctx *c);                     // host_batch.h: one chain 
 static int mft_launch(gh_ctx *c, SweepArgs &a);
 static int launch_lonsym(gh_ctx *c, SweepArgs &a);  // host_lonsym.h
 static bool lonsym_on(const gh_ctx *c);
+static bool lonsym_harmonic(const gh_ctx *c);
+static int lonsym_classes(const gh_ctx *c);
 static int lonsym_grid(const gh_ctx *c);
 static int64_t lonsym_table_bytes(const gh_ctx *c);
 
@@ -525,11 +527,17 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
     if (a.mode & SW_FWD) {
         c->slab_live = c->grid;
         c->dsum_live = false;
+        c->dsum_n = 0;
     }
     if (c->mf) {
         if (lonsym_on(c) && (a.mode & SW_FWD) && c->dsum) {
             a.dsum = c->dsum;  // (the shift-invariant pass delivers the sums of its slab rows as well)
             c->dsum_live = true;
+        }
+        if (lonsym_harmonic(c) && (a.mode & SW_FWD)) {
+            // (harmonic form: ONE finished slab row; the sums come per class of observations)
+            c->slab_live = 1;
+            c->dsum_n = lonsym_classes(c);
         }
         return launch_mf(c, a);
     }

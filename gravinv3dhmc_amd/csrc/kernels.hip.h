@@ -629,7 +629,8 @@ struct ReduceFinishArgs {
     const double *slab;
     int n_rows_slab, n_dpart, n_regpart;
     int64_t ld, N;
-    const double *dsum;      // n_rows_slab
+    const double *dsum;      // n_dsum partial sums of d over the observations (one per slab row, or as delivered)
+    int n_dsum;
     double gfix_sum;         // sum of grav_fix (0 without)
     const double *gfix, *dobs_c;
     double *d, *r, *scal;    // as FinishArgs (scal: only [3] = mean is written here)
@@ -647,7 +648,7 @@ __global__ void __launch_bounds__(256) reduce_finish_kernel(ReduceFinishArgs a)
     } else {
         // mean of d + grav_fix from the slab rows' sums, identical bits in every block
         double ds = 0.0;
-        for (int t = threadIdx.x; t < a.n_rows_slab; t += 256) ds += a.dsum[t];
+        for (int t = threadIdx.x; t < a.n_dsum; t += 256) ds += a.dsum[t];
         const double mean = (block_allreduce_sum(ds, red, 4) + a.gfix_sum) / (double)a.N;
         const int rx = threadIdx.x & 31, ty = threadIdx.x >> 5;
         const int64_t i = (int64_t)blockIdx.x * 32 + rx;

@@ -1,0 +1,471 @@
+// The shift-invariant store of a regular spherical grid in the LONGITUDE-HARMONIC domain (gfx950).
+//
+// lonsym.hip.h keeps K[i, (c, k)] = T[c][a_i][(m_i - k) mod n] and evaluates forward and adjoint as circular
+// correlations along the longitude, directly: N M multiply-adds each (C4: 5.3e8).  A circular correlation of
+// length n is a product per frequency of the length-n DFTs (real input: nf = n / 2 + 1 frequencies):
+//     S^[c][f]  = sum_a conj(T^[c][a][f]) R^[a][f]          adjoint  (R = slot sums of the residual)
+//     D^[a][f] += T^[c][a][f] X^[c][f]                       forward  (X = xs of the cell row)
+// -- n_c n_a nf complex multiply-adds per product (C4: 2.2e6), ~60x less arithmetic, from a table of the same
+// size (T^[c][a][f], complex: n_c n_a nf 16 bytes = 35.7 MB at C4), read once per leapfrog step.  The
+// clamp-and-reflect update of hmc.py:135-141 is per cell, so a cell row's gradient goes back to the
+// longitudes (inverse DFT of nf coefficients at n points), is updated, and the new positions are
+// transformed again (DFT) for the forward product: all inside the workgroup that owns the cell row, which
+// holds R^ (59.5 KB at C4) in LDS and its row of T^ in registers -- thread (f, group of classes).
+// The lengths are small (n = 120): the transforms are direct sums against a table of the n twiddle factors
+// (exact index arithmetic (f k) mod n; an FFT would save nothing at 4 barriers per cell row).
+//
+// Around the sweep: lonsymh_rhat_kernel (slot sums of r and their DFT, one block per class) in front of it,
+// lonsymh_post_kernel behind it (sum of the workgroups' D^ partials, inverse DFT per class, scatter to the
+// observations of the class: ONE finished slab row + per-class sums for the one-launch epilogue).
+//
+// Same values as lonsym.hip.h up to the rounding of the transforms (~1e-15 of a row's largest entry);
+// sums in a fixed order: reproducible bit for bit.  Reference arithmetic: gravmag/_tesseroid_numba.py:207-222
+// (cos(lon - lon')), gravmag/tesseroid.py:189-232, inversion/potential.py:698,708, inversion/hmc.py:114-152.
+#pragma once
+#include "lonsym.hip.h"
+
+namespace ghk {
+
+struct LonHarmGeom {
+    int n, nf, na, nc;
+    const d2 *That;          // [nc][na][nf]
+    const d2 *tw;            // n: (cos, sin)(2 pi j / n)
+    d2 *Rhat;                // [na][nf]
+    d2 *Dpart;               // [grid][na][nf]
+    const int *slot_first;   // na * n: first observation of slot (a, m), or -1
+    int n_xslots;
+    const int *xslot, *xptr, *xobs;
+    int64_t N;
+    long long *dbg;          // optional: 8 accumulated phase times (100 MHz ticks) of workgroup 0, thread 0
+};
+
+constexpr int LH_THREADS = 256;
+constexpr int LH_AK = 16;  // classes per thread: na <= 4 * LH_AK; nf <= 64
+
+static inline size_t lonsymh_lds_doubles(int n, int nf, int na)
+{
+    return 2 * (size_t)na * nf + 2 * (size_t)n + 8 * (size_t)nf + 2 * (size_t)nf + (size_t)n + 8 * (size_t)nf + 4 * (size_t)n + 16;
+}
+
+// T^[c][a][f] = sum_delta T[c][a][delta] e^{-2 pi i f delta / n}: one block per (c, a) row of the table
+__global__ void __launch_bounds__(64) lonsymh_table_kernel(const double *T, int64_t ldT, int n, int nf, int na, const d2 *tw, d2 *That)
+{
+    __shared__ double row[1024];
+    const int c = blockIdx.x / na, a = blockIdx.x - c * na;
+    const double *src = T + (int64_t)c * ldT + (int64_t)a * n;
+    for (int e = threadIdx.x; e < n; e += 64) row[e] = src[e];
+    __syncthreads();
+    for (int f = threadIdx.x; f < nf; f += 64) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;
+        for (int d = 0; d < n; ++d) {
+            const d2 w = tw[idx];
+            re += row[d] * w.x;
+            im -= row[d] * w.y;
+            idx += f;
+            if (idx >= n) idx -= n;
+        }
+        That[((int64_t)c * na + a) * nf + f] = d2{re, im};
+    }
+}
+
+__global__ void __launch_bounds__(256) lonsymh_twiddle_kernel(int n, d2 *tw)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) {
+        double s, c;
+        sincospi(2.0 * (double)j / (double)n, &s, &c);
+        tw[j] = d2{c, s};
+    }
+}
+
+// sum over ff in [f0, f1) of Re(H[ff] e^{+2 pi i ff k / n}): H and the twiddle table in LDS, reads in batches of
+// eight in front of their arithmetic (one wave per SIMD: a read-use-read-use loop runs at LDS latency)
+__device__ __forceinline__ double lh_idft_part(const d2 *H, const d2 *tws, int f0, int f1, int k, int n)
+{
+    double s = 0.0;
+    int idx = (int)(((long long)f0 * k) % n);
+    int ff = f0;
+    for (; ff + 8 <= f1; ff += 8) {
+        d2 h[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            h[u] = H[ff + u];
+            w[u] = tws[idx];
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += h[u].x * w[u].x - h[u].y * w[u].y;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; ff < f1; ++ff) {
+        const d2 h = H[ff], w = tws[idx];
+        s += h.x * w.x - h.y * w.y;
+        idx += k;
+        if (idx >= n) idx -= n;
+    }
+    return s;
+}
+
+// sum over k in [k0, k1) of v[k] e^{-2 pi i f k / n}
+__device__ __forceinline__ d2 lh_dft_part(const double *v, const d2 *tws, int k0, int k1, int f, int n)
+{
+    d2 acc = d2{0.0, 0.0};
+    int idx = (int)(((long long)f * k0) % n);
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        double x[8];
+        d2 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = v[k + u];
+            w[u] = tws[idx];
+            idx += f;
+            if (idx >= n) idx -= n;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x += x[u] * w[u].x;
+            acc.y -= x[u] * w[u].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; k < k1; ++k) {
+        const d2 w = tws[idx];
+        acc.x += v[k] * w.x;
+        acc.y -= v[k] * w.y;
+        idx += f;
+        if (idx >= n) idx -= n;
+    }
+    return acc;
+}
+
+// R^[a][f] of the residual r: block = class a
+__global__ void __launch_bounds__(256) lonsymh_rhat_kernel(LonHarmGeom g, const double *__restrict__ r)
+{
+    __shared__ double row[1024];
+    __shared__ d2 tws[1024];
+    __shared__ d2 part[4][64];
+    const int a = blockIdx.x, n = g.n, nf = g.nf, tid = threadIdx.x;
+    for (int m = tid; m < n; m += 256) {
+        const int e = a * n + m, idx = g.slot_first[e];
+        double v = idx >= 0 ? r[idx] : 0.0;
+        for (int x = 0; x < g.n_xslots; ++x)
+            if (g.xslot[x] == e)
+                for (int q = g.xptr[x]; q < g.xptr[x + 1]; ++q) v += r[g.xobs[q]];
+        row[m] = v;
+        tws[m] = g.tw[m];
+    }
+    __syncthreads();
+    const int f = tid & 63, q = tid >> 6, qn = (n + 3) / 4;
+    if (f < nf) {
+        const int k0 = q * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
+        part[q][f] = lh_dft_part(row, tws, k0 < n ? k0 : n, k1, f, n);
+    }
+    __syncthreads();
+    if (tid < nf) {
+        d2 sres = part[0][tid];
+#pragma unroll
+        for (int u = 1; u < 4; ++u) {
+            sres.x += part[u][tid].x;
+            sres.y += part[u][tid].y;
+        }
+        g.Rhat[a * nf + tid] = sres;
+    }
+}
+
+// The fused pass (modes of SweepArgs as lonsym_sweep_kernel).  Thread (f = tid & 63, ag = tid >> 6) holds the
+// classes ag * LH_AK + u of its frequency.
+__global__ void __launch_bounds__(LH_THREADS) lonsymh_sweep_kernel(LonHarmGeom g, SweepArgs a, const double *__restrict__ wm)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, f = tid & 63, ag = tid >> 6;
+    const int n = g.n, nf = g.nf, na = g.na;
+    const int mode = a.mode;
+    d2 *Rh = reinterpret_cast<d2 *>(smem);            // na x nf
+    d2 *tws = Rh + (size_t)na * nf;                    // n
+    d2 *Gp = tws + n;                                  // 4 x nf partial S^ of the class groups
+    d2 *Gh = Gp + 4 * nf;                              // nf
+    double *xs = reinterpret_cast<double *>(Gh + nf);  // n
+    d2 *Xp = reinterpret_cast<d2 *>(xs + n);           // 4 x nf partial X^ of the longitude quarters
+    double *Sp = reinterpret_cast<double *>(Xp + 4 * nf);  // 4 x n partial inverse transforms (frequency ranges)
+    double *red = Sp + 4 * n;
+    const bool fv = f < nf;
+    __shared__ long long tph_s[9];
+    const bool clk = g.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    if (clk) {
+        for (int q = 0; q < 8; ++q) tph_s[q] = 0;
+        tph_s[8] = wall_clock64();
+    }
+    auto mark = [&](int ph) {
+        if (clk) {
+            const long long now = wall_clock64();
+            tph_s[ph] += now - tph_s[8];
+            tph_s[8] = now;
+        }
+    };
+
+    for (int e = tid; e < n; e += LH_THREADS) tws[e] = g.tw[e];
+    if (mode & SW_ADJ) {
+        // (eight loads in flight per thread)
+        const int tot = na * nf;
+        for (int e0 = 0; e0 < tot; e0 += 8 * LH_THREADS) {
+            d2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * LH_THREADS + tid;
+                v[u] = g.Rhat[e < tot ? e : tot - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * LH_THREADS + tid;
+                if (e < tot) Rh[e] = v[u];
+            }
+        }
+    }
+    d2 th[LH_AK], dacc[LH_AK];
+#pragma unroll
+    for (int u = 0; u < LH_AK; ++u) dacc[u] = d2{0.0, 0.0};
+    auto t_fetch = [&](int c, d2 (&dst)[LH_AK]) {
+        const d2 *Tg = g.That + (int64_t)c * na * nf;
+#pragma unroll
+        for (int u = 0; u < LH_AK; ++u) {
+            const int aa = ag * LH_AK + u;
+            dst[u] = (fv && aa < na) ? Tg[aa * nf + f] : d2{0.0, 0.0};
+        }
+    };
+    double pp = 0.0;
+    const int qn = (n + 3) / 4;  // longitudes per quarter of the forward transform
+    const int np = (LH_THREADS / n) < 1 ? 1 : ((LH_THREADS / n) > 4 ? 4 : LH_THREADS / n);  // frequency ranges of the inverse one
+    const int fpp = (nf + np - 1) / np;
+    if ((int)blockIdx.x < g.nc) t_fetch(blockIdx.x, th);
+    __syncthreads();
+    mark(0);
+    for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
+        // the operands of this row's update (thread tid < n: cell (c, tid))
+        const int64_t j = (int64_t)c * n + tid;
+        double u_w = 1.0, u_x = 0.0, u_g = 0.0, u_p = 0.0, u_pn = 0.0, u_hi = 0.0, u_lo = 0.0;
+        if (tid < n) {
+            u_w = wm ? wm[j] : 1.0;
+            u_x = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+            if (mode & SW_ADJ) {
+                u_g = a.greg ? a.greg[j] : 0.0;
+                if (mode & (SW_PFIN | SW_UPD)) u_p = a.p_in[j];
+                if (mode & SW_SPEC) u_pn = a.pn_in[j];
+                if (mode & SW_UPD) {
+                    u_hi = a.high[j];
+                    u_lo = a.low[j];
+                }
+            }
+        }
+        double xj = u_x, iwj = 1.0;
+        if (tid < n) iwj = (u_w != 0.0) ? 1.0 / u_w : 1.0;
+        if (mode & SW_ADJ) {
+            // S^[f] = sum_a conj(T^[a][f]) R^[a][f]: this thread's classes, then the four groups
+            d2 gp = d2{0.0, 0.0};
+            if (fv) {
+                d2 rr[LH_AK];
+#pragma unroll
+                for (int u = 0; u < LH_AK; ++u) {
+                    const int aa = ag * LH_AK + u;
+                    rr[u] = Rh[(aa < na ? aa : na - 1) * nf + f];   // (classes past the last: th is zero there)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < LH_AK; ++u) {
+                    gp.x += th[u].x * rr[u].x + th[u].y * rr[u].y;
+                    gp.y += th[u].x * rr[u].y - th[u].y * rr[u].x;
+                }
+                Gp[ag * nf + f] = gp;
+            }
+            mark(1);
+            __syncthreads();
+            if (tid < nf) {
+                d2 s = Gp[tid];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    s.x += Gp[q * nf + tid].x;
+                    s.y += Gp[q * nf + tid].y;
+                }
+                // weight of the frequency in the inverse transform of a real sequence
+                const double wf = (tid == 0 || (2 * tid == n)) ? 1.0 : 2.0;
+                Gh[tid] = d2{s.x * wf, s.y * wf};
+            }
+            __syncthreads();
+            mark(2);
+            // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}): the frequencies in np ranges, one per
+            // group of n threads, summed in range order
+            {
+                const int part = tid / n, k = tid - part * n;
+                if (part < np) {
+                    const int f0 = part * fpp, f1 = (f0 + fpp < nf) ? f0 + fpp : nf;
+                    Sp[part * n + k] = lh_idft_part(Gh, tws, f0 < nf ? f0 : nf, f1, k, n);
+                }
+            }
+            __syncthreads();
+            if (tid < n) {
+                double s = Sp[tid];
+                for (int q = 1; q < np; ++q) s += Sp[q * n + tid];
+                const double t = (s / (double)n) * iwj;
+                const double grad = 2.0 * t + u_g;
+                if (mode & SW_GOUT) a.g_out[j] = grad;
+                if (mode & SW_PFIN) {
+                    const double pf = u_p - a.c_p * grad;
+                    pp += pf * pf;
+                    if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+                }
+                if (mode & SW_UPD) {
+                    const double psrc = (mode & SW_SPEC) ? u_pn : u_p;
+                    double pj = psrc - a.c_u * grad;
+                    xj = xj + a.dt * pj;
+                    if (xj > u_hi) {
+                        xj = u_hi;
+                        pj = -pj;
+                    } else if (xj < u_lo) {
+                        xj = u_lo;
+                        pj = -pj;
+                    }
+                    a.p_out[j] = pj;
+                    a.x_out[j] = xj;
+                }
+            }
+        }
+        mark(3);
+        // the next row's table: in flight behind the forward below
+        d2 thn[LH_AK];
+        const bool more = c + (int)gridDim.x < g.nc;
+        if (more) t_fetch(c + gridDim.x, thn);
+        if (mode & SW_FWD) {
+            if (tid < n) xs[tid] = xj * iwj;
+            __syncthreads();
+            // X^[f] = sum_k xs[k] e^{-2 pi i f k / n}: quarter ag of the longitudes, then the four quarters
+            if (fv) {
+                const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
+                Xp[ag * nf + f] = lh_dft_part(xs, tws, k0 < n ? k0 : n, k1, f, n);
+            }
+            mark(4);
+            __syncthreads();
+            if (fv) {
+                d2 xh = Xp[f];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    xh.x += Xp[q * nf + f].x;
+                    xh.y += Xp[q * nf + f].y;
+                }
+#pragma unroll
+                for (int u = 0; u < LH_AK; ++u) {
+                    dacc[u].x += th[u].x * xh.x - th[u].y * xh.y;
+                    dacc[u].y += th[u].x * xh.y + th[u].y * xh.x;
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < LH_AK; ++u) th[u] = thn[u];
+        }
+        mark(5);
+        __syncthreads();  // (Gp / xs / Xp of this row are done with before the next row writes them)
+        mark(6);
+    }
+    if (mode & SW_PFIN) {
+        const double t = block_allreduce_sum(tid < n ? pp : 0.0, red, LH_THREADS / 64);
+        if (tid == 0) a.pp_part[blockIdx.x] = t;
+    }
+    if ((mode & SW_FWD) && fv) {
+        d2 *out = g.Dpart + (int64_t)blockIdx.x * na * nf;
+#pragma unroll
+        for (int u = 0; u < LH_AK; ++u) {
+            const int aa = ag * LH_AK + u;
+            if (aa < na) out[aa * nf + f] = dacc[u];
+        }
+    }
+    mark(7);
+    if (clk)
+        for (int q = 0; q < 8; ++q) g.dbg[q] += tph_s[q];
+}
+
+// D^ = sum of the workgroups' partials, inverse transform per class, scatter to the observations of the
+// class (slab row 0), per-class sum of the predicted data (dsum[a]).  Block = class a.
+__global__ void __launch_bounds__(512) lonsymh_post_kernel(LonHarmGeom g, int nparts, int64_t ld, double *__restrict__ out,
+                                                           double *__restrict__ dsum)
+{
+    __shared__ d2 Dp[8][64];
+    __shared__ d2 Dh[64];
+    __shared__ d2 tws[1024];
+    __shared__ double Sp[4][1024];
+    __shared__ double red[8];
+    const int a = blockIdx.x, tid = threadIdx.x, f = tid & 63, q = tid >> 6;
+    const int n = g.n, nf = g.nf, na = g.na;
+    for (int m = tid; m < n; m += 512) tws[m] = g.tw[m];
+    if (f < nf) {
+        // parts q, q + 8, ...: eight loads in flight
+        d2 s = d2{0.0, 0.0};
+        const d2 *src = g.Dpart + (int64_t)a * nf + f;
+        const int64_t stride = (int64_t)na * nf;
+        int w = q;
+        for (; w + 56 < nparts; w += 64) {
+            d2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(w + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s.x += v[u].x;
+                s.y += v[u].y;
+            }
+        }
+        for (; w < nparts; w += 8) {
+            const d2 v = src[(int64_t)w * stride];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        Dp[q][f] = s;
+    }
+    __syncthreads();
+    if (tid < nf) {
+        d2 s = Dp[0][tid];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) {
+            s.x += Dp[u][tid].x;
+            s.y += Dp[u][tid].y;
+        }
+        const double wf = (tid == 0 || (2 * tid == n)) ? 1.0 : 2.0;
+        Dh[tid] = d2{s.x * wf, s.y * wf};
+    }
+    __syncthreads();
+    // inverse transform: the frequencies in np ranges, one per group of n threads
+    const int np = (512 / n) < 1 ? 1 : ((512 / n) > 4 ? 4 : 512 / n), fpp = (nf + np - 1) / np;
+    for (int m0 = 0; m0 < n; m0 += 512) {  // (one trip while n <= 512)
+        const int part = np > 1 ? tid / n : 0, m = np > 1 ? tid - part * n : m0 + tid;
+        if (part < np && m < n) {
+            const int f0 = part * fpp, f1 = (f0 + fpp < nf) ? f0 + fpp : nf;
+            Sp[part][m] = lh_idft_part(Dh, tws, f0 < nf ? f0 : nf, f1, m, n);
+        }
+    }
+    __syncthreads();
+    double rs = 0.0;
+    for (int m = tid; m < n; m += 512) {
+        double s = Sp[0][m];
+        for (int u = 1; u < np; ++u) s += Sp[u][m];
+        const double d = s / (double)n;
+        const int e = a * n + m, i0 = g.slot_first[e];
+        if (i0 >= 0) {
+            out[i0] = d;
+            rs += d;
+            for (int x = 0; x < g.n_xslots; ++x)
+                if (g.xslot[x] == e)
+                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) {
+                        out[g.xobs[qq]] = d;
+                        rs += d;
+                    }
+        }
+    }
+    if (a == 0)
+        for (int64_t i = g.N + tid; i < ld; i += 512) out[i] = 0.0;  // (the padding rows of the slab row)
+    const double t = block_allreduce_sum(rs, red, 8);
+    if (tid == 0 && dsum) dsum[a] = t;
+}
+
+}  // namespace ghk
