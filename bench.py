@@ -302,11 +302,15 @@ EXTRA_RUNS = [
     ("c2_uniform_16_chains_two_reads_of_G", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                                              "--warmup", "20", "--batch-team", "off"]),
     ("c3_segment_wavelet3d_tv", ["--workload", "c3_segment_wavelet3d_tv", "--steps", "20000", "--warmup", "2000"]),
+    ("c3_segment_wavelet3d_tv_16_chains", ["--workload", "c3_segment_wavelet3d_tv", "--chains-per-gpu", "16", "--steps", "4000",
+                                           "--warmup", "400"]),
     ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
                                          "--warmup", "10"]),
     ("c4_global_tesseroid_dense", ["--workload", "c4_global_tesseroid", "--steps", "2000", "--warmup", "200"]),
     ("c4_global_tesseroid_shift_invariant", ["--workload", "c4_global_tesseroid", "--shift-invariant", "--steps", "4000",
                                              "--warmup", "400"]),
+    ("c4_global_tesseroid_shift_invariant_8_chains", ["--workload", "c4_global_tesseroid", "--shift-invariant",
+                                                      "--chains-per-gpu", "8", "--steps", "2000", "--warmup", "200"]),
     ("c4_global_tesseroid_matrix_free_8_chains", ["--workload", "c4_global_tesseroid", "--matrix-free",
                                                   "--chains-per-gpu", "8", "--steps", "100", "--warmup", "20"]),
     ("c5_share_of_one_gpu_of_8", ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "8", "--steps", "40",
@@ -793,24 +797,44 @@ def main():
                     "fp64_matrix_peak_TFLOPs": 78.6,
                     "reference_formulation_equiv_GBps": 2 * bytes_sweep * CPG * args.steps / elapsed / 1e9})
         if args.shift_invariant:
-            # K[i, (c, k)] = T[c][class_i][(m_i - k) mod n]: the pass reads the table once (L2 / Infinity
-            # Cache resident) and does the N*M multiply-adds of adjoint and forward out of LDS
+            # K[i, (c, k)] = T[c][class_i][(m_i - k) mod n]: the pass reads the table once per step
             si = eng.shift_invariant_info()
+            hm = eng.shift_invariant_harmonic()
             secs = prof["sweep_ms"] * 1e-3
-            flops = 4.0 * N * M * prof["sweeps"]
-            line["roofline"] = {
-                "bound": "fp64 vector out of LDS (shift-invariant table, %.1f MB, cache resident; the N*M "
-                         "multiply-adds of adjoint and forward remain)" % (si["table_bytes"] / 1e6),
-                "achieved": flops / secs / 1e12 if secs > 0 else None, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": flops / secs / 1e12 / FP64_VECTOR_PEAK_TFLOPS if secs > 0 else None,
-                "traffic": None,
-                "kernel": "lonsym_sweep_kernel (workgroup = cell row of %d longitudes: %d observation classes in "
-                          "the lanes, 8-shift register window, fused adjoint+update+forward)"
-                          % (si["n_lon"], si["n_classes"]),
-                "launches": prof["sweeps"], "avg_ms": sweep_ms, "table": si,
-                "table_read_GBps": si["table_bytes"] / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None,
-                "flop_model": "2 N M multiply-adds per pass (adjoint + forward) = 4 N M flop",
-                "dense_G_equiv_GBps": N * M * 8 / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None}
+            if hm["on"]:
+                # harmonic domain: n_rows x n_classes x n_freq complex multiply-adds per product; what the pass
+                # must move is the complex table T^ (beyond L2: Infinity Cache / HBM), once per step
+                byts = float(hm["table_bytes"])
+                ach = byts * prof["sweeps"] / secs / 1e9 if secs > 0 else None
+                line["roofline"] = {
+                    "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                    "frac": ach / 8000.0 if ach else None, "traffic": None,
+                    "kernel": "lonsymh_rhat_kernel + lonsymh_sweep_kernel + lonsymh_post_kernel (longitude-harmonic "
+                              "domain: %d frequencies x %d classes x %d cell rows, complex table T^ of %.1f MB read once "
+                              "per step by %d workgroups; transforms of length %d inside the cell row's workgroup)"
+                              % (hm["n_freq"], si["n_classes"], si["n_rows"], byts / 1e6, hm["workgroups"], si["n_lon"]),
+                    "launches": prof["sweeps"], "avg_ms": sweep_ms, "table": dict(si, harmonic=hm),
+                    "algorithmic_bytes_per_launch": byts,
+                    "byte_model": "the complex table T^[row][class][frequency] (16 bytes per entry), read once per pass",
+                    "note": "three dependent, latency-bound launches per pass (time between the first one's start and "
+                            "the last one's end)" + ("; %d chains on their own streams: the passes overlap, their "
+                                                     "durations are summed" % CPG if CPG > 1 else ""),
+                    "dense_G_equiv_GBps": N * M * 8 / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None}
+            else:
+                flops = 4.0 * N * M * prof["sweeps"]
+                line["roofline"] = {
+                    "bound": "fp64 vector out of LDS (shift-invariant table, %.1f MB, cache resident; the N*M "
+                             "multiply-adds of adjoint and forward remain)" % (si["table_bytes"] / 1e6),
+                    "achieved": flops / secs / 1e12 if secs > 0 else None, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": flops / secs / 1e12 / FP64_VECTOR_PEAK_TFLOPS if secs > 0 else None,
+                    "traffic": None,
+                    "kernel": "lonsym_sweep_kernel (workgroup = cell row of %d longitudes: %d observation classes in "
+                              "the lanes, 8-shift register window, fused adjoint+update+forward)"
+                              % (si["n_lon"], si["n_classes"]),
+                    "launches": prof["sweeps"], "avg_ms": sweep_ms, "table": si,
+                    "table_read_GBps": si["table_bytes"] / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None,
+                    "flop_model": "2 N M multiply-adds per pass (adjoint + forward) = 4 N M flop",
+                    "dense_G_equiv_GBps": N * M * 8 / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None}
         elif args.matrix_free:
             # no stored G: the pass is bound by fp64 vector arithmetic.  FLOP model: the
             # operations of the reference's formulas as written, every +, -, *, /, sqrt and

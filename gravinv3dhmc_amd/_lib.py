@@ -41,6 +41,8 @@ PROTOTYPES = {
     "gh_set_shift_invariant": (C.c_int, [_ctx, C.c_int]),
     "gh_shift_invariant_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_int64)]),
+    "gh_shift_invariant_harmonic": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                                              C.POINTER(C.c_int)]),
     "gh_matrix_free_stats": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
                                        C.POINTER(_i64), C.POINTER(_i64)]),
     "gh_build_G": (C.c_int, [_ctx]),

@@ -203,6 +203,17 @@ int gh_shift_invariant_info(const gh_ctx *c, int *n_lon, int *n_classes, int *n_
     return GH_OK;
 }
 
+int gh_shift_invariant_harmonic(const gh_ctx *c, int *on, int *n_freq, int64_t *table_bytes, int *workgroups)
+{
+    if (!c) return GH_ERR_ARG;
+    const bool h = lonsym_harmonic(c);
+    if (on) *on = h ? 1 : 0;
+    if (n_freq) *n_freq = h ? c->ls->nf : 0;
+    if (table_bytes) *table_bytes = h ? (int64_t)c->ls->nc * c->ls->na * c->ls->nf * 16 : 0;
+    if (workgroups) *workgroups = h ? c->ls->hgrid : 0;
+    return GH_OK;
+}
+
 int gh_set_matrix_free_exact(gh_ctx *c, int exact)
 {
     if (!c) return GH_ERR_ARG;

@@ -13,7 +13,7 @@ struct LonSymHost {
     long long *dbg = nullptr;  // GRAVHMC_LONSYM_TIMING: per-phase clocks of one workgroup
     // the same store in the longitude-harmonic domain (lonsymh.hip.h): default where it applies
     bool harm = false;
-    int nf = 0, hgrid = 0;
+    int nf = 0, hgrid = 0, rw = 1;   // rw: cell rows a workgroup of the pass works on at once
     ghk::d2 *That = nullptr, *tw = nullptr, *Rhat = nullptr, *Dpart = nullptr;
     size_t hlds = 0;
     size_t lds = 0;
@@ -26,6 +26,12 @@ static lonsym_fn_t lonsym_fn(int items, int W, int T)
 {
     if (W == 16) return T == 512 ? lonsym_sweep_kernel<1, 16, 512> : lonsym_sweep_kernel<1, 16, 1024>;
     return items <= 1 ? lonsym_sweep_kernel<1, 8, 1024> : items <= 2 ? lonsym_sweep_kernel<2, 8, 1024> : lonsym_sweep_kernel<4, 8, 1024>;
+}
+
+typedef void (*lonsymh_fn_t)(LonHarmGeom, SweepArgs, const double *);
+static lonsymh_fn_t lonsymh_fn(int rw)
+{
+    return rw <= 1 ? lonsymh_sweep_kernel<1> : rw == 2 ? lonsymh_sweep_kernel<2> : rw == 3 ? lonsymh_sweep_kernel<3> : lonsymh_sweep_kernel<4>;
 }
 
 static LonSymGeom lonsym_geom(const gh_ctx *c)
@@ -222,12 +228,13 @@ static int lonsym_build(gh_ctx *c)
     // correlations of lonsym.hip.h (also the fallback for geometries beyond these limits).
     h.harm = false;
     h.nf = (int)n / 2 + 1;
-    h.hlds = lonsymh_lds_doubles((int)n, h.nf, (int)na) * sizeof(double);
+    // (one workgroup per CU at most -- its T^ rows and accumulators take the CU's registers -- every one with the
+    // same number of cell rows, up to four of them at once)
+    const int rp = (int)((nc + (int64_t)c->cus - 1) / (int64_t)c->cus);
+    h.rw = std::min(rp, 4);
+    h.hlds = lonsymh_lds_doubles((int)n, h.nf, (int)na, h.rw) * sizeof(double);
     if (env_int("GRAVHMC_LONSYM_HARMONIC", 1) != 0 && h.nf <= 64 && na <= 4 * LH_AK && n <= 1024 && h.hlds <= 160 * 1024 - 512 &&
-        allow_dynamic_lds(reinterpret_cast<const void *>(lonsymh_sweep_kernel), h.hlds) == hipSuccess) {
-        // (one workgroup per CU at most -- its T^ rows and accumulators take the CU's registers -- every one with
-        // the same number of cell rows)
-        const int rp = (int)((nc + (int64_t)c->cus - 1) / (int64_t)c->cus);
+        allow_dynamic_lds(reinterpret_cast<const void *>(lonsymh_fn(h.rw)), h.hlds) == hipSuccess) {
         h.hgrid = (int)((nc + rp - 1) / rp);
         TRY(dalloc(c, &h.tw, (size_t)n, false));
         TRY(dalloc(c, &h.That, (size_t)nc * (size_t)na * (size_t)h.nf, false));
@@ -284,7 +291,7 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
         // harmonic domain: R^ in front of the pass, the finished slab row (and the classes' sums) behind it
         const LonHarmGeom g = lonsymh_geom(c);
         if (a.mode & SW_ADJ) lonsymh_rhat_kernel<<<dim3((unsigned)h.na), dim3(256), 0, c->stream>>>(g, a.r);
-        hipLaunchKernelGGL(lonsymh_sweep_kernel, dim3((unsigned)h.hgrid), dim3(LH_THREADS), h.hlds, c->stream, g, a,
+        hipLaunchKernelGGL(lonsymh_fn(h.rw), dim3((unsigned)h.hgrid), dim3(LH_THREADS), h.hlds, c->stream, g, a,
                            c->weighted ? c->wm : nullptr);
         if (a.mode & SW_FWD)
             lonsymh_post_kernel<<<dim3((unsigned)h.na), dim3(512), 0, c->stream>>>(g, h.hgrid, c->ld, a.slab, a.dsum);

@@ -42,9 +42,9 @@ struct LonHarmGeom {
 constexpr int LH_THREADS = 256;
 constexpr int LH_AK = 16;  // classes per thread: na <= 4 * LH_AK; nf <= 64
 
-static inline size_t lonsymh_lds_doubles(int n, int nf, int na)
+static inline size_t lonsymh_lds_doubles(int n, int nf, int na, int rw)
 {
-    return 2 * (size_t)na * nf + 2 * (size_t)n + 8 * (size_t)nf + 2 * (size_t)nf + (size_t)n + 8 * (size_t)nf + 4 * (size_t)n + 16;
+    return 2 * (size_t)na * nf + 2 * (size_t)n + (size_t)rw * (8 * (size_t)nf + 2 * (size_t)nf + (size_t)n + 8 * (size_t)nf) + 16;
 }
 
 // T^[c][a][f] = sum_delta T[c][a][delta] e^{-2 pi i f delta / n}: one block per (c, a) row of the table
@@ -178,21 +178,26 @@ __global__ void __launch_bounds__(256) lonsymh_rhat_kernel(LonHarmGeom g, const 
 }
 
 // The fused pass (modes of SweepArgs as lonsym_sweep_kernel).  Thread (f = tid & 63, ag = tid >> 6) holds the
-// classes ag * LH_AK + u of its frequency.
+// classes ag * LH_AK + u of its frequency.  A workgroup works on RW cell rows AT ONCE (rows blockIdx.x +
+// r * gridDim.x): all their T^ rows are requested up front (RW x 16 loads of 16 bytes per thread in flight:
+// the table arrives in one burst, at the memory system's rate) and every phase -- products, transforms,
+// update -- covers the RW rows between two barriers: four barriers per group of rows instead of five per
+// row, and no phase waits for a row's data.  (One row at a time, the next row's table prefetched: 25 us per
+// pass at C4; the phases of a single row are too short to hide an LDS or memory round trip each.)
+template <int RW>
 __global__ void __launch_bounds__(LH_THREADS) lonsymh_sweep_kernel(LonHarmGeom g, SweepArgs a, const double *__restrict__ wm)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, f = tid & 63, ag = tid >> 6;
     const int n = g.n, nf = g.nf, na = g.na;
     const int mode = a.mode;
-    d2 *Rh = reinterpret_cast<d2 *>(smem);            // na x nf
-    d2 *tws = Rh + (size_t)na * nf;                    // n
-    d2 *Gp = tws + n;                                  // 4 x nf partial S^ of the class groups
-    d2 *Gh = Gp + 4 * nf;                              // nf
-    double *xs = reinterpret_cast<double *>(Gh + nf);  // n
-    d2 *Xp = reinterpret_cast<d2 *>(xs + n);           // 4 x nf partial X^ of the longitude quarters
-    double *Sp = reinterpret_cast<double *>(Xp + 4 * nf);  // 4 x n partial inverse transforms (frequency ranges)
-    double *red = Sp + 4 * n;
+    d2 *Rh = reinterpret_cast<d2 *>(smem);                   // na x nf
+    d2 *tws = Rh + (size_t)na * nf;                           // n
+    d2 *Gp = tws + n;                                         // RW x 4 x nf partial S^ of the class groups
+    d2 *Gh = Gp + RW * 4 * nf;                                // RW x nf
+    double *xs = reinterpret_cast<double *>(Gh + RW * nf);    // RW x n
+    d2 *Xp = reinterpret_cast<d2 *>(xs + RW * n);             // RW x 4 x nf partial X^ of the longitude quarters
+    double *red = reinterpret_cast<double *>(Xp + RW * 4 * nf);
     const bool fv = f < nf;
     __shared__ long long tph_s[9];
     const bool clk = g.dbg != nullptr && blockIdx.x == 0 && tid == 0;
@@ -207,171 +212,179 @@ __global__ void __launch_bounds__(LH_THREADS) lonsymh_sweep_kernel(LonHarmGeom g
             tph_s[8] = now;
         }
     };
-
-    for (int e = tid; e < n; e += LH_THREADS) tws[e] = g.tw[e];
-    if (mode & SW_ADJ) {
-        // (eight loads in flight per thread)
-        const int tot = na * nf;
-        for (int e0 = 0; e0 < tot; e0 += 8 * LH_THREADS) {
-            d2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * LH_THREADS + tid;
-                v[u] = g.Rhat[e < tot ? e : tot - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * LH_THREADS + tid;
-                if (e < tot) Rh[e] = v[u];
-            }
-        }
-    }
-    d2 th[LH_AK], dacc[LH_AK];
+    constexpr int NI = (RW * 128 + LH_THREADS - 1) / LH_THREADS;  // (row, longitude) items per thread (n <= 126)
+    d2 dacc[LH_AK];
 #pragma unroll
     for (int u = 0; u < LH_AK; ++u) dacc[u] = d2{0.0, 0.0};
-    auto t_fetch = [&](int c, d2 (&dst)[LH_AK]) {
-        const d2 *Tg = g.That + (int64_t)c * na * nf;
-#pragma unroll
-        for (int u = 0; u < LH_AK; ++u) {
-            const int aa = ag * LH_AK + u;
-            dst[u] = (fv && aa < na) ? Tg[aa * nf + f] : d2{0.0, 0.0};
-        }
-    };
     double pp = 0.0;
     const int qn = (n + 3) / 4;  // longitudes per quarter of the forward transform
-    const int np = (LH_THREADS / n) < 1 ? 1 : ((LH_THREADS / n) > 4 ? 4 : LH_THREADS / n);  // frequency ranges of the inverse one
-    const int fpp = (nf + np - 1) / np;
-    if ((int)blockIdx.x < g.nc) t_fetch(blockIdx.x, th);
-    __syncthreads();
-    mark(0);
-    for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
-        // the operands of this row's update (thread tid < n: cell (c, tid))
-        const int64_t j = (int64_t)c * n + tid;
-        double u_w = 1.0, u_x = 0.0, u_g = 0.0, u_p = 0.0, u_pn = 0.0, u_hi = 0.0, u_lo = 0.0;
-        if (tid < n) {
-            u_w = wm ? wm[j] : 1.0;
-            u_x = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+    bool first = true;
+    for (int base = blockIdx.x; base < g.nc; base += gridDim.x * RW) {
+        // ---- requests: the rows' table, R^, the twiddles, the operands of the rows' updates
+        d2 th[RW][LH_AK];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int c = base + r * gridDim.x;
+            const d2 *Tg = g.That + (int64_t)(c < g.nc ? c : base) * na * nf;
+#pragma unroll
+            for (int u = 0; u < LH_AK; ++u) {
+                const int aa = ag * LH_AK + u;
+                th[r][u] = (fv && aa < na && c < g.nc) ? Tg[aa * nf + f] : d2{0.0, 0.0};
+            }
+        }
+        if (first) {
+            for (int e = tid; e < n; e += LH_THREADS) tws[e] = g.tw[e];
             if (mode & SW_ADJ) {
-                u_g = a.greg ? a.greg[j] : 0.0;
-                if (mode & (SW_PFIN | SW_UPD)) u_p = a.p_in[j];
-                if (mode & SW_SPEC) u_pn = a.pn_in[j];
-                if (mode & SW_UPD) {
-                    u_hi = a.high[j];
-                    u_lo = a.low[j];
+                const int tot = na * nf;
+                for (int e0 = 0; e0 < tot; e0 += 8 * LH_THREADS) {
+                    d2 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u * LH_THREADS + tid;
+                        v[u] = g.Rhat[e < tot ? e : tot - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u * LH_THREADS + tid;
+                        if (e < tot) Rh[e] = v[u];
+                    }
+                }
+            }
+            first = false;
+        }
+        // items (row r, longitude k) of this thread: it = tid + q * LH_THREADS -> r = it / n, k = it % n
+        int64_t ij[NI];
+        bool iv[NI];
+        double u_w[NI], u_x[NI], u_g[NI], u_p[NI], u_pn[NI], u_hi[NI], u_lo[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int it = tid + q * LH_THREADS, r = it / n, k = it - r * n;
+            const int c = base + r * gridDim.x;
+            iv[q] = r < RW && c < g.nc;
+            ij[q] = (int64_t)(iv[q] ? c : base) * n + k;
+            u_w[q] = 1.0;
+            u_x[q] = u_g[q] = u_p[q] = u_pn[q] = u_hi[q] = u_lo[q] = 0.0;
+            if (iv[q]) {
+                const int64_t j = ij[q];
+                u_w[q] = wm ? wm[j] : 1.0;
+                u_x[q] = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+                if (mode & SW_ADJ) {
+                    u_g[q] = a.greg ? a.greg[j] : 0.0;
+                    if (mode & (SW_PFIN | SW_UPD)) u_p[q] = a.p_in[j];
+                    if (mode & SW_SPEC) u_pn[q] = a.pn_in[j];
+                    if (mode & SW_UPD) {
+                        u_hi[q] = a.high[j];
+                        u_lo[q] = a.low[j];
+                    }
                 }
             }
         }
-        double xj = u_x, iwj = 1.0;
-        if (tid < n) iwj = (u_w != 0.0) ? 1.0 / u_w : 1.0;
+        __syncthreads();  // Rh, tws in place (first group); the previous group is done with Gp / xs / Xp
+        mark(0);
         if (mode & SW_ADJ) {
-            // S^[f] = sum_a conj(T^[a][f]) R^[a][f]: this thread's classes, then the four groups
-            d2 gp = d2{0.0, 0.0};
+            // S^_r[f] = sum_a conj(T^_r[a][f]) R^[a][f]: this thread's classes, all rows from one read of R^
             if (fv) {
                 d2 rr[LH_AK];
 #pragma unroll
                 for (int u = 0; u < LH_AK; ++u) {
                     const int aa = ag * LH_AK + u;
-                    rr[u] = Rh[(aa < na ? aa : na - 1) * nf + f];   // (classes past the last: th is zero there)
+                    rr[u] = Rh[(aa < na ? aa : na - 1) * nf + f];  // (classes past the last: th is zero there)
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < LH_AK; ++u) {
-                    gp.x += th[u].x * rr[u].x + th[u].y * rr[u].y;
-                    gp.y += th[u].x * rr[u].y - th[u].y * rr[u].x;
+                for (int r = 0; r < RW; ++r) {
+                    d2 gp = d2{0.0, 0.0};
+#pragma unroll
+                    for (int u = 0; u < LH_AK; ++u) {
+                        gp.x += th[r][u].x * rr[u].x + th[r][u].y * rr[u].y;
+                        gp.y += th[r][u].x * rr[u].y - th[r][u].y * rr[u].x;
+                    }
+                    Gp[(r * 4 + ag) * nf + f] = gp;
                 }
-                Gp[ag * nf + f] = gp;
             }
             mark(1);
             __syncthreads();
-            if (tid < nf) {
-                d2 s = Gp[tid];
+            for (int e = tid; e < RW * nf; e += LH_THREADS) {
+                const int r = e / nf, ff = e - r * nf;
+                d2 s = Gp[(r * 4) * nf + ff];
 #pragma unroll
                 for (int q = 1; q < 4; ++q) {
-                    s.x += Gp[q * nf + tid].x;
-                    s.y += Gp[q * nf + tid].y;
+                    s.x += Gp[(r * 4 + q) * nf + ff].x;
+                    s.y += Gp[(r * 4 + q) * nf + ff].y;
                 }
                 // weight of the frequency in the inverse transform of a real sequence
-                const double wf = (tid == 0 || (2 * tid == n)) ? 1.0 : 2.0;
-                Gh[tid] = d2{s.x * wf, s.y * wf};
+                const double wf = (ff == 0 || (2 * ff == n)) ? 1.0 : 2.0;
+                Gh[e] = d2{s.x * wf, s.y * wf};
             }
             __syncthreads();
             mark(2);
-            // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}): the frequencies in np ranges, one per
-            // group of n threads, summed in range order
-            {
-                const int part = tid / n, k = tid - part * n;
-                if (part < np) {
-                    const int f0 = part * fpp, f1 = (f0 + fpp < nf) ? f0 + fpp : nf;
-                    Sp[part * n + k] = lh_idft_part(Gh, tws, f0 < nf ? f0 : nf, f1, k, n);
-                }
-            }
-            __syncthreads();
-            if (tid < n) {
-                double s = Sp[tid];
-                for (int q = 1; q < np; ++q) s += Sp[q * n + tid];
+        }
+        // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}), gradient, update (hmc.py:114-152)
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int it = tid + q * LH_THREADS, r = it / n, k = it - r * n;
+            double xj = u_x[q];
+            const double iwj = (u_w[q] != 0.0) ? 1.0 / u_w[q] : 1.0;
+            if ((mode & SW_ADJ) && iv[q]) {
+                const int64_t j = ij[q];
+                const double s = lh_idft_part(Gh + r * nf, tws, 0, nf, k, n);
                 const double t = (s / (double)n) * iwj;
-                const double grad = 2.0 * t + u_g;
+                const double grad = 2.0 * t + u_g[q];
                 if (mode & SW_GOUT) a.g_out[j] = grad;
                 if (mode & SW_PFIN) {
-                    const double pf = u_p - a.c_p * grad;
+                    const double pf = u_p[q] - a.c_p * grad;
                     pp += pf * pf;
                     if (!(mode & SW_SPEC)) a.p_out[j] = pf;
                 }
                 if (mode & SW_UPD) {
-                    const double psrc = (mode & SW_SPEC) ? u_pn : u_p;
+                    const double psrc = (mode & SW_SPEC) ? u_pn[q] : u_p[q];
                     double pj = psrc - a.c_u * grad;
                     xj = xj + a.dt * pj;
-                    if (xj > u_hi) {
-                        xj = u_hi;
+                    if (xj > u_hi[q]) {
+                        xj = u_hi[q];
                         pj = -pj;
-                    } else if (xj < u_lo) {
-                        xj = u_lo;
+                    } else if (xj < u_lo[q]) {
+                        xj = u_lo[q];
                         pj = -pj;
                     }
                     a.p_out[j] = pj;
                     a.x_out[j] = xj;
                 }
             }
+            if ((mode & SW_FWD) && r < RW) xs[r * n + k] = iv[q] ? xj * iwj : 0.0;
         }
         mark(3);
-        // the next row's table: in flight behind the forward below
-        d2 thn[LH_AK];
-        const bool more = c + (int)gridDim.x < g.nc;
-        if (more) t_fetch(c + gridDim.x, thn);
         if (mode & SW_FWD) {
-            if (tid < n) xs[tid] = xj * iwj;
             __syncthreads();
-            // X^[f] = sum_k xs[k] e^{-2 pi i f k / n}: quarter ag of the longitudes, then the four quarters
+            // X^_r[f] = sum_k xs_r[k] e^{-2 pi i f k / n}: quarter ag of the longitudes, then the four quarters
             if (fv) {
                 const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
-                Xp[ag * nf + f] = lh_dft_part(xs, tws, k0 < n ? k0 : n, k1, f, n);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) Xp[(r * 4 + ag) * nf + f] = lh_dft_part(xs + r * n, tws, k0 < n ? k0 : n, k1, f, n);
             }
             mark(4);
             __syncthreads();
             if (fv) {
-                d2 xh = Xp[f];
 #pragma unroll
-                for (int q = 1; q < 4; ++q) {
-                    xh.x += Xp[q * nf + f].x;
-                    xh.y += Xp[q * nf + f].y;
-                }
+                for (int r = 0; r < RW; ++r) {
+                    d2 xh = Xp[(r * 4) * nf + f];
 #pragma unroll
-                for (int u = 0; u < LH_AK; ++u) {
-                    dacc[u].x += th[u].x * xh.x - th[u].y * xh.y;
-                    dacc[u].y += th[u].x * xh.y + th[u].y * xh.x;
+                    for (int q = 1; q < 4; ++q) {
+                        xh.x += Xp[(r * 4 + q) * nf + f].x;
+                        xh.y += Xp[(r * 4 + q) * nf + f].y;
+                    }
+#pragma unroll
+                    for (int u = 0; u < LH_AK; ++u) {
+                        dacc[u].x += th[r][u].x * xh.x - th[r][u].y * xh.y;
+                        dacc[u].y += th[r][u].x * xh.y + th[r][u].y * xh.x;
+                    }
                 }
             }
         }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < LH_AK; ++u) th[u] = thn[u];
-        }
         mark(5);
-        __syncthreads();  // (Gp / xs / Xp of this row are done with before the next row writes them)
-        mark(6);
     }
     if (mode & SW_PFIN) {
-        const double t = block_allreduce_sum(tid < n ? pp : 0.0, red, LH_THREADS / 64);
+        const double t = block_allreduce_sum(pp, red, LH_THREADS / 64);
         if (tid == 0) a.pp_part[blockIdx.x] = t;
     }
     if ((mode & SW_FWD) && fv) {

@@ -118,6 +118,17 @@ int gh_set_shift_invariant(gh_ctx *ctx, int enable);
 /* The structure gh_build_G found: longitudes per cell row, observation classes (distinct latitude /
  * height pairs), cell rows, bytes of the table (all 0 when the store is not in use). */
 int gh_shift_invariant_info(const gh_ctx *ctx, int *n_lon, int *n_classes, int *n_rows, int64_t *table_bytes);
+/* The store in the longitude-harmonic domain (csrc/lonsymh.hip.h; the default where the geometry allows it: at
+ * most 126 longitudes per cell row and 64 observation classes; GRAVHMC_LONSYM_HARMONIC=0 keeps the direct
+ * correlations): a circular correlation along the longitude is a product per frequency of length-n DFTs, so
+ * forward and adjoint cost n_rows x n_classes x (n / 2 + 1) complex multiply-adds each instead of N M real ones
+ * (C4: 2.2e6 against 5.3e8) from a complex table T^[row][class][frequency] of the same size, read once per
+ * leapfrog step; the clamp-and-reflect update (hmc.py:135-141) happens at the longitudes, between an inverse
+ * and a forward transform inside the cell row's workgroup.  on, frequencies n / 2 + 1, bytes of T^, workgroups
+ * of the pass.  gh_batch_* on a shift-invariant context (BASELINE configs[3]: 8 chains) runs every chain as a
+ * light context of its own -- stream, chain state, work buffers -- on the shared tables, one host thread per
+ * chain; nothing stays in flight between calls (n_started = n_done = T in carry-over mode). */
+int gh_shift_invariant_harmonic(const gh_ctx *ctx, int *on, int *n_freq, int64_t *table_bytes, int *workgroups);
 /* Work of the matrix-free passes since gh_profile_enable(ctx, 1) (fused form only): entries
  * evaluated, 2x2x2 Gauss-Legendre leaves evaluated (tesseroids; = entries for prisms), launches.
  * Tesseroids: the pairs that need the reference's adaptive subdivision (_tesseroid_numba.py:135-157)
