@@ -575,6 +575,10 @@ def main():
                          "all-reduce of the forward partial per step (strong scaling); default "
                          "is one independent chain per GPU (weak scaling)")
     ap.add_argument("--shard-backend", default="rccl", choices=["rccl", "gloo"])
+    ap.add_argument("--shard-axis", default="cells", choices=["cells", "rows"],
+                    help="--shard: what is split over the ranks -- the cells (column blocks of G: all-reduce of N + 2 doubles "
+                         "per step, ONE read of the shard) or the observations (row blocks, BASELINE configs[4] as worded: "
+                         "all-reduce of the M-vector gradient + two scalars per step, TWO reads of the shard)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks share GPU 0 (rehearsal of the N>1 launch path on a 1-GPU box)")
     args = ap.parse_args()
@@ -617,7 +621,7 @@ def main():
     dev = 0 if args.rehearse_on_one_gpu else local_rank
     if args.shard:
         from gravinv3dhmc_amd.dist import make_sharded_engine
-        eng = make_sharded_engine(N, M, ranks, device=dev, backend=args.shard_backend)
+        eng = make_sharded_engine(N, M, ranks, device=dev, backend=args.shard_backend, axis=args.shard_axis)
     else:
         eng = g.Engine(N, M, device=dev)
     info = eng.device_info()
@@ -749,7 +753,10 @@ def main():
                        "accepted": naccept, "final_U": LAST_STATE["U"] if CPG == 1 else None,
                        "final_U_per_rank": final_U_ranks if CPG == 1 and world > 1 else None,
                        "seed": args.seed,
-                       "speculative_first_steps": eng.chain_stats() if CPG == 1 else None, "parallelism": ("1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step"
+                       "speculative_first_steps": eng.chain_stats() if CPG == 1 else None, "parallelism": (("1 chain, observations (row blocks) sharded x%d, %s all-reduce of the M-vector gradient + 2 "
+                                        "scalars per step, two reads of the shard per step"
+                                        if args.shard_axis == "rows" else
+                                        "1 chain, cells sharded x%d, %s all-reduce of N+2 doubles per step")
                                        % (world, args.shard_backend)) if args.shard
                        else "chain-parallel x%d (no collective)" % world,
                        "device": info["name"], "cus": info["cus"],

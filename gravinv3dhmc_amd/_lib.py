@@ -88,6 +88,8 @@ PROTOTYPES = {
     "gh_shard_unique_id": (C.c_int, [C.c_void_p]),
     "gh_shard_init": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
     "gh_shard_init_callback": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
+    "gh_shard_init_rows": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
+    "gh_shard_init_rows_callback": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i64, _i64]),
     "gh_shard_allreduce": (C.c_int, [_ctx, _dp, _i64]),
     "gh_rng_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
     "gh_rng_destroy": (None, [C.c_void_p]),

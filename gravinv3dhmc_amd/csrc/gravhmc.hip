@@ -378,6 +378,18 @@ int gh_weight(gh_ctx *c, double weightfactor, double *wm_out)
     } else if (c->mf) {
         mf_colnorm_kernel<<<dim3((unsigned)((c->M + 3) / 4)), dim3(256), 0, c->stream>>>(mf_geom(c), weightfactor,
                                                                                         c->wm);
+    } else if (shard_rows(c)) {
+        // row blocks: a column's norm spans the ranks -- local sums of squares, all-reduce, then the power and
+        // the scaling of the local rows
+        const unsigned blocks = (unsigned)std::min<int64_t>(c->M, (int64_t)c->cus * 16);
+        colnorm_kernel<<<dim3(blocks), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, 1.0, c->wm);
+        HIPCHK(c, hipGetLastError());
+        TRY(comm_allreduce(c, c->wm, c->M));
+        std::vector<double> ss((size_t)c->M);
+        TRY(d2h(c, ss.data(), c->wm, (size_t)c->M));
+        for (auto &v : ss) v = (weightfactor == 0.5) ? std::sqrt(v) : std::pow(v, weightfactor);
+        TRY(h2d(c, c->wm, ss.data(), (size_t)c->M));
+        colscale_kernel<<<dim3(blocks), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, c->wm);
     } else if (c->n_panels > 1) {
         const unsigned blocks = (unsigned)std::min<int64_t>(c->M, (int64_t)c->cus * 16);
         colnorm_kernel<<<dim3(blocks), dim3(256), 0, c->stream>>>(c->G, c->ld, c->M, weightfactor, c->wm);
@@ -433,7 +445,13 @@ int gh_set_data(gh_ctx *c, const double *dobs, const double *grav_fix)
             return sum(a, n2) + sum(a + n2, n - n2);
         }
     };
-    const double mean = PW::sum(t.data(), N) / (double)N;
+    double mean = PW::sum(t.data(), N) / (double)N;
+    if (shard_rows(c)) {
+        // (row blocks: the mean of ALL observations -- the sum of the ranks' pairwise sums)
+        double v2[1] = {PW::sum(t.data(), N)};
+        TRY(comm_allreduce_host(c, v2, 1));
+        mean = v2[0] / (double)c->sh.N_global;
+    }
     for (auto &v : t) v -= mean;
     TRY(h2d(c, c->dobs_c, t.data(), N));
     c->have_fix = grav_fix != nullptr;
@@ -451,7 +469,7 @@ int gh_set_reg(gh_ctx *c, int kind, double alpha, double beta, const int shape3[
     if (kind < 0 || kind > 3)
         return fail(c, GH_ERR_ARG, "Please choose regularization from 'MS','Damping', 'Smoothness', 'TV'.");
     const bool stencil = (kind == GH_REG_SMOOTHNESS || kind == GH_REG_TV);
-    if (c->sh.kind != 0 && stencil) {
+    if (shard_cols(c) && stencil) {
         // the finite-difference stencil crosses the shard boundaries: shards of whole z-planes
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->sh.M_global)
             return fail(c, GH_ERR_ARG, "gh_set_reg: Smoothness/TV on a sharded model need the GLOBAL shape nz*ny*nx == M_global");
@@ -477,7 +495,7 @@ int gh_set_reg(gh_ctx *c, int kind, double alpha, double beta, const int shape3[
         c->shape[2] = shape3[2];
     }
     c->sh.halo = false;
-    if (c->sh.kind != 0 && stencil) {
+    if (shard_cols(c) && stencil) {
         gh_ctx::Shard &sh = c->sh;
         const int64_t P = (int64_t)shape3[1] * shape3[2];
         const size_t need = (size_t)c->ld + 8 + 2 * (size_t)sh.world * (size_t)P;
@@ -531,7 +549,7 @@ int gh_forward(gh_ctx *c, const double *mw, double *dpre)
     TRY(launch_sweep(c, a));
     reduce_slab(c, nullptr, c->tmpN);
     HIPCHK(c, hipGetLastError());
-    TRY(comm_allreduce(c, c->tmpN, c->ld));
+    if (!shard_rows(c)) TRY(comm_allreduce(c, c->tmpN, c->ld));  // (row blocks: the local rows are complete)
     return d2h(c, dpre, c->tmpN, (size_t)c->N);  // (forward-only sweeps never run on teams)
 }
 
@@ -986,7 +1004,7 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
     else
         for (int t = 0; t < c->n_pp0; ++t) pp0 += h[16 + 2 * nt + t];
     double pn_pp0_g = pn_pp0;
-    if (c->sh.kind != 0) {
+    if (shard_cols(c)) {
         // kinetic energies are sums over cells: combine the ranks' parts (same bits everywhere)
         double v[4] = {pp1, use_spec ? 0.0 : pp0, spec ? pn_pp0 : 0.0, failed ? 1.0 : 0.0};
         if (failed) v[0] = v[1] = v[2] = 0.0;  // (whatever the aborted sweeps left: not worth a NaN in the sum)
@@ -2047,6 +2065,37 @@ int gh_shard_init_callback(gh_ctx *c, gh_allreduce_fn fn, void *user, int rank, 
     if (c->sh.kind != 0) return fail(c, GH_ERR_ARG, "gh_shard_init: already initialised");
     HIPCHK(c, hipSetDevice(c->device));
     TRY(shard_common_init(c, rank, world, M_global, m0));
+    c->sh.cb = fn;
+    c->sh.user = user;
+    c->sh.kind = 2;
+    return GH_OK;
+}
+
+int gh_shard_init_rows(gh_ctx *c, const void *id128, int rank, int world, int64_t N_global, int64_t n0)
+{
+    if (!c || !id128) return fail(c, GH_ERR_ARG, "gh_shard_init_rows: null pointer");
+    if (c->sh.kind != 0) return fail(c, GH_ERR_ARG, "gh_shard_init_rows: already initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(shard_rows_init(c, rank, world, N_global, n0));
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(c, GH_ERR_COMM, "%s", err.c_str());
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclResult_t r = api->CommInitRank(&c->sh.comm, world, id, rank);
+    if (r != ncclSuccess)
+        return fail(c, GH_ERR_COMM, "ncclCommInitRank: %s", api->GetErrorString ? api->GetErrorString(r) : "error");
+    c->sh.kind = 1;
+    return GH_OK;
+}
+
+int gh_shard_init_rows_callback(gh_ctx *c, gh_allreduce_fn fn, void *user, int rank, int world, int64_t N_global,
+                                int64_t n0)
+{
+    if (!c || !fn) return fail(c, GH_ERR_ARG, "gh_shard_init_rows_callback: null pointer");
+    if (c->sh.kind != 0) return fail(c, GH_ERR_ARG, "gh_shard_init_rows: already initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(shard_rows_init(c, rank, world, N_global, n0));
     c->sh.cb = fn;
     c->sh.user = user;
     c->sh.kind = 2;

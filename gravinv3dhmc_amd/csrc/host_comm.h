@@ -42,6 +42,9 @@ static RcclApi *rccl_api(std::string &err)
     return &api;
 }
 
+static bool shard_cols(const gh_ctx *c) { return c->sh.kind != 0 && c->sh.axis == 0; }
+static bool shard_rows(const gh_ctx *c) { return c->sh.kind != 0 && c->sh.axis == 1; }
+
 // In-place sum over ranks of `count` doubles at device pointer `buf`, ordered on the stream.
 static int comm_allreduce(gh_ctx *c, double *buf, int64_t count)
 {
@@ -99,5 +102,35 @@ static int shard_common_init(gh_ctx *c, int rank, int world, int64_t M_global, i
     c->chain_ready = false;
     c->bt.ready = false;
     c->rs.state = 0;  // a context that ran unsharded before must not keep the resident chain kernel
+    return GH_OK;
+}
+
+// Row blocks (BASELINE configs[4] as it is worded: "G row-block sharded ... RCCL reduce ... for the misfit sum";
+// SURVEY 8e.2): this context holds the observations [n0, n0 + N) of N_global and ALL cells.  Model vectors are
+// replicated; a column's dot with r spans the ranks, so the gradient (M doubles) is all-reduced between the
+// adjoint pass and the update, and the step reads the local shard twice (adjoint pass, forward pass).
+static int shard_rows_init(gh_ctx *c, int rank, int world, int64_t N_global, int64_t n0)
+{
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, GH_ERR_ARG, "gh_shard_init_rows: bad rank/world");
+    if (n0 < 0 || n0 + c->N > N_global) return fail(c, GH_ERR_ARG, "gh_shard_init_rows: observation range outside the problem");
+    if (c->mf) return fail(c, GH_ERR_UNSUPPORTED, "row blocks need the stored kernel");
+    if (c->wv.on) return fail(c, GH_ERR_UNSUPPORTED, "sharding with the wavelet forward is not supported");
+    c->sh.axis = 1;
+    c->sh.rank = rank;
+    c->sh.world = world;
+    c->sh.N_global = N_global;
+    c->sh.n0 = n0;
+    c->sh.M_global = c->M;
+    c->sh.m0 = 0;
+    const size_t need = (size_t)std::max<int64_t>(c->ld + 8, c->M);
+    TRY(dalloc(c, &c->sh.buf, need));
+    if (!c->sh.hbuf) HIPCHK(c, hipHostMalloc((void **)&c->sh.hbuf, sizeof(double) * need));
+    c->sh.buf_n = need;
+    TRY(dalloc(c, &c->sh.rbuf, 8));
+    // (the partial sums of p'p come from vec_update_kernel: one per 256 cells)
+    c->n_teams = std::max(c->n_teams, (int)((c->M + 255) / 256));
+    c->chain_ready = false;
+    c->bt.ready = false;
+    c->rs.state = -1;  // (the resident chain kernel has no exchange between GPUs)
     return GH_OK;
 }

@@ -148,6 +148,9 @@ struct gh_ctx {
     // summed across ranks once per potential evaluation.
     struct Shard {
         int kind = 0;  // 0 single GPU, 1 RCCL all-reduce on the stream, 2 host callback
+        int axis = 0;  // 0: the CELLS (columns of G) are split over the ranks; 1: the OBSERVATIONS (rows of G)
+        int64_t N_global = 0, n0 = 0;  // axis 1: observations of the whole problem, first one of this rank
+        double *rbuf = nullptr;        // axis 1: {sum of d + grav_fix, |r|^2} on their way through the all-reduces
         int rank = 0, world = 1;
         int64_t M_global = 0, m0 = 0;
         ncclComm_t comm = nullptr;

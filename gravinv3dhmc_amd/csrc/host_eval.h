@@ -43,6 +43,34 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
     int n_regpart = c->n_regpart;
     const double *src;
     int nseg;
+    if (shard_rows(c)) {
+        // observations sharded over the ranks: d, r of the local rows; the mean and |r|^2 are sums over all
+        // ranks (two scalar all-reduces); the regulariser is replicated with the model
+        reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
+        RowsFinishArgs fa{};
+        fa.N = c->N;
+        fa.ld = c->ld;
+        fa.N_global = c->sh.N_global;
+        fa.nseg = c->slab_live > 0 ? c->slab_live : c->grid;
+        fa.n_regpart = c->n_regpart;
+        fa.src = c->slab;
+        fa.gfix = gfix;
+        fa.dobs_c = c->dobs_c;
+        fa.regpart = c->regpart;
+        fa.alpha = c->alpha;
+        fa.d = d_out;
+        fa.r = r_out;
+        fa.scal = scal_out;
+        fa.rbuf = c->sh.rbuf;
+        rows_stage_a_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(fa);
+        TRY(comm_allreduce(c, c->sh.rbuf, 1));
+        rows_stage_b_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(fa);
+        TRY(comm_allreduce(c, c->sh.rbuf + 1, 1));
+        rows_stage_c_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(fa);
+        HIPCHK(c, hipGetLastError());
+        o.pending = false;
+        return GH_OK;
+    }
     if (c->sh.kind != 0) {
         // sharded cells: local forward partial and local regulariser sum travel in ONE
         // all-reduce, then every rank finishes the (replicated) data part identically
@@ -174,7 +202,7 @@ static int ensure_work(gh_ctx *c)
     TRY(dalloc(c, &c->pb[0], M));
     TRY(dalloc(c, &c->pb[1], M));
     TRY(dalloc(c, &c->pn, M));
-    if (c->n_panels > 1) TRY(dalloc(c, &c->gbuf, M));
+    if (c->n_panels > 1 || shard_rows(c)) TRY(dalloc(c, &c->gbuf, M));
     // (N > 16384: the team sweep writes one slab row per team, up to 128, whatever the panel grid)
     TRY(dalloc(c, &c->slab, (size_t)(c->n_panels > 1 ? std::max(c->grid, 128) : c->grid) * ld));
     if (c->grid > 64) {

@@ -263,6 +263,8 @@ static int build_near_table(gh_ctx *c)
 static bool mft_plan(gh_ctx *c);                     // host_batch.h: one chain on teams (mf_team_kernel)
 static int mft_launch(gh_ctx *c, SweepArgs &a);
 static int launch_lonsym(gh_ctx *c, SweepArgs &a);  // host_lonsym.h
+static bool shard_rows(const gh_ctx *c);                            // host_comm.h
+static int comm_allreduce(gh_ctx *c, double *buf, int64_t count);
 static bool lonsym_on(const gh_ctx *c);
 static bool lonsym_harmonic(const gh_ctx *c);
 static int lonsym_classes(const gh_ctx *c);
@@ -540,6 +542,44 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
             c->dsum_n = lonsym_classes(c);
         }
         return launch_mf(c, a);
+    }
+    if (shard_rows(c)) {
+        // Row blocks: the dot of a column with r spans the ranks.  Adjoint of the local rows (panel by panel)
+        // into the gradient buffer -- alpha grad R added by rank 0 only --, all-reduce of its M doubles,
+        // elementwise update (replicated: every rank holds the whole model), forward of the local rows: TWO
+        // reads of the local shard per leapfrog step.
+        const SweepArgs full = a;
+        auto panel = [&](SweepArgs &s, int p) {
+            s.row0 = (int64_t)p * c->panel_rows;
+            s.rows = c->n_panels == 1 ? c->ld : std::min<int64_t>(c->panel_rows, c->ld - s.row0);
+        };
+        if (full.mode & SW_ADJ) {
+            double *gdst = (full.mode & SW_GOUT) ? full.g_out : c->gbuf;
+            for (int p = 0; p < c->n_panels; ++p) {
+                SweepArgs s = full;
+                s.mode = SW_ADJ | SW_GOUT | (p ? SW_GACC : 0);
+                s.greg = (p == 0 && c->sh.rank == 0) ? full.greg : nullptr;
+                s.g_out = gdst;
+                panel(s, p);
+                TRY(launch_sweep_one(c, s));
+            }
+            TRY(comm_allreduce(c, gdst, c->M));
+            if (full.mode & (SW_UPD | SW_PFIN)) {
+                SweepArgs u = full;
+                vec_update_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(u, gdst, c->M, c->n_teams);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+        if (full.mode & SW_FWD) {
+            for (int p = 0; p < c->n_panels; ++p) {
+                SweepArgs s = full;
+                s.mode = SW_FWD;
+                s.x_in = (full.mode & SW_UPD) ? full.x_out : full.x_in;
+                panel(s, p);
+                TRY(launch_sweep_one(c, s));
+            }
+        }
+        return GH_OK;
     }
     if (c->n_panels == 1) {
         a.row0 = 0;

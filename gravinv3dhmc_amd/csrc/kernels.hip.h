@@ -873,6 +873,66 @@ __global__ void __launch_bounds__(256) vec_update_kernel(SweepArgs a, const doub
     }
 }
 
+// ---- epilogue of an evaluation with the observations sharded over ranks (row blocks): the mean of d + grav_fix
+// and |r|^2 are sums over ALL observations -- two scalar all-reduces sit between these three single-block stages
+struct RowsFinishArgs {
+    int64_t N, ld, N_global;
+    int nseg, n_regpart;
+    const double *src;      // nseg x ld partial forward products of the local rows
+    const double *gfix, *dobs_c, *regpart;
+    double alpha;
+    double *d, *r, *scal;
+    double *rbuf;           // [0] local / global sum of d + grav_fix, [1] local / global |r|^2
+};
+
+__global__ void __launch_bounds__(1024) rows_stage_a_kernel(RowsFinishArgs a)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < a.ld; i += 1024) {
+        double di = 0.0;
+        for (int q = 0; q < a.nseg; ++q) di += a.src[(int64_t)q * a.ld + i];
+        a.d[i] = di;
+        if (i < a.N) s += di + (a.gfix ? a.gfix[i] : 0.0);
+    }
+    const double t = block_allreduce_sum(s, red, 16);
+    if (threadIdx.x == 0) a.rbuf[0] = t;
+}
+
+__global__ void __launch_bounds__(1024) rows_stage_b_kernel(RowsFinishArgs a)
+{
+    __shared__ double red[16];
+    const double mean = a.rbuf[0] / (double)a.N_global;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < a.ld; i += 1024) {
+        double ri = 0.0;
+        if (i < a.N) {
+            const double dinv = a.d[i] + (a.gfix ? a.gfix[i] : 0.0);
+            ri = (dinv - mean) - a.dobs_c[i];
+        }
+        a.r[i] = ri;
+        s += ri * ri;
+    }
+    const double t = block_allreduce_sum(s, red, 16);
+    if (threadIdx.x == 0) {
+        a.rbuf[1] = t;
+        a.scal[3] = mean;
+    }
+}
+
+__global__ void __launch_bounds__(1024) rows_stage_c_kernel(RowsFinishArgs a)
+{
+    __shared__ double red[16];
+    double sr = 0.0;
+    for (int t = threadIdx.x; t < a.n_regpart; t += 1024) sr += a.regpart[t];
+    const double R = block_allreduce_sum(sr, red, 16);
+    if (threadIdx.x == 0) {
+        a.scal[0] = a.rbuf[1];
+        a.scal[1] = R;
+        a.scal[2] = a.rbuf[1] + a.alpha * R;
+    }
+}
+
 // column norms / scaling without keeping a column in registers (any N): one workgroup per column
 __global__ void __launch_bounds__(256)
 colnorm_kernel(const double *G, int64_t ld, int64_t M, double wf, double *wm)

@@ -142,13 +142,17 @@ def _engine_base():
     return Engine
 
 
-def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
-    """Engine-compatible object whose methods take and return FULL model vectors while the
+def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1, axis="cells"):
+    """axis="cells" (default): column blocks, below.  axis="rows": row blocks (make_row_sharded_engine).
+
+    Engine-compatible object whose methods take and return FULL model vectors while the
     device holds only this rank's cells.  backend: "rccl" (all-reduce on the GPU stream over
     xGMI) or "gloo" (host-staged through torch.distributed; several ranks per GPU, tests).
     align: cells per z-plane (ny*nx) to shard in whole planes, which the Smoothness/TV
     regularisers need (their stencil crosses the shard boundaries: one boundary plane per
     neighbour travels with the forward partial's all-reduce)."""
+    if axis == "rows":
+        return make_row_sharded_engine(N, M, ranks, device=device, backend=backend)
     import ctypes as C
     import numpy as np
     from . import _lib
@@ -274,3 +278,107 @@ def make_sharded_engine(N, M, ranks, device=None, backend="rccl", align=1):
             raise NotImplementedError("the sharded kernel is never gathered on one host")
 
     return ShardedEngine()
+
+
+def make_row_sharded_engine(N, M, ranks, device=None, backend="rccl"):
+    """Row blocks (BASELINE configs[4] as worded: "G row-block sharded ... RCCL reduce ... for the misfit sum";
+    SURVEY 8e.2): the device holds this rank's OBSERVATIONS (rows of G) and all cells.  The object takes and
+    returns FULL vectors: observation vectors are sliced on the way in and gathered on the way out, model
+    vectors are replicated.  Per evaluation two scalar all-reduces (mean of the predicted data, |r|^2) and an
+    all-reduce of the M-vector gradient; two reads of the local shard per leapfrog step (include/gravhmc.h,
+    gh_shard_init_rows)."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    Engine = _engine_base()
+
+    class RowShardedEngine(Engine):
+        def __init__(self):
+            self.ranks = ranks
+            self.parts = column_partition(N, ranks.world)      # (the same near-equal split, of the rows)
+            self.n0, self.n1 = self.parts[ranks.rank]
+            self.N_global, self.M_global = int(N), int(M)
+            Engine.__init__(self, self.n1 - self.n0, M, ranks.device if device is None else device)
+            self.M_local = self.M
+            self._backend = backend
+            self._sharded = False
+            self._shard()
+
+        def _shard(self):
+            """gh_shard_init_rows (collective)."""
+            if self._sharded:
+                return
+            lib = self._lib
+            if self._backend == "rccl":
+                import sys
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)      # (RCCL's banner goes to stderr: stdout carries the caller's JSON line)
+                try:
+                    idbuf = C.create_string_buffer(128)
+                    rc = lib.gh_shard_unique_id(idbuf) if ranks.rank == 0 else 0
+                    _lib.check(rc, None)
+                    raw = ranks.broadcast_bytes(idbuf.raw)
+                    idbuf = C.create_string_buffer(raw, 128)
+                    rc = lib.gh_shard_init_rows(self._h, idbuf, ranks.rank, ranks.world, self.N_global, self.n0)
+                finally:
+                    os.dup2(saved, 1)
+                    os.close(saved)
+                self._chk(rc)
+            else:
+                def _cb(_user, ptr_, count):
+                    try:
+                        arr = np.ctypeslib.as_array(ptr_, shape=(count,))
+                        arr[:] = ranks.allreduce_array(arr)
+                        return 0
+                    except Exception:
+                        return 1
+
+                self._cb = _lib.ALLREDUCE_FN(_cb)
+                self._chk(lib.gh_shard_init_rows_callback(self._h, C.cast(self._cb, C.c_void_p), None, ranks.rank,
+                                                          ranks.world, self.N_global, self.n0))
+            self._sharded = True
+
+        def _rows(self, v):
+            v = np.asarray(v, dtype=np.float64)
+            if v.shape[0] == self.N_global:
+                return np.ascontiguousarray(v[self.n0:self.n1])
+            if v.shape[0] != self.n1 - self.n0:
+                raise ValueError("expected an observation vector of %d entries" % self.N_global)
+            return v
+
+        def _gather_rows(self, local):
+            return allgather_slices(self.ranks, local, self.parts)
+
+        def set_obs(self, a, b, c):
+            Engine.set_obs(self, self._rows(a), self._rows(b), self._rows(c))
+
+        def upload_G(self, A):
+            A = np.asarray(A)
+            Engine.upload_G(self, A[self.n0:self.n1] if A.shape[0] == self.N_global else A)
+
+        def set_data(self, dobs, grav_fix=None):
+            Engine.set_data(self, self._rows(dobs), None if grav_fix is None else self._rows(grav_fix))
+
+        def forward(self, mw):
+            return self._gather_rows(Engine.forward(self, mw))
+
+        def adjoint(self, r):
+            return Engine.adjoint(self, self._rows(r))
+
+        def misfit_and_grad(self, x):
+            m, g, d, dv, mv = Engine.misfit_and_grad(self, x)
+            return m, g, self._gather_rows(d), dv, mv
+
+        def chain_get_dsyn(self):
+            return self._gather_rows(Engine.chain_get_dsyn(self))
+
+        def run_chain(self, draws, dt, on_result, **kw):
+            if self._backend != "rccl":
+                kw["overlap"] = False      # (one process group: no collective from a second thread)
+            return Engine.run_chain(self, draws, dt, on_result, **kw)
+
+        def download_G(self):
+            raise NotImplementedError("the sharded kernel is never gathered on one host")
+
+    return RowShardedEngine()

@@ -358,8 +358,8 @@ int gh_leapfrog(gh_ctx *ctx, double *x_inout, const double *p0, double dt, int L
  * kept.  Damping and MS with any partition; Smoothness / TV with shards of whole z-planes (the
  * boundary planes of the model travel in the same all-reduce, see gh_set_reg).  Every rank ends up
  * with bit-identical scalars, hence identical Metropolis decisions.  (Row blocks -- every rank a
- * slice of the observations -- would need the M-vector gradient all-reduced between the adjoint
- * and the update: two reads of G per step)
+ * slice of the observations -- need the M-vector gradient all-reduced between the adjoint and the
+ * update: two reads of the shard per step; gh_shard_init_rows below)
  *
  * RCCL flavour: rank 0 obtains a 128-byte id with gh_shard_unique_id, the launcher
  * broadcasts it, every rank calls gh_shard_init (ncclCommInitRank, collective).  The
@@ -372,6 +372,21 @@ int gh_shard_init(gh_ctx *ctx, const void *id128, int rank, int world, int64_t M
 typedef int (*gh_allreduce_fn)(void *user, double *host_buf, int64_t count);
 int gh_shard_init_callback(gh_ctx *ctx, gh_allreduce_fn fn, void *user, int rank, int world,
                            int64_t M_global, int64_t m0);
+/* Row-block sharding, BASELINE configs[4] as it is worded ("G row-block sharded ... RCCL reduce over xGMI for
+ * the misfit sum"; SURVEY 8e.2, first form): rank g creates its context with ITS observations
+ * (gh_create(N_local, M)), passes only its rows of every N-vector (obs, dobs, grav_fix; dpre comes back for its
+ * rows) and FULL model vectors, which are replicated.  Call right after gh_create / gh_build_G, before
+ * gh_weight and gh_set_data (both are collective then: a column's norm and the mean of the data span the
+ * ranks).  Per potential evaluation: the local rows' forward product, two scalar all-reduces (sum of the
+ * predicted data for the mean removal of potential.py:706, |r|^2 -- "the misfit sum") and, because a column's
+ * dot with r spans the ranks, an all-reduce of the M-vector gradient between the adjoint pass and the update
+ * -- the fused one-read sweep is not possible: TWO reads of the local shard per leapfrog step, and M doubles
+ * per step across the ranks instead of the column form's N + 2.  Updates and the regulariser are replicated
+ * (any regulariser, no halo).  Same scalars on every rank, hence identical Metropolis decisions.  Stored
+ * kernel only; no batches, no wavelet forward. */
+int gh_shard_init_rows(gh_ctx *ctx, const void *id128, int rank, int world, int64_t N_global, int64_t n0);
+int gh_shard_init_rows_callback(gh_ctx *ctx, gh_allreduce_fn fn, void *user, int rank, int world,
+                                int64_t N_global, int64_t n0);
 /* Sum of `count` (<= N) doubles in place across the ranks of the shard group (host buffers):
  * lets the host combine per-rank scalars through the same communicator. */
 int gh_shard_allreduce(gh_ctx *ctx, double *host_buf, int64_t count);

@@ -1883,8 +1883,10 @@ def test_c5_shaped_row_panels_and_column_shards_together():
     assert ab["decisions_equal"] and ab["out5"] < 1e-11 and ab["x"] < 1e-11, ab
 
 
-def test_bench_shard_rehearsal_two_ranks_one_gpu():
-    """The N > 1 launch path of bench.py as the driver starts it (torch.distributed.run, one rank per
+@pytest.mark.parametrize("axis", ["cells", "rows"])
+def test_bench_shard_rehearsal_two_ranks_one_gpu(axis):
+    """(axis: column blocks -- the cells split -- or row blocks -- the observations split, BASELINE configs[4] as
+    it is worded.)  The N > 1 launch path of bench.py as the driver starts it (torch.distributed.run, one rank per
     process), rehearsed on one GPU: ONE chain whose cells are sharded over two ranks
     (`--shard --shard-backend gloo --rehearse-on-one-gpu`) on a small C5-shaped workload (the full
     200 x 200 observation grid, 1/600 of the cells).  The JSON line must say strong scaling, count the
@@ -1907,7 +1909,7 @@ def test_bench_shard_rehearsal_two_ranks_one_gpu():
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--shard", "--shard-backend", "gloo", "--rehearse-on-one-gpu"] + common
+           "--gpus", "2", "--shard", "--shard-axis", axis, "--shard-backend", "gloo", "--rehearse-on-one-gpu"] + common
     two = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert two.returncode == 0, (two.stdout[-1000:], two.stderr[-3000:])
     lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
@@ -1919,8 +1921,8 @@ def test_bench_shard_rehearsal_two_ranks_one_gpu():
     assert sh["config"]["trajectories"] == single["config"]["trajectories"] == 3
     assert sh["config"]["accepted"] == single["config"]["accepted"]
     assert relmax(sh["config"]["final_U"], single["config"]["final_U"]) < 1e-9
-    print("bench --shard rehearsal: %.1f steps/s on 2 ranks of one GPU (gloo), unsharded %.1f; final U %r"
-          % (sh["value"], single["value"], sh["config"]["final_U"]))
+    print("bench --shard --shard-axis %s rehearsal: %.1f steps/s on 2 ranks of one GPU (gloo), unsharded %.1f; final U %r"
+          % (axis, sh["value"], single["value"], sh["config"]["final_U"]))
 
 
 def test_bench_gpus_n_launches_its_own_ranks():
