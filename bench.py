@@ -315,6 +315,9 @@ EXTRA_RUNS = [
                                                   "--chains-per-gpu", "8", "--steps", "100", "--warmup", "20"]),
     ("c5_share_of_one_gpu_of_8", ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "8", "--steps", "40",
                                   "--warmup", "10"]),
+    # (the same 96 GB as the row block one of 8 GPUs holds: 5000 observations x all 2.4e6 cells, two reads per step)
+    ("c5_share_row_blocks", ["--workload", "c5_uniform_200x200x60", "--rows-fraction", "8", "--shard", "--shard-axis", "rows",
+                             "--steps", "20", "--warmup", "10"]),
 ]
 
 
@@ -556,6 +559,9 @@ def main():
     ap.add_argument("--cells-fraction", type=int, default=1,
                     help="keep only the first 1/F of the cells: the share one of F GPUs holds when "
                          "the chain is sharded (single-GPU rehearsal of a model that exceeds one HBM)")
+    ap.add_argument("--rows-fraction", type=int, default=1,
+                    help="keep only the first 1/F of the observations: the share one of F GPUs holds when the chain is "
+                         "sharded in ROW blocks (--shard --shard-axis rows; single-GPU rehearsal)")
     ap.add_argument("--matrix-free", action="store_true",
                     help="never store G: re-evaluate the kernel entries in every pass")
     ap.add_argument("--shift-invariant", action="store_true",
@@ -617,6 +623,9 @@ def main():
     if args.cells_fraction > 1:
         keep = mesh.size // args.cells_fraction
         bounds, rho = bounds[:keep], rho[:keep]
+    if args.rows_fraction > 1:
+        keep = xp.size // args.rows_fraction
+        xp, yp, zp = xp[:keep], yp[:keep], zp[:keep]
     N, M = xp.size, bounds.shape[0]
     dev = 0 if args.rehearse_on_one_gpu else local_rank
     if args.shard:
@@ -774,6 +783,9 @@ def main():
                          "vs_stream_read_microbench": achieved / stream_gbps if stream_gbps else None},
         }
         cstat = eng.chain_stats()
+        if args.shard and args.shard_axis == "rows":
+            line["roofline"]["kernel"] = ("sweep_kernel, adjoint-only and forward-only passes over the rank's row block (the "
+                                          "gradient is all-reduced between them: two reads of the shard per leapfrog step)")
         if cstat.get("team_launches", 0) > 0:
             # N > 16384: the timed launches were team sweeps (csrc/teamsweep.hip.h)
             line["roofline"]["kernel"] = ("teamsweep_kernel (teams of %d workgroups share each column: fused "
