@@ -493,8 +493,9 @@ static int batch_alloc(gh_ctx *c)
         b.n_waves = wgs * 4;
         // One read of G per step on teams (batch_team_kernel) where the problem fits them, else -- or with
         // GRAVHMC_BATCH_TEAM=0 -- two reads and a second, operand-ordered copy of G.  Measured at C2 with 16
-        // chains on three boxes: 1 300 ... 1 360 chain-steps/s on the teams against 1 176 ... 1 195 (same box: +10 %),
-        // with 40 GB of HBM instead of 80.
+        // chains: 1 286.6 chain-steps/s on the teams against 1 187.0 in the committed driver-command record of round 3
+        // (profiles/r03/bench_c2_driver_command.json: +8.4 %, sampler level; the launches alone 11.1 ... 11.6 ms against
+        // 6.5 + 6.5), with 40 GB of HBM instead of 80.
         if (env_int("GRAVHMC_BATCH_TEAM", 1) != 0) TRY(bteam_plan(c));
         if (b.fus_on) {
             b.n_waves = std::max(b.n_waves, (b.fus_members * b.fus_ranges + 3) / 4 * 4);  // rows of pp_part
