@@ -669,11 +669,11 @@ def main():
         x0s = np.stack([0.001 * wm for _ in range(CPG)])
         eng.batch_init(x0s, low, high)
         # (trajectories offered per chain and call: the sampler's rule, inversion/hmc.py HMCSampleBatch)
-        Tmax = int(max(2, min(8, (256 << 20) // (8 * M * CPG))))
+        Tmax = int(max(2, min(32, (256 << 20) // (8 * M * CPG))))
 
         class Rounds(object):
             """Every chain runs total_steps leapfrog steps in trajectories of L (the last one shorter), through
-            the sampler's path (HMCSampleBatch): gh_batch_run in carry-over mode, up to Tmax trajectories per
+            the sampler's path (HMCSampleBatch): gh_batch_run in carry-over mode, up to Tmax (<= 32) trajectories per
             chain offered per call -- a finishing chain's last step takes the first step of the next one it
             has been offered -- the following offers drawn meanwhile, each chain from its own legacy stream
             (bit for bit np.random.RandomState(seed + chain): randn(M) * Sigma, rand() per trajectory) by the
