@@ -591,6 +591,7 @@ int gh_misfit_and_grad(gh_ctx *c, const double *x, double out3[3], double *grad,
     HIPCHK(c, hipMemcpyAsync(c->h_scal, o.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TRY(d2h(c, grad, c->tmpM, (size_t)c->M));
     if (dpre) TRY(d2h(c, dpre, o.d, (size_t)c->N));
+    TRY(lonsym_epilogue_check(c));
     out3[0] = c->h_scal[2];
     out3[1] = c->h_scal[0];
     out3[2] = c->h_scal[1];
@@ -800,6 +801,7 @@ int gh_chain_init(gh_ctx *c, const double *x0, const double *low, const double *
     TRY(eval_forward(c, c->xb[0], c->st[0]));
     TRY(scal_ready(c, c->st[0]));
     TRY(d2h(c, c->h_scal, c->st[0].scal, 4));
+    TRY(lonsym_epilogue_check(c));
     c->U_cur[0] = c->h_scal[2];
     c->U_cur[1] = c->h_scal[0];
     c->U_cur[2] = c->h_scal[1];
@@ -982,6 +984,7 @@ static int chain_trajectory_impl(gh_ctx *c, const double *p0, double dt, int L, 
     // a team sweep of this trajectory gave up (its workgroups were not all resident): nothing of
     // the chain's current state was touched -- run the trajectory again, in row panels.  Sharded
     // chain: decided by all ranks together, below (the flag rides on the scalar all-reduce)
+    TRY(lonsym_epilogue_check(c));
     bool failed = false;
     TRY(team_failed(c, &failed));
     if (!failed) TRY(mft_failed(c, &failed));  // (matrix-free chain on teams: same contract)
@@ -1224,9 +1227,16 @@ static int kids_make(gh_ctx *c, int C, const double *x0s, const double *low, con
         k->ls = new LonSymHost(*c->ls);  // (the tables are the parent's; the pass's work buffers are its own)
         k->ls->Rhat = k->ls->Dpart = nullptr;
         k->ls->dbg = nullptr;
+        k->ls->csum = nullptr;
+        k->ls->epi_abort = nullptr;
+        k->ls->rhat_of = nullptr;
+        k->ls->post_pending = false;
+        k->ls->epi_tag = 0;
         if (k->ls->harm) {
             int rc = dalloc(k, &k->ls->Rhat, (size_t)k->ls->na * (size_t)k->ls->nf);
             if (rc == GH_OK) rc = dalloc(k, &k->ls->Dpart, (size_t)k->ls->hgrid * (size_t)k->ls->na * (size_t)k->ls->nf);
+            if (rc == GH_OK && k->ls->fused) rc = dalloc(k, &k->ls->csum, 2 * (size_t)k->ls->na);
+            if (rc == GH_OK && k->ls->fused) rc = dalloc(k, &k->ls->epi_abort, 4);
             if (rc != GH_OK) return fail(c, rc, "gh_batch_init: %s", gh_last_error(k));
         }
         int rc = configure_mf(k);

@@ -8,6 +8,7 @@
 // hundreds of rows serially.
 static void reduce_slab(gh_ctx *c, const double *gfix, double *d_out)
 {
+    (void)lonsym_post_now(c);  // (harmonic shift-invariant store: the sweep left D^ partials, not a slab row)
     const int rows = c->slab_live > 0 ? c->slab_live : c->grid;
     if (rows > 64 && c->slab2) {
         const int nseg = c->slab2_rows;
@@ -43,6 +44,10 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
     int n_regpart = c->n_regpart;
     const double *src;
     int nseg;
+    // harmonic shift-invariant store: the sweep left D^ partials; either the fused epilogue below consumes them or
+    // they are turned into the slab row first
+    const bool fused_epi = lonsym_harmonic(c) && c->ls->fused && c->ls->post_pending && o.part != nullptr;
+    if (!fused_epi) TRY(lonsym_post_now(c));
     if (shard_rows(c)) {
         // observations sharded over the ranks: d, r of the local rows; the mean and |r|^2 are sums over all
         // ranks (two scalar all-reduces); the regulariser is replicated with the model
@@ -110,6 +115,37 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         reg_kernel<<<dim3(c->n_regpart), dim3(256), 0, c->stream>>>(ra);
         src = d_out;
         nseg = 1;
+    } else if (fused_epi) {
+        // harmonic shift-invariant store: partial sums -> d -> mean -> r -> R^ of the next adjoint, and the
+        // regulariser, in ONE launch (lonsymh_epilogue_kernel)
+        LonSymHost &h = *c->ls;
+        LhEpiArgs e{};
+        e.nparts = h.hgrid;
+        e.n_dpart = c->n_dpart;
+        e.ld = c->ld;
+        e.N = c->N;
+        e.gfix = gfix;
+        e.dobs_c = c->dobs_c;
+        e.d = d_out;
+        e.r = r_out;
+        e.scal = scal_out;
+        e.r2part = o.part;
+        e.csum = h.csum;
+        h.epi_tag += 1u;
+        if (h.epi_tag > 0xf0000000u) {
+            HIPCHK(c, hipMemsetAsync(h.csum, 0, sizeof(unsigned long long) * 2 * (size_t)h.na, c->stream));
+            h.epi_tag = 1u;
+        }
+        e.tag = h.epi_tag;
+        e.abort_w = h.epi_abort;
+        e.ra = ra;
+        e.ra.regpart = o.part + c->n_dpart;
+        lonsymh_epilogue_kernel<<<dim3((unsigned)(h.na + c->n_regpart)), dim3(256), 0, c->stream>>>(lonsymh_geom(c), e);
+        HIPCHK(c, hipGetLastError());
+        h.post_pending = false;
+        h.rhat_of = r_out;
+        o.pending = true;
+        return GH_OK;
     } else if (c->dsum_live && o.part) {
         // the slab rows' sums at hand (and N >= 2048): the whole epilogue in one launch
         ReduceFinishArgs fa{};

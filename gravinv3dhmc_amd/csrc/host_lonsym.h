@@ -16,6 +16,14 @@ struct LonSymHost {
     int nf = 0, hgrid = 0, rw = 1;   // rw: cell rows a workgroup of the pass works on at once
     ghk::d2 *That = nullptr, *tw = nullptr, *Rhat = nullptr, *Dpart = nullptr;
     size_t hlds = 0;
+    // the epilogue in one launch behind the sweep (lonsymh_epilogue_kernel): default with the harmonic form
+    bool fused = false;
+    bool post_pending = false;       // the sweep's D^ partials have not been turned into d yet
+    const double *rhat_of = nullptr; // the residual vector R^ was last computed from (by the fused epilogue)
+    double *post_slab = nullptr, *post_dsum = nullptr;
+    unsigned long long *csum = nullptr;
+    unsigned *epi_abort = nullptr;
+    unsigned epi_tag = 0;
     size_t lds = 0;
     int grid = 0, items = 1, W = 8, thr = 1024;  // items: work items per wave, W: longitudes per work item (instantiation of the kernel)
     std::string why;  // why the geometry does not qualify (gh_last_error text)
@@ -245,6 +253,11 @@ static int lonsym_build(gh_ctx *c)
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         h.harm = true;
+        h.fused = env_int("GRAVHMC_LONSYM_FUSED", 1) != 0;
+        if (h.fused) {
+            TRY(dalloc(c, &h.csum, 2 * (size_t)na));
+            TRY(dalloc(c, &h.epi_abort, 4));
+        }
     } else {
         (void)hipGetLastError();
     }
@@ -290,14 +303,51 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
     if (h.harm) {
         // harmonic domain: R^ in front of the pass, the finished slab row (and the classes' sums) behind it
         const LonHarmGeom g = lonsymh_geom(c);
-        if (a.mode & SW_ADJ) lonsymh_rhat_kernel<<<dim3((unsigned)h.na), dim3(256), 0, c->stream>>>(g, a.r);
+        LonSymHost &hw = *c->ls;
+        // (R^ of this very residual vector may have come with the fused epilogue that produced it)
+        if ((a.mode & SW_ADJ) && !(h.fused && a.r && h.rhat_of == a.r))
+            lonsymh_rhat_kernel<<<dim3((unsigned)h.na), dim3(256), 0, c->stream>>>(g, a.r);
         hipLaunchKernelGGL(lonsymh_fn(h.rw), dim3((unsigned)h.hgrid), dim3(LH_THREADS), h.hlds, c->stream, g, a,
                            c->weighted ? c->wm : nullptr);
-        if (a.mode & SW_FWD)
-            lonsymh_post_kernel<<<dim3((unsigned)h.na), dim3(512), 0, c->stream>>>(g, h.hgrid, c->ld, a.slab, a.dsum);
+        if (a.mode & SW_FWD) {
+            if (h.fused) {
+                hw.post_pending = true;  // finalize() turns the partials into d, r and R^ in one launch
+                hw.post_slab = a.slab;
+                hw.post_dsum = a.dsum;
+            } else {
+                lonsymh_post_kernel<<<dim3((unsigned)h.na), dim3(512), 0, c->stream>>>(g, h.hgrid, c->ld, a.slab, a.dsum);
+            }
+        }
         return GH_OK;
     }
     hipLaunchKernelGGL(lonsym_fn(h.items, h.W, h.thr), dim3((unsigned)h.grid), dim3((unsigned)h.thr), h.lds, c->stream, lonsym_geom(c), a,
                        c->weighted ? c->wm : nullptr);
     return GH_OK;
+}
+
+// The sweep's D^ partials as one finished slab row (callers that do not go through the fused epilogue:
+// gh_forward, the generic epilogues).
+static int lonsym_post_now(gh_ctx *c)
+{
+    if (!lonsym_harmonic(c) || !c->ls->post_pending) return GH_OK;
+    LonSymHost &h = *c->ls;
+    lonsymh_post_kernel<<<dim3((unsigned)h.na), dim3(512), 0, c->stream>>>(lonsymh_geom(c), h.hgrid, c->ld, h.post_slab, h.post_dsum);
+    HIPCHK(c, hipGetLastError());
+    h.post_pending = false;
+    return GH_OK;
+}
+
+// after a synchronisation point: did a fused epilogue give up waiting for its class blocks?
+static int lonsym_epilogue_check(gh_ctx *c)
+{
+    if (!lonsym_harmonic(c) || !c->ls->fused || !c->ls->epi_abort) return GH_OK;
+    unsigned w[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(w, c->ls->epi_abort, sizeof w, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (w[0] == 0u) return GH_OK;
+    HIPCHK(c, hipMemsetAsync(c->ls->epi_abort, 0, sizeof w, c->stream));
+    c->ls->fused = false;  // (the three-launch epilogue from here on)
+    c->ls->rhat_of = nullptr;
+    return fail(c, GH_ERR_HIP, "shift-invariant store: the one-launch epilogue timed out waiting for its class blocks (GPU shared?); "
+                               "the evaluation is void, the three-launch form is used from here on");
 }

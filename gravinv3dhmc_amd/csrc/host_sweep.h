@@ -267,6 +267,8 @@ static bool shard_rows(const gh_ctx *c);                            // host_comm
 static int comm_allreduce(gh_ctx *c, double *buf, int64_t count);
 static bool lonsym_on(const gh_ctx *c);
 static bool lonsym_harmonic(const gh_ctx *c);
+static int lonsym_post_now(gh_ctx *c);
+static int lonsym_epilogue_check(gh_ctx *c);
 static int lonsym_classes(const gh_ctx *c);
 static int lonsym_grid(const gh_ctx *c);
 static int64_t lonsym_table_bytes(const gh_ctx *c);

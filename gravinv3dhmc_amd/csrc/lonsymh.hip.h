@@ -23,6 +23,7 @@
 // (cos(lon - lon')), gravmag/tesseroid.py:189-232, inversion/potential.py:698,708, inversion/hmc.py:114-152.
 #pragma once
 #include "lonsym.hip.h"
+#include "resident.hip.h"
 
 namespace ghk {
 
@@ -479,6 +480,177 @@ __global__ void __launch_bounds__(512) lonsymh_post_kernel(LonHarmGeom g, int np
         for (int64_t i = g.N + tid; i < ld; i += 512) out[i] = 0.0;  // (the padding rows of the slab row)
     const double t = block_allreduce_sum(rs, red, 8);
     if (tid == 0 && dsum) dsum[a] = t;
+}
+
+// ---- the epilogue of an evaluation in ONE launch behind the sweep: what lonsymh_post_kernel, the one-launch
+// epilogue of kernels.hip.h (reduce_finish_kernel) and the NEXT pass's lonsymh_rhat_kernel do in three.
+// Blocks [0, na): class a -- sum of the sweep's D^ partials, inverse transform, the class's predicted data; the
+// mean of d + grav_fix needs every class's sum: the classes exchange them as tagged granule pairs (the data is
+// the flag; the na class blocks are the first of the grid, 256 threads each: resident together); residuals of
+// the class's observations (potential.py:700-706), their |r|^2 share, and R^[a] for the next adjoint.
+// Blocks [na, na + n_regpart): the regulariser of 256 cells each (reg_block, as in reduce_finish_kernel).
+struct LhEpiArgs {
+    int nparts, n_dpart;
+    int64_t ld, N;
+    double gfix_sum;
+    const double *gfix, *dobs_c;
+    double *d, *r, *scal;
+    double *r2part;      // n_dpart entries (class a writes entry a, the rest are zero)
+    unsigned long long *csum;  // na granule pairs: the classes' sums of d
+    unsigned tag;
+    unsigned *abort_w;
+    RegArgs ra;
+};
+
+__global__ void __launch_bounds__(256) lonsymh_epilogue_kernel(LonHarmGeom g, LhEpiArgs e)
+{
+    __shared__ d2 Dp[4][64];
+    __shared__ d2 Dh[64];
+    __shared__ d2 tws[1024];
+    __shared__ double Sp[2][1024];
+    __shared__ double row[1024];
+    __shared__ double red[8];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x;
+    const int n = g.n, nf = g.nf, na = g.na;
+    if ((int)blockIdx.x >= na) {
+        reg_block(e.ra, blockIdx.x - na, red);
+        return;
+    }
+    const int a = blockIdx.x, f = tid & 63, q = tid >> 6;
+    for (int m = tid; m < n; m += 256) tws[m] = g.tw[m];
+    if (tid == 0) ok_s = 1;
+    if (f < nf) {
+        // parts q, q + 4, ...: ten loads in flight
+        d2 s = d2{0.0, 0.0};
+        const d2 *src = g.Dpart + (int64_t)a * nf + f;
+        const int64_t stride = (int64_t)na * nf;
+        int w = q;
+        for (; w + 36 < e.nparts; w += 40) {
+            d2 v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v[u] = src[(int64_t)(w + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                s.x += v[u].x;
+                s.y += v[u].y;
+            }
+        }
+        for (; w < e.nparts; w += 4) {
+            const d2 v = src[(int64_t)w * stride];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        Dp[q][f] = s;
+    }
+    __syncthreads();
+    if (tid < nf) {
+        d2 s = Dp[0][tid];
+#pragma unroll
+        for (int u = 1; u < 4; ++u) {
+            s.x += Dp[u][tid].x;
+            s.y += Dp[u][tid].y;
+        }
+        const double wf = (tid == 0 || (2 * tid == n)) ? 1.0 : 2.0;
+        Dh[tid] = d2{s.x * wf, s.y * wf};
+    }
+    __syncthreads();
+    // inverse transform: two frequency ranges (n <= 126: two groups of n threads)
+    {
+        const int part = tid / n, m = tid - part * n, fpp = (nf + 1) / 2;
+        if (part < 2) {
+            const int f0 = part * fpp, f1 = (f0 + fpp < nf) ? f0 + fpp : nf;
+            Sp[part][m] = lh_idft_part(Dh, tws, f0 < nf ? f0 : nf, f1, m, n);
+        }
+    }
+    __syncthreads();
+    // the class's predicted data at its slots; the class's sum of d (+ grav_fix) over its observations
+    double dm = 0.0, rs = 0.0;
+    int i0 = -1;
+    if (tid < n) {
+        dm = (Sp[0][tid] + Sp[1][tid]) / (double)n;
+        const int sl = a * n + tid;
+        i0 = g.slot_first[sl];
+        if (i0 >= 0) {
+            rs += dm + (e.gfix ? e.gfix[i0] : 0.0);
+            for (int x = 0; x < g.n_xslots; ++x)
+                if (g.xslot[x] == sl)
+                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) rs += dm + (e.gfix ? e.gfix[g.xobs[qq]] : 0.0);
+        }
+    }
+    const double csum = block_allreduce_sum(rs, red, 4);
+    if (tid == 0) st_gran(e.csum + 2 * a, e.tag, csum);
+    // every class's sum -> the mean (summed in class order: identical bits in every block)
+    if (tid < 64) {
+        double tot = 0.0;
+        bool got = true;
+        for (int a0 = 0; a0 < na && got; a0 += 64) {
+            double v = 0.0;
+            const int aa = a0 + tid;
+            got = res_poll(e.abort_w, [&]() -> bool { return aa >= na || ld_gran(e.csum + 2 * aa, e.tag, v); });
+            // (lane order inside the group of 64, groups in order)
+            tot += wave_sum_dpp(v);
+        }
+        if (tid == 0) {
+            red[7] = tot;
+            if (!got) ok_s = 0;
+        }
+    }
+    __syncthreads();
+    if (ok_s == 0) return;  // (timed out: the host sees the abort word)
+    const double mean = red[7] / (double)e.N;
+    // residuals of the class's observations, R[a][m] = their sum per slot, |r|^2 share
+    double r2 = 0.0;
+    if (tid < n) {
+        double Rm = 0.0;
+        if (i0 >= 0) {
+            const int sl = a * n + tid;
+            auto one = [&](int i) {
+                const double dinv = dm + (e.gfix ? e.gfix[i] : 0.0);
+                const double ri = (dinv - mean) - e.dobs_c[i];
+                e.d[i] = dm;
+                e.r[i] = ri;
+                Rm += ri;
+                r2 += ri * ri;
+            };
+            one(i0);
+            for (int x = 0; x < g.n_xslots; ++x)
+                if (g.xslot[x] == sl)
+                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) one(g.xobs[qq]);
+        }
+        row[tid] = Rm;
+    }
+    const double r2c = block_allreduce_sum(r2, red, 4);
+    if (tid == 0) {
+        e.r2part[a] = r2c;
+        if (a == 0) e.scal[3] = mean;
+    }
+    if (a == 0) {
+        for (int t = na + tid; t < e.n_dpart; t += 256) e.r2part[t] = 0.0;
+        for (int64_t i = e.N + tid; i < e.ld; i += 256) {  // (the padding rows)
+            e.d[i] = 0.0;
+            e.r[i] = 0.0;
+        }
+    }
+    __syncthreads();  // row complete
+    // R^[a][f] for the next adjoint pass
+    {
+        const int qn = (n + 3) / 4;
+        if (f < nf) {
+            const int k0 = q * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
+            Dp[q][f] = lh_dft_part(row, tws, k0 < n ? k0 : n, k1, f, n);
+        }
+        __syncthreads();
+        if (tid < nf) {
+            d2 sres = Dp[0][tid];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                sres.x += Dp[u][tid].x;
+                sres.y += Dp[u][tid].y;
+            }
+            g.Rhat[a * nf + tid] = sres;
+        }
+    }
 }
 
 }  // namespace ghk
