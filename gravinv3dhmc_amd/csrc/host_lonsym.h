@@ -253,7 +253,11 @@ static int lonsym_build(gh_ctx *c)
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         h.harm = true;
-        h.fused = env_int("GRAVHMC_LONSYM_FUSED", 1) != 0;
+        // (the epilogue in one launch: built and tested, NOT the default -- measured at C4 it takes 21.9 us against
+        // 12.7 + 4.1 + 7.4 for the three launches it replaces, 16.4 k steps/s against 17.3 k: the sum of the sweep's
+        // 200 partials per class is latency-bound on 256 threads, and larger blocks could not all be resident
+        // when eight chains run their epilogues at once)
+        h.fused = env_int("GRAVHMC_LONSYM_FUSED", 0) != 0;
         if (h.fused) {
             TRY(dalloc(c, &h.csum, 2 * (size_t)na));
             TRY(dalloc(c, &h.epi_abort, 4));

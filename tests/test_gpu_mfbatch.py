@@ -221,8 +221,9 @@ def _global_model(G, dlon, dlat, dr, obs_h, nlat_obs_step=None):
     return mesh, lon, lat, np.full_like(lon, obs_h)
 
 
-@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size"])
-def test_shift_invariant_store_matches_the_stored_kernel(G, case):
+@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size", "c4_full_size_direct_correlations",
+                                  "c4_full_size_one_launch_epilogue"])
+def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
     """gh_set_shift_invariant: K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] for regular spherical grids
     (example/global/main_global.py:25-28; BASELINE configs[3]'s geometry) against the dense engine on the
     same problem: column norms, unweighted forward (the reference's gz), adjoint, potential + gradient
@@ -230,6 +231,12 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, case):
     (not a multiple of 8 per block boundary: 36 = 4.5 blocks), duplicated +-180 observations, shuffled
     observation order, two observation heights (classes = (lat, h) pairs)."""
     rng = np.random.default_rng(12)
+    # (default: the longitude-harmonic form with its three-launch epilogue; the direct correlations of round 3 and the
+    # one-launch epilogue -- built, not the default, DESIGN 4.9 -- stay covered)
+    if case.endswith("direct_correlations"):
+        monkeypatch.setenv("GRAVHMC_LONSYM_HARMONIC", "0")
+    if case.endswith("one_launch_epilogue"):
+        monkeypatch.setenv("GRAVHMC_LONSYM_FUSED", "1")
     if case == "coarse_odd_sizes":
         mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
         h[::3] = 45000.0
