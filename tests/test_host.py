@@ -311,3 +311,53 @@ def test_build_stamps_the_isa_scan_and_the_library_honours_it(tmp_path, monkeypa
     assert not isa_check.team_form_cleared()
     (tmp_path / "stamp.json").write_text('{"hipcc": "x", "findings": []}')
     assert isa_check.team_form_cleared()
+
+
+def test_bench_config_values_and_resident_rooflines():
+    """bench.py's flat `config_values` map (what survives in the driver's record of the line) and the two on-chip
+    roofline blocks: one chain against the aggregate LDS bandwidth, chains in lock-step against the fp64 matrix peak."""
+    import json
+    import bench
+    line = {"value": 150.66, "roofline": {"frac": 0.823456},
+            "extra": {"c1_uniform_20x30x10": {"value": 145000.0, "roofline": {"frac": 0.0593}},
+                      "c1_uniform_16_chains": {"value": 372000.0, "roofline": {"frac": 0.1251}},
+                      "c4_global_tesseroid_shift_invariant_8_chains": {"value": 32000.0, "roofline": {"frac": None}},
+                      "c5_share_row_blocks": {"error": "x"},
+                      "c2_hmcsample": {"binary_sink": {"leapfrog_steps_per_s": 163.4}, "sampler_vs_run_chain": 0.9912}}}
+    cv = bench.config_values(line)
+    assert cv["c2"] == [150.7, 0.8235] and cv["c1"] == [145000.0, 0.0593] and cv["c1_16"] == [372000.0, 0.1251]
+    assert cv["c4_si8"] == [32000.0, None] and cv["c5_rows"] is None and cv["c2_sampler"] == [163.4, 0.991]
+    assert len(json.dumps(bench.config_values({"value": 1.0, "roofline": {"frac": 0.5}, "extra": {
+        t: {"value": 123456.7, "roofline": {"frac": 0.1234}} for t in (
+            "c1_uniform_20x30x10", "c1_uniform_16_chains", "c2_uniform_16_chains", "c2_uniform_16_chains_two_reads_of_G",
+            "c3_segment_wavelet3d_tv", "c3_segment_wavelet3d_tv_16_chains", "c4_global_tesseroid_matrix_free",
+            "c4_global_tesseroid_dense", "c4_global_tesseroid_shift_invariant",
+            "c4_global_tesseroid_shift_invariant_8_chains", "c4_global_tesseroid_matrix_free_8_chains",
+            "c5_share_of_one_gpu_of_8", "c5_share_row_blocks")}}))) < 600
+    prof = {"sweep_ms": 6.48, "sweeps": 1000}
+    one = bench.resident_roofline(600, 6000, 1, prof, 100, {"resident_launches": 4})
+    assert one["bound"] == "lds" and abs(one["achieved"] - 2 * 600 * 6000 * 8 / 6.48e-6 / 1e9) < 1e-6 * one["achieved"]
+    assert abs(one["frac"] - one["achieved"] / 150000.0) < 1e-12
+    prof = {"sweep_ms": 23.2, "sweeps": 1000}
+    many = bench.resident_roofline(600, 6000, 16, prof, 100, {"resident_launches": 1, "resident_batch_launches": 12})
+    assert many["bound"] == "mfma" and abs(many["achieved"] - 4.0 * 600 * 6000 * 16 / 23.2e-6 / 1e12) < 1e-9
+    assert abs(many["frac"] - many["achieved"] / 78.6) < 1e-12 and many["us_per_lock_step"] == pytest.approx(23.2)
+
+
+def test_native_legacy_draws_from_a_seed_are_numpys_randomstate(built_lib):
+    """LegacyDraws(seed=s) -- the stream a chain of HMCSampleBatch draws from -- is np.random.RandomState(s) bit for
+    bit in the reference's order per trajectory (randint, randn(M) * Sigma, rand: hmc.py:297,95,164), and leaves
+    NumPy's global generator alone (host code: no GPU call)."""
+    from gravinv3dhmc_amd.inversion.rng import LegacyDraws
+    M, sig = 777, 0.003
+    np.random.seed(5)
+    before = np.random.get_state()[1].copy()
+    d = LegacyDraws(M, (5, 20), sig, seed=104)
+    Ls, p0s, us = d.take_block(7)
+    d.release()
+    r = np.random.RandomState(104)
+    for i in range(7):
+        assert int(Ls[i]) == r.randint(5, 21)
+        assert np.array_equal(p0s[i], r.randn(M) * sig)
+        assert float(us[i]) == r.rand()
+    assert np.array_equal(np.random.get_state()[1], before)
