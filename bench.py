@@ -295,8 +295,9 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
 #: (same script, its own workload) and summarised under `extra`, so one driver record carries them
 EXTRA_RUNS = [
     ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
-    ("c1_uniform_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--steps", "4000",
-                              "--warmup", "400"]),
+    ("c1_uniform_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--steps", "8000",
+                              "--warmup", "800"]),
+    ("c1_hmcsample_batch_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--hmcsample-batch", "300"]),
     ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                               "--warmup", "20"]),
     ("c2_uniform_16_chains_two_reads_of_G", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
@@ -409,6 +410,52 @@ def hmcsample_block(device, workload, nsamples=60):
     return out
 
 
+def hmcsample_batch_block(device, workload, chains, nsamples):
+    """The BATCH sampler (HMCSampleBatch: `chains` chains of the reference's ranks first_rank .. on one GPU,
+    inversion/hmc.py) on a small workload -- at C1 the chains run in lock-step inside the resident batch kernel --
+    until every chain has `nsamples` accepted samples: leapfrog steps/s of all chains with the console lines, the
+    misfit rows and the sample sink inside the number (sink "none" and "binary")."""
+    import contextlib
+    import shutil
+    import tempfile
+    import gravinv3dhmc_amd as g
+    mesh, xp, yp, zp, rho = make_problem(workload)
+    N, M = xp.size, mesh.size
+    nx, ny, nz = WORKLOADS[workload][:3]
+    dt = WORKLOADS[workload][4]
+    gm = g.GravMagModule(np.zeros(N), (0, 100.0 * nx, 0, 100.0 * ny, 0, 100.0 * nz), (100.0, 100.0, 100.0), (xp, yp, zp),
+                         device=device, verbose=False)
+    eng = gm._engine
+    wm = gm.Wm.diagonal()
+    d_true = eng.forward(wm * rho)
+    dobs = d_true + np.random.default_rng(0).normal(0.0, 0.02 * np.abs(d_true).max(), N)
+    eng.set_data(dobs)
+    gm.dobs = dobs
+    ones = np.ones(M)
+    out = {"workload": workload, "chains": chains, "nsamples_per_chain": nsamples, "Lrange": [5, 20], "dt": dt}
+    tmp = tempfile.mkdtemp(prefix="gravhmc_bench_")
+    try:
+        for sink in ("none", "binary"):
+            st0 = eng.batch_resident_stats()
+            with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+                t0 = time.perf_counter()
+                acc_n, tot_n = g.HMCSampleBatch(gm, chains, nsamples, 0, dt, [5, 20], 0.001 * ones, 0.001 * ones,
+                                                np.c_[0.0 * ones, ones], "mandatory", 1000, dobs, "Fixed", 0.8, 1.0,
+                                                "Damping", 0.01, 100, 0.001, save_folder=os.path.join(tmp, sink + "_chain"),
+                                                sample_sink=sink)
+                eng.synchronize()
+                el = time.perf_counter() - t0
+            st1 = eng.batch_resident_stats()
+            steps = st1["chain_steps"] - st0["chain_steps"]
+            out[sink + "_sink"] = {"seconds": el, "trajectories": int(sum(tot_n)), "accepted": int(sum(acc_n)),
+                                   "leapfrog_steps": int(steps), "leapfrog_steps_per_s": steps / el,
+                                   "lock_step_launches": st1["launches"] - st0["launches"]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    eng.close()
+    return out
+
+
 def c1_block(device, want_cpu):
     """BASELINE.json's target configuration (north_star: uniformgrid 20 x 30 x 10, Damping, one chain)
     measured in the same process, for the `extra` field of the line: steps/s, us per potential
@@ -513,6 +560,9 @@ def config_values(line):
     for tag, d in (line.get("extra") or {}).items():
         if tag in short:
             out[short[tag]] = pair(d)
+    hb = (line.get("extra") or {}).get("c1_hmcsample_batch_16_chains")
+    if isinstance(hb, dict) and "none_sink" in hb:
+        out["c1_16_sampler"] = [round(hb["none_sink"]["leapfrog_steps_per_s"], 1), None]
     hs = (line.get("extra") or {}).get("c2_hmcsample")
     if isinstance(hs, dict) and "binary_sink" in hs:
         out["c2_sampler"] = [round(hs["binary_sink"]["leapfrog_steps_per_s"], 1),
@@ -571,6 +621,9 @@ def main():
     ap.add_argument("--hmcsample", type=int, default=0, metavar="NSAMPLES",
                     help="measure the SAMPLER (HMCSample, binary and text sinks, Lrange [5,20]) on the workload "
                          "until NSAMPLES proposals are accepted, print its block and exit")
+    ap.add_argument("--hmcsample-batch", type=int, default=0, metavar="NSAMPLES",
+                    help="measure the BATCH sampler (HMCSampleBatch, --chains-per-gpu chains, sinks none and binary) on the "
+                         "workload until every chain has NSAMPLES accepted samples, print its block and exit")
     ap.add_argument("--seed", type=int, default=100,
                     help="np.random.seed of the chain of rank 0; rank r takes seed + r (hmc.py:369)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -594,6 +647,10 @@ def main():
     if args.hmcsample > 0:
         print(json.dumps({"hmcsample": hmcsample_block(int(os.environ.get("LOCAL_RANK", "0")), args.workload,
                                                        args.hmcsample)}))
+        return
+    if args.hmcsample_batch > 0:
+        print(json.dumps({"hmcsample": hmcsample_batch_block(int(os.environ.get("LOCAL_RANK", "0")), args.workload,
+                                                             max(2, args.chains_per_gpu), args.hmcsample_batch)}))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as the driver types it for N = 1: start the N ranks ourselves, as
@@ -665,7 +722,10 @@ def main():
         # the stream np.random.seed gives the reference's rank), lock-step rounds of L steps
         from concurrent.futures import ThreadPoolExecutor
         from gravinv3dhmc_amd.inversion.rng import LegacyDraws
-        pool = ThreadPoolExecutor(max_workers=CPG + 1)
+        pool = ThreadPoolExecutor(max_workers=2)
+        # (the chains' draws on a few threads: sixteen of them, each with the generator's own helpers, crowd the
+        # thread that launches the GPU work off the box's 16 cores)
+        draw_pool = ThreadPoolExecutor(max_workers=min(4, CPG))
         x0s = np.stack([0.001 * wm for _ in range(CPG)])
         eng.batch_init(x0s, low, high)
         # (trajectories offered per chain and call: the sampler's rule, inversion/hmc.py HMCSampleBatch)
@@ -691,7 +751,7 @@ def main():
                     if n > 0:
                         Ls, p0s, us = self.draws[k].take_block(n)
                         self.queue[k].extend((int(Ls[i]), p0s[i], float(us[i])) for i in range(len(Ls)))
-                list(pool.map(one, range(CPG)))
+                list(draw_pool.map(one, range(CPG)))
 
             def run(self):
                 queue, nacc, done = self.queue, 0, [0] * CPG

@@ -342,7 +342,10 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     tot_n = [0] * n_chains
     target = ndraws + nsamples
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=n_chains + 1)
+    pool = ThreadPoolExecutor(max_workers=2)
+    # (the chains' draws on a few threads: one per chain plus the generator's own helpers crowd the thread that
+    # launches the GPU work off a 16-core share)
+    draw_pool = ThreadPoolExecutor(max_workers=min(4, n_chains))
 
     # Trajectories offered per chain and library call.  The chains run desynchronised
     # (gh_batch_run, carry-over mode): a call ends when the first chain has used up its offer, the
@@ -365,7 +368,7 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
                 Ls, p0s, us = rs[c].take_block(n)
                 for i in range(n):
                     pending[c].append((int(Ls[i]), p0s[i], float(us[i])))
-        list(pool.map(one, range(n_chains)))
+        list(draw_pool.map(one, range(n_chains)))
 
     def offer():
         cur = [[pending[c][t] for t in range(T)] for c in range(n_chains)]
@@ -412,6 +415,7 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
                                                         acc_n[c] / tot_n[c]))
         sys.stdout.flush()
     pool.shutdown(wait=False)
+    draw_pool.shutdown(wait=False)
     for r in rs:
         r.release()
     return acc_n, tot_n
