@@ -297,7 +297,7 @@ EXTRA_RUNS = [
     ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
     ("c1_uniform_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--steps", "8000",
                               "--warmup", "800"]),
-    ("c1_hmcsample_batch_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--hmcsample-batch", "300"]),
+    ("c1_hmcsample_batch_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--hmcsample-batch", "600"]),
     ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                               "--warmup", "20"]),
     ("c2_uniform_16_chains_two_reads_of_G", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
