@@ -741,7 +741,9 @@ def main():
 
             def __init__(self, total_steps, seed0):
                 self.plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
-                self.draws = [LegacyDraws(M, (L, L), Sigma, fixed_L=self.plan, seed=seed0 + k) for k in range(CPG)]
+                # (each chain draws into a ring of page-locked rows: the library sends them to the GPU from there)
+                self.draws = [LegacyDraws(M, (L, L), Sigma, fixed_L=self.plan, seed=seed0 + k).use_ring(eng, 2 * Tmax)
+                              for k in range(CPG)]
                 self.queue = [[] for _ in range(CPG)]      # per chain: (n, p0, u) drawn, not started yet
                 self.top_up()                              # a sampler in steady state has its next offer drawn
 
@@ -749,13 +751,14 @@ def main():
                 def one(k):
                     n = 2 * Tmax - len(self.queue[k])
                     if n > 0:
-                        Ls, p0s, us = self.draws[k].take_block(n)
-                        self.queue[k].extend((int(Ls[i]), p0s[i], float(us[i])) for i in range(len(Ls)))
+                        self.queue[k].extend(self.draws[k].take_ring(n))   # (L, row address, u, ring index)
                 list(draw_pool.map(one, range(CPG)))
 
             def run(self):
                 queue, nacc, done = self.queue, 0, [0] * CPG
+                clk = HOST_LOOP
                 while min(done) < len(self.plan):
+                    t_a = time.perf_counter()
                     T = min(Tmax, min(len(q) for q in queue))
                     if T == 0:                             # nothing left to offer: finish what is in flight
                         acc, _, _, ns, nd = eng.batch_run([[] for _ in range(CPG)], dt, np.zeros((CPG, 0)),
@@ -765,7 +768,11 @@ def main():
                                           [[tr[0] for tr in q[:T]] for q in queue],
                                           [[tr[2] for tr in q[:T]] for q in queue], False, True)
                         self.top_up()                      # (the offers after this one, while the GPU runs)
+                        t_b = time.perf_counter()
                         acc, _, _, ns, nd = fut.result()
+                        clk["draw_s"] += t_b - t_a
+                        clk["wait_for_gpu_call_s"] += time.perf_counter() - t_b
+                        clk["calls"] += 1
                     for k in range(CPG):
                         del queue[k][:int(ns[k])]
                         done[k] += int(nd[k])
@@ -774,9 +781,11 @@ def main():
                     d.release()
                 return nacc, len(self.plan)
 
+        HOST_LOOP = {"draw_s": 0.0, "wait_for_gpu_call_s": 0.0, "calls": 0}
         if args.warmup > 0:
             Rounds(args.warmup, args.seed + 1000 + rank * CPG).run()
         rounds = Rounds(args.steps, args.seed + rank * CPG)
+        HOST_LOOP.update(draw_s=0.0, wait_for_gpu_call_s=0.0, calls=0)
         eng.synchronize()
         barrier()
         eng.profile_enable(True)
@@ -819,6 +828,10 @@ def main():
                        "matrix_free": bool(args.matrix_free), "shift_invariant": bool(args.shift_invariant),
                        "wavelet_nnz": nnz,
                        "chains_per_gpu": CPG, "dt": dt, "traj_len": L, "trajectories": ntraj,
+                       # several chains: the host loop's clocks (drawing the next offers beside the GPU call, then
+                       # waiting for the call)
+                       "host_loop": ({k: (round(v, 4) if isinstance(v, float) else v) for k, v in HOST_LOOP.items()}
+                                     if CPG > 1 else None),
                        "accepted": naccept, "final_U": LAST_STATE["U"] if CPG == 1 else None,
                        "final_U_per_rank": final_U_ranks if CPG == 1 and world > 1 else None,
                        "seed": args.seed,

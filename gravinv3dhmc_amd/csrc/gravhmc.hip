@@ -95,6 +95,8 @@ void gh_destroy(gh_ctx *c)
     if (c->sh.hbuf) hipHostFree(c->sh.hbuf);
     if (c->bt.h) hipHostFree(c->bt.h);
     if (c->rs.ls.h_stage) hipHostFree(c->rs.ls.h_stage);
+    if (c->rs.ls.h_xstage) hipHostFree(c->rs.ls.h_xstage);
+    for (gh_ctx::Pinned &pm : c->pinned) hipHostFree(pm.base);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_scal) hipHostFree(c->h_scal);
     for (hipEvent_t ev : c->ev) hipEventDestroy(ev);
@@ -1943,6 +1945,39 @@ int gh_batch_resident_stats(gh_ctx *c, int64_t *launches, int64_t *lock_steps, i
     if (chain_steps) *chain_steps = b.chain_steps;
     if (lost_steps) *lost_steps = b.lost;
     if (timeouts) *timeouts = b.aborts;
+    return GH_OK;
+}
+
+int gh_pinned_alloc(gh_ctx *c, size_t bytes, void **host)
+{
+    if (!c || !host || bytes == 0) return fail(c, GH_ERR_ARG, "gh_pinned_alloc: null pointer or no bytes");
+    HIPCHK(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, bytes));
+    c->pinned.push_back({(char *)p, bytes});
+    *host = p;
+    return GH_OK;
+}
+
+int gh_pinned_free(gh_ctx *c, void *host)
+{
+    if (!c || !host) return fail(c, GH_ERR_ARG, "gh_pinned_free: null pointer");
+    for (size_t i = 0; i < c->pinned.size(); ++i)
+        if (c->pinned[i].base == (char *)host) {
+            HIPCHK(c, hipSetDevice(c->device));
+            if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipHostFree(host));
+            c->pinned.erase(c->pinned.begin() + (long)i);
+            return GH_OK;
+        }
+    return fail(c, GH_ERR_ARG, "gh_pinned_free: not a block of gh_pinned_alloc");
+}
+
+int gh_batch_staging_stats(gh_ctx *c, int64_t *rows_direct, int64_t *rows_staged)
+{
+    if (!c) return GH_ERR_ARG;
+    if (rows_direct) *rows_direct = c->rs.ls.rows_direct;
+    if (rows_staged) *rows_staged = c->rs.ls.rows_staged;
     return GH_OK;
 }
 

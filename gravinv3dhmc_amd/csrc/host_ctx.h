@@ -277,6 +277,10 @@ struct gh_ctx {
             int *L = nullptr, *accepted = nullptr, *n_io = nullptr;
             double *h_stage = nullptr;       // pinned staging of the momentum rows
             size_t h_stage_n = 0;
+            double *h_xstage = nullptr;      // pinned staging of the accepted models on their way out
+            size_t h_xstage_n = 0;
+            const double **p0tab = nullptr;  // device: where each list element's momentum row lies (chain-major)
+            int64_t rows_direct = 0, rows_staged = 0;  // rows sent straight from the caller's pinned memory / gathered first
             int cap = 0;                 // list elements the device lists hold
             unsigned tag = 0, ltag = 0;
             bool dirty = false;          // an aborted launch left tags behind
@@ -287,6 +291,14 @@ struct gh_ctx {
         } ls;
     } rs;
     int64_t prof_res_evals = 0;
+
+    // page-locked host memory handed to the caller (gh_pinned_alloc): momentum rows drawn into it go to the device
+    // without a gather on the host
+    struct Pinned {
+        char *base;
+        size_t bytes;
+    };
+    std::vector<Pinned> pinned;
 
     // ring of the last K accepted samples (posterior statistics without text I/O)
     double *ring = nullptr, *ring_mean = nullptr, *ring_sd = nullptr;

@@ -122,9 +122,11 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
         b.dirty = false;
     }
     HIPCHK(c, hipMemsetAsync(r.abort_w, 0, 4 * sizeof(unsigned), c->stream));
-    // Momenta: device rows trajectory-major (t * C + ch), gathered into ONE pinned staging buffer (a few host
-    // threads: 6 MB at C1 with 16 chains x 8 trajectories) and sent with one copy -- 128 separate copies of
-    // pageable rows cost more than the kernel they feed.
+    // Momenta: device rows chain-major (ch * T + t), like the lists.  Rows inside a block of gh_pinned_alloc go
+    // straight from where they lie, adjacent ones in one copy (a sampler drawing into a ring of such rows: one
+    // or two copies per chain); the others are gathered into ONE pinned staging buffer first (a few host threads:
+    // 6 MB at C1 with 16 chains x 8 trajectories) -- 128 separate copies of pageable rows cost more than the
+    // kernel they feed.
     if ((size_t)K * M > b.h_stage_n) {
         if (b.h_stage) HIPCHK(c, hipHostFree(b.h_stage));
         b.h_stage = nullptr;
@@ -132,23 +134,47 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
         HIPCHK(c, hipHostMalloc((void **)&b.h_stage, b.h_stage_n * sizeof(double)));
     }
     if (K > 0) {
-        auto stage_rows = [&](int k0, int k1) {
-            for (int k = k0; k < k1; ++k) {
-                const int t = k / C, ch = k % C;
-                memcpy(b.h_stage + (size_t)k * M, p0flat ? p0flat + ((size_t)ch * T + t) * M : p0rows[(size_t)ch * T + t],
-                       M * sizeof(double));
-            }
-        };
-        const int nthr = (size_t)K * M * sizeof(double) >= ((size_t)1 << 20) ? std::min(4, K) : 1;
-        if (nthr > 1) {
-            std::vector<std::thread> pool;
-            for (int i = 1; i < nthr; ++i) pool.emplace_back(stage_rows, (int)((int64_t)K * i / nthr), (int)((int64_t)K * (i + 1) / nthr));
-            stage_rows(0, K / nthr);
-            for (std::thread &th : pool) th.join();
-        } else {
-            stage_rows(0, K);
+        std::vector<const double *> src((size_t)K);
+        std::vector<char> direct((size_t)K, 0);
+        int n_staged = 0;
+        for (int k = 0; k < K; ++k) {
+            src[(size_t)k] = p0flat ? p0flat + (size_t)k * M : p0rows[(size_t)k];
+            const char *lo = (const char *)src[(size_t)k], *hi = lo + M * sizeof(double);
+            for (const gh_ctx::Pinned &pm : c->pinned)
+                if (lo >= pm.base && hi <= pm.base + pm.bytes) {
+                    direct[(size_t)k] = 1;
+                    break;
+                }
+            n_staged += direct[(size_t)k] ? 0 : 1;
         }
-        HIPCHK(c, hipMemcpyAsync(b.p0s, b.h_stage, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        b.rows_direct += K - n_staged;
+        b.rows_staged += n_staged;
+        if (n_staged > 0) {
+            auto stage_rows = [&](int k0, int k1) {
+                for (int k = k0; k < k1; ++k)
+                    if (!direct[(size_t)k]) memcpy(b.h_stage + (size_t)k * M, src[(size_t)k], M * sizeof(double));
+            };
+            const int nthr = (size_t)n_staged * M * sizeof(double) >= ((size_t)1 << 20) ? std::min(4, K) : 1;
+            if (nthr > 1) {
+                std::vector<std::thread> pool;
+                for (int i = 1; i < nthr; ++i) pool.emplace_back(stage_rows, (int)((int64_t)K * i / nthr), (int)((int64_t)K * (i + 1) / nthr));
+                stage_rows(0, K / nthr);
+                for (std::thread &th : pool) th.join();
+            } else {
+                stage_rows(0, K);
+            }
+        }
+        // one copy per run of rows that are adjacent at their source
+        for (int k0 = 0; k0 < K;) {
+            int k1 = k0 + 1;
+            const double *from = direct[(size_t)k0] ? src[(size_t)k0] : b.h_stage + (size_t)k0 * M;
+            while (k1 < K && direct[(size_t)k1] == direct[(size_t)k0] &&
+                   (direct[(size_t)k0] ? src[(size_t)k1] == src[(size_t)k1 - 1] + M : true))
+                ++k1;
+            HIPCHK(c, hipMemcpyAsync(b.p0s + (size_t)k0 * M, from, (size_t)(k1 - k0) * M * sizeof(double), hipMemcpyHostToDevice,
+                                     c->stream));
+            k0 = k1;
+        }
         HIPCHK(c, hipMemcpyAsync(b.us, us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(b.L, L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
@@ -236,17 +262,38 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
     HIPCHK(c, hipMemcpyAsync(acc.data(), b.accepted, (size_t)Kout * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(o5.data(), b.out5s, (size_t)Kout * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // accepted models: one copy per chain (its done slots are adjacent) into pinned staging, rows picked from there --
+    // a copy per accepted row into the caller's pageable array costs ~15 us each, hundreds per call
+    bool want_rows = false;
     for (int ch = 0; ch < C; ++ch) {
         const int nd = h_n[16 + ch];
         if (nd > a.Tout || h_n[ch] > T)
             return fail(c, GH_ERR_HIP, "resident batch kernel: chain %d reports %d results in %d slots (%d of %d started)", ch, nd,
                         a.Tout, h_n[ch], T);
+        if (!x_out) continue;
+        int last = -1;
+        for (int i = 0; i < nd; ++i)
+            if (acc[(size_t)ch * a.Tout + i]) last = i;
+        if (last < 0) continue;
+        if (!want_rows && (size_t)Kout * M > b.h_xstage_n) {
+            if (b.h_xstage) HIPCHK(c, hipHostFree(b.h_xstage));
+            b.h_xstage = nullptr;
+            b.h_xstage_n = (size_t)std::max(Kout, 32) * M;
+            HIPCHK(c, hipHostMalloc((void **)&b.h_xstage, b.h_xstage_n * sizeof(double)));
+        }
+        want_rows = true;
+        const size_t s0 = (size_t)ch * a.Tout;
+        HIPCHK(c, hipMemcpyAsync(b.h_xstage + s0 * M, b.xacc + s0 * M, (size_t)(last + 1) * M * sizeof(double), hipMemcpyDeviceToHost,
+                                 c->stream));
+    }
+    if (want_rows) HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int ch = 0; ch < C; ++ch) {
+        const int nd = h_n[16 + ch];
         for (int i = 0; i < nd; ++i) {
             const size_t slot = (size_t)ch * a.Tout + i;
             accepted[slot] = acc[slot];
             memcpy(out5s + slot * 5, o5.data() + slot * 5, 5 * sizeof(double));
-            if (x_out && acc[slot])
-                HIPCHK(c, hipMemcpyAsync(x_out + slot * M, b.xacc + slot * M, M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (x_out && acc[slot]) memcpy(x_out + slot * M, b.h_xstage + slot * M, M * sizeof(double));
         }
         if (n_started) n_started[ch] = h_n[ch];
         if (n_done) n_done[ch] = nd;
@@ -254,7 +301,6 @@ static int resbatch_launch(gh_ctx *c, int T, const int *L, const double *const *
         b.lost += h_n[48 + ch];
         b.chain_steps += h_n[80 + ch];
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->prof) {
         float t = 0.f;
         HIPCHK(c, hipEventElapsedTime(&t, r.ev0, r.ev1));

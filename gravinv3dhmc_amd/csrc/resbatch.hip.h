@@ -61,7 +61,7 @@ struct ResBatchArgs {
     int C;             // chains
     int T;             // trajectories offered per chain; element (c, t) of L / us at c * T + t
     const int *L;
-    const double *p0s; // (T C) x M momenta, trajectory-major: row t * C + c
+    const double *p0s; // (C T) x M momenta, chain-major like the lists: row c * T + t
     const double *us;
     double dt;
     int stop_any;      // 1: end when a chain has nothing left to start (carry-over); 0: run all lists to their end
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(RB_THREADS) resident_batch_kernel(ResBatchArgs
         xs = xj;
     };
     auto list_p0 = [&](int q) -> double {
-        return (cell && q < T) ? a.p0s[((int64_t)q * C + ct) * M + jg] : 0.0;
+        return (cell && q < T) ? a.p0s[((int64_t)ct * T + q) * M + jg] : 0.0;
     };
     // a chain with nothing in flight starts the first element of its list
     if (ct < C && mode == IDLE && T > 0) {

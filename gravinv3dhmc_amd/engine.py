@@ -482,15 +482,22 @@ class Engine(object):
         with carry -- and, with carry=True, (n_started, n_done): the call then ends as soon as a chain has nothing left to
         start, the others keep their trajectory in flight for the next call (T = 0, i.e. C empty
         lists, drains them)."""
-        rows = [[f64(p) for p in chain] for chain in p0s]
-        Cn = len(rows)
-        T = len(rows[0]) if Cn else 0
-        if any(len(r) != T for r in rows) or any(p.shape != (self.M,) for r in rows for p in r):
+        Cn = len(p0s)
+        T = len(p0s[0]) if Cn else 0
+        if any(len(r) != T for r in p0s):
             raise ValueError("p0s must hold the same number of M-vectors for every chain")
+        if T and isinstance(p0s[0][0], (int, np.integer)):
+            # row ADDRESSES (LegacyDraws.take_ring: M float64 values each, alive for the call)
+            addr = np.ascontiguousarray(p0s, dtype=np.uint64).reshape(Cn * T)
+            ptrs = addr.ctypes.data_as(C.POINTER(_lib._dp))
+        else:
+            rows = [[f64(p) for p in chain] for chain in p0s]
+            if any(p.shape != (self.M,) for r in rows for p in r):
+                raise ValueError("p0s must hold the same number of M-vectors for every chain")
+            ptrs = (_lib._dp * max(1, Cn * T))(*[ptr(p) for r in rows for p in r])
         To = T + 1 if carry else T            # result slots per chain
         Ls = np.ascontiguousarray(Ls, dtype=np.int32).reshape(Cn, T)
         us = np.ascontiguousarray(us, dtype=np.float64).reshape(Cn, T)
-        ptrs = (_lib._dp * max(1, Cn * T))(*[ptr(p) for r in rows for p in r])
         acc = np.zeros((Cn, To), dtype=np.int32)
         out5 = np.zeros((Cn, To, 5))
         xs = np.empty((Cn, To, self.M)) if want_x else None
@@ -503,6 +510,30 @@ class Engine(object):
         if carry:
             return acc.astype(bool), out5, xs, ns, nd
         return acc.astype(bool), out5, xs
+
+    def pinned_empty(self, shape):
+        """A float64 array in page-locked host memory of the library (gh_pinned_alloc): momentum rows drawn into
+        it go to the device without a gather on the host.  It lives until pinned_free(array) or close()."""
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        self._chk(self._lib.gh_pinned_alloc(self._h, max(1, n) * 8, C.byref(p)))
+        buf = (C.c_double * max(1, n)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def pinned_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is None:
+            raise ValueError("not an array of pinned_empty")
+        self._chk(self._lib.gh_pinned_free(self._h, C.c_void_p(p)))
+
+    def batch_staging_stats(self):
+        """Momentum rows of the lock-step form sent straight from pinned memory / gathered on the host first."""
+        d, s = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_batch_staging_stats(self._h, C.byref(d), C.byref(s)))
+        return {"rows_direct": d.value, "rows_staged": s.value}
 
     def batch_fused_stats(self):
         """Team form of the matrix-free batch (one evaluation per entry and step): grid, launches, time-outs."""

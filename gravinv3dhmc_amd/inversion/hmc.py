@@ -326,7 +326,15 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     # trajectory's 6000 normals cost NumPy 57 us on a GPU box's core -- with 16 chains in lock-step the GPU
     # needs 23 us for a step of ALL chains; the native draws take half of NumPy's time and run one thread per chain)
     from .rng import LegacyDraws
-    rs = [LegacyDraws(M, Lrange, Sigma, seed=seed + r) for r in ranks]
+    # Trajectories offered per chain and library call.  The chains run desynchronised
+    # (gh_batch_run, carry-over mode): a call ends when the first chain has used up its offer, the
+    # others keep their trajectory in flight; what a chain has not started is offered again next
+    # time together with fresh draws.  Bounded by the momenta held on the host.
+    # (up to 32 per call: at 6000 cells a lock-step of 16 chains takes 23 us on the GPU -- 8 trajectories per chain
+    # are 2 ms of kernel against ~1.5 ms of staging, copies and Python per call)
+    T = int(max(2, min(32, (256 << 20) // (8 * M * n_chains))))
+    # (each chain draws into a ring of 2 T page-locked rows: the library sends them to the GPU from where they lie)
+    rs = [LegacyDraws(M, Lrange, Sigma, seed=seed + r).use_ring(eng, 2 * T) for r in ranks]
     folders = [save_folder + str(r) for r in ranks]
     for f in folders:
         os.makedirs(f, exist_ok=True)
@@ -347,16 +355,11 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     # launches the GPU work off a 16-core share)
     draw_pool = ThreadPoolExecutor(max_workers=min(4, n_chains))
 
-    # Trajectories offered per chain and library call.  The chains run desynchronised
-    # (gh_batch_run, carry-over mode): a call ends when the first chain has used up its offer, the
-    # others keep their trajectory in flight; what a chain has not started is offered again next
-    # time together with fresh draws.  Bounded by the momenta held on the host.
     import collections
-    # (up to 32 per call: at 6000 cells a lock-step of 16 chains takes 23 us on the GPU -- 8 trajectories per chain
-    # are 2 ms of kernel against ~1.5 ms of staging, copies and Python per call)
-    T = int(max(2, min(32, (256 << 20) // (8 * M * n_chains))))
-    pending = [collections.deque() for _ in range(n_chains)]    # drawn, not started yet
-    inflight = [collections.deque() for _ in range(n_chains)]   # started, result not reported yet
+    import queue
+    import threading
+    pending = [collections.deque() for _ in range(n_chains)]    # drawn, not started yet: (L, row address, u, row)
+    inflight = [0] * n_chains                                   # started, result not reported yet
 
     def top_up():
         """Fill every chain's queue up to 2 T draws (L, momentum, Metropolis variate), each chain
@@ -365,9 +368,7 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
         def one(c):
             n = 2 * T - len(pending[c])
             if n > 0:
-                Ls, p0s, us = rs[c].take_block(n)
-                for i in range(n):
-                    pending[c].append((int(Ls[i]), p0s[i], float(us[i])))
+                pending[c].extend(rs[c].take_ring(n))
         list(draw_pool.map(one, range(n_chains)))
 
     def offer():
@@ -383,22 +384,14 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     f_misfit = [open(f + "/misfit.dat", "ab") for f in folders]
     f_model = [open(f + "/" + sink_name, "ab") for f in folders] if sink_name else None
     wdiag = WmInv.diagonal()
-    lines = []
-    while min(acc_n) < target:
-        p0s, Ls, us = offer()
-        # more is drawn on the host while the GPU runs (appended behind what has been offered)
-        fut = pool.submit(eng.batch_run, p0s, delta, Ls, us, want_x, True)
-        top_up()
-        accepted, out5, xs, n_started, n_done = fut.result()
-        for c in range(n_chains):
-            for _ in range(int(n_started[c])):
-                inflight[c].append(pending[c].popleft())
+
+    def report(accepted, out5, xs, n_done):
+        """A call's results in the order the reference's ranks would report them: files and console lines
+        (hmc.py:318-336 per chain)."""
+        lines = []
         for i in range(int(max(n_done))):
             for c in range(n_chains):
-                if i >= n_done[c]:
-                    continue
-                inflight[c].popleft()
-                if acc_n[c] >= target:
+                if i >= n_done[c] or acc_n[c] >= target:
                     continue
                 U, U_data, U_model = out5[c, i, 0], out5[c, i, 1], out5[c, i, 2]
                 Udn, Umn = U_data / N, U_model / M
@@ -418,14 +411,53 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
                              "-- accept ratio {:.2%}\n\n".format(ranks[c], acc_n[c] / target, Un, Udn, alpha, Umn,
                                                                acc_n[c] / tot_n[c]))
         sys.stdout.write("".join(lines))
-        lines.clear()
         sys.stdout.flush()
         for fh in f_misfit + (f_model or []):
             fh.flush()
-    for fh in f_misfit + (f_model or []):
-        fh.close()
-    pool.shutdown(wait=False)
-    draw_pool.shutdown(wait=False)
-    for r in rs:
-        r.release()
+
+    # The reporting runs on a thread of its own BESIDE the next library call (which waits for the GPU with the
+    # interpreter lock released): at 6000 cells a call's ~500 results cost Python as long as the GPU needs for them.
+    # The loop itself only counts accepted samples to know when every chain has its target.
+    results = queue.Queue(maxsize=4)
+    failure = []
+
+    def reporter():
+        while True:
+            item = results.get()
+            if item is None:
+                return
+            if failure:
+                continue                                  # (keep draining: the producer must not block)
+            try:
+                report(*item)
+            except BaseException as e:                    # noqa: B902 -- handed to the caller below
+                failure.append(e)
+
+    rep = threading.Thread(target=reporter, name="hmc-batch-report", daemon=True)
+    rep.start()
+    acc_fast = np.zeros(n_chains, dtype=np.int64)
+    try:
+        while acc_fast.min() < target and not failure:
+            p0s, Ls, us = offer()
+            # more is drawn on the host while the GPU runs (appended behind what has been offered)
+            fut = pool.submit(eng.batch_run, p0s, delta, Ls, us, want_x, True)
+            top_up()
+            accepted, out5, xs, n_started, n_done = fut.result()
+            for c in range(n_chains):
+                for _ in range(int(n_started[c])):
+                    pending[c].popleft()
+                inflight[c] += int(n_started[c]) - int(n_done[c])
+                acc_fast[c] += int(accepted[c, :int(n_done[c])].sum())
+            results.put((accepted, out5, xs, n_done))
+    finally:
+        results.put(None)
+        rep.join()
+        for fh in f_misfit + (f_model or []):
+            fh.close()
+        pool.shutdown(wait=False)
+        draw_pool.shutdown(wait=False)
+        for r in rs:
+            r.release()
+    if failure:
+        raise failure[0]
     return acc_n, tot_n

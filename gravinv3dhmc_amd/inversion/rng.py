@@ -54,7 +54,13 @@ class LegacyDraws(object):
             raise RuntimeError("gh_rng_set_state failed")
 
     def release(self):
-        """Hand the stream back to np.random and free the native generator."""
+        """Hand the stream back to np.random and free the native generator (and the ring of use_ring)."""
+        if getattr(self, "_ring", None) is not None:
+            ring, self._ring = self._ring, None
+            try:
+                self._ring_engine.pinned_free(ring)
+            except Exception:
+                pass                      # (the engine was closed first: its blocks went with it)
         if not self._h:
             return
         if self._own:
@@ -109,6 +115,43 @@ class LegacyDraws(object):
         if self._left is not None:
             self._left -= n
         return Ls, p0s, us
+
+    # -- a ring of page-locked rows -------------------------------------------------------
+    def use_ring(self, engine, rows):
+        """Draw into a ring of `rows` momentum rows in page-locked memory of the engine's library
+        (gh_pinned_alloc): Engine.batch_run sends such rows to the device from where they lie, a chain's adjacent
+        rows in one copy.  take_ring(n) writes the next n rows; the caller keeps at most `rows` of them in use
+        (drawn and not yet started by a call that has returned), oldest first."""
+        self._ring_engine = engine
+        self._ring = engine.pinned_empty((int(rows), self.M))
+        self._ring_Ls = np.empty(int(rows), dtype=np.int32)
+        self._ring_us = np.empty(int(rows))
+        self._ring_head = 0
+        self._ring_base = self._ring.ctypes.data
+        return self
+
+    def take_ring(self, n):
+        """Up to n further trajectories into the ring: a list of (L, row address, u, row index).  The address is
+        what Engine.batch_run takes in place of an array; ring_row(index) is the row as an array."""
+        rows = self._ring.shape[0]
+        if n > rows:
+            raise ValueError("take_ring: more rows than the ring holds")
+        out, stride = [], self.M * 8
+        while n > 0:
+            h = self._ring_head
+            k = min(n, rows - h)
+            Ls, _, us = self.take_block(k, out=(self._ring_Ls, self._ring, self._ring_us), at=h)
+            got = len(Ls)
+            base = self._ring_base + h * stride
+            out.extend((int(Ls[i]), base + i * stride, float(us[i]), h + i) for i in range(got))
+            self._ring_head = (h + got) % rows
+            if got < k:
+                break
+            n -= k
+        return out
+
+    def ring_row(self, index):
+        return self._ring[index]
 
     def __iter__(self):
         return self

@@ -302,6 +302,14 @@ int gh_batch_trajectory(gh_ctx *ctx, const double *p0s, double dt, const int *L,
 int gh_batch_run(gh_ctx *ctx, int T, const int *L, const double *const *p0_rows, const double *us,
                  double dt, int *accepted, double *out5s, double *x_out, int *n_started, int *n_done);
 int gh_batch_get_x(gh_ctx *ctx, int chain, double *x /* M */);
+/* Page-locked host memory for momentum rows (the reference draws a trajectory's momentum with
+ * np.random.randn(M) * Sigma into a fresh array, inversion/hmc.py:91): rows of gh_batch_run that lie in such a
+ * block go to the device straight from it, adjacent rows of a chain's list in one copy; rows anywhere else
+ * are gathered into the library's own staging buffer first (gh_batch_staging_stats counts both kinds, lock-step
+ * form).  Blocks live until gh_pinned_free or gh_destroy. */
+int gh_pinned_alloc(gh_ctx *ctx, size_t bytes, void **host);
+int gh_pinned_free(gh_ctx *ctx, void *host);
+int gh_batch_staging_stats(gh_ctx *ctx, int64_t *rows_direct, int64_t *rows_staged);
 /* Two or more chains on a problem small enough for the resident chain kernel with every column in LDS
  * (<= 32 cells per CU, N <= 640: BASELINE configs[0] and [2]) do not take turns: ALL chains advance in
  * lock-step inside one launch per gh_batch_run / gh_batch_trajectory call (csrc/resbatch.hip.h) -- one

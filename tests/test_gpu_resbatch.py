@@ -215,3 +215,58 @@ def test_lockstep_chains_with_the_compressed_forward_as_baseline_config_3(G, orc
     print("C3 (wavelet 3D forward, TV), 8 chains in lock-step vs the ORACLE: worst %.2e; %r" % (worst, st))
     assert worst < 1e-9 and st["launches"] == 1 and st["timeouts"] == 0
     e.close()
+
+
+def test_momentum_rows_in_pinned_memory_go_straight_to_the_device(G, c1):
+    """gh_pinned_alloc / LegacyDraws.use_ring: rows of a page-locked ring are sent from where they lie (adjacent
+    rows of a chain in one copy, the ring's wrap-around splits a run), rows anywhere else are gathered first --
+    and a list mixing both kinds is still the same list.  Same draws (RandomState(seed + chain): hmc.py:369,
+    91, 164) three ways: identical decisions, potentials and samples, bit for bit."""
+    from gravinv3dhmc_amd.inversion.rng import LegacyDraws
+    mesh, obs, Aw, wm, dobs = c1
+    C, T, M = 4, 6, mesh.size
+    low, high = 0.0 * wm, 1.0 * wm
+    x0s = np.stack([0.001 * wm * (1.0 + 0.1 * k) for k in range(C)])
+    outs = []
+    for mode in ("arrays", "ring", "mixed"):
+        e = _engine(G, c1, "Damping", 1e-3, 0.0)
+        e.batch_init(x0s, low, high)
+        draws = [LegacyDraws(M, (3, 9), 0.001, seed=50 + k) for k in range(C)]
+        if mode != "arrays":
+            for d in draws:
+                d.use_ring(e, T + 2)
+                d.take_ring(4)                       # (moves the head: the next 6 rows wrap around the ring's end)
+        else:
+            for d in draws:
+                d.take_block(4)
+        p0s, Ls, us = [], [], []
+        for k, d in enumerate(draws):
+            if mode == "arrays":
+                Lk, pk, uk = d.take_block(T)
+                rows = [pk[i] for i in range(T)]
+            else:
+                got = d.take_ring(T)
+                Lk, uk = [g[0] for g in got], [g[2] for g in got]
+                rows = [g[1] for g in got]
+                if mode == "mixed":                  # every other row from ordinary memory, as arrays
+                    rows = [d.ring_row(g[3]).copy() if i % 2 else d.ring_row(g[3]) for i, g in enumerate(got)]
+            p0s.append(rows)
+            Ls.append(list(Lk))
+            us.append(list(uk))
+        acc, out5, xs = e.batch_run(p0s, 0.05, Ls, us, want_x=True)
+        st = e.batch_staging_stats()
+        if mode == "arrays":
+            assert st["rows_direct"] == 0 and st["rows_staged"] == C * T
+        elif mode == "ring":
+            assert st["rows_direct"] == C * T and st["rows_staged"] == 0
+        else:
+            assert st["rows_direct"] == C * T // 2 and st["rows_staged"] == C * T // 2
+        assert e.batch_resident_stats()["launches"] >= 1
+        outs.append((acc, out5, np.where(acc[:, :, None], xs, 0.0), np.stack([e.batch_get_x(k) for k in range(C)])))
+        for d in draws:
+            d.release()
+        e.close()
+    assert outs[0][0].any()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
