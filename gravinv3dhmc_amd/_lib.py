@@ -44,6 +44,8 @@ PROTOTYPES = {
     "gh_pinned_alloc": (C.c_int, [_ctx, C.c_size_t, C.POINTER(C.c_void_p)]),
     "gh_pinned_free": (C.c_int, [_ctx, C.c_void_p]),
     "gh_batch_staging_stats": (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gh_shift_invariant_resident_stats": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "gh_shift_invariant_harmonic": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                               C.POINTER(C.c_int)]),
     "gh_matrix_free_stats": (C.c_int, [_ctx, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),

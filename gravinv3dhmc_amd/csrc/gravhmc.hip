@@ -10,6 +10,7 @@
 #include "batchteam.hip.h"
 #include "lonsym.hip.h"
 #include "lonsymh.hip.h"
+#include "lonres.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -37,6 +38,7 @@ using namespace ghk;
 #include "host_eval.h"
 #include "host_resident.h"
 #include "host_resbatch.h"
+#include "host_lonres.h"
 #include "host_batch.h"
 
 // ------------------------------------------------------------------------- C-ABI
@@ -96,6 +98,11 @@ void gh_destroy(gh_ctx *c)
     if (c->bt.h) hipHostFree(c->bt.h);
     if (c->rs.ls.h_stage) hipHostFree(c->rs.ls.h_stage);
     if (c->rs.ls.h_xstage) hipHostFree(c->rs.ls.h_xstage);
+    if (c->ls) {
+        if (c->ls->res.h_stage) hipHostFree(c->ls->res.h_stage);
+        if (c->ls->res.ev0) hipEventDestroy(c->ls->res.ev0);
+        if (c->ls->res.ev1) hipEventDestroy(c->ls->res.ev1);
+    }
     for (gh_ctx::Pinned &pm : c->pinned) hipHostFree(pm.base);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_scal) hipHostFree(c->h_scal);
@@ -191,6 +198,19 @@ int gh_set_shift_invariant(gh_ctx *c, int enable)
         c->mf_before_ls = c->mf;
         c->mf = true;
     }
+    return GH_OK;
+}
+
+int gh_shift_invariant_resident_stats(gh_ctx *c, int *workgroups, int64_t *launches, int64_t *evaluations, int64_t *trajectories,
+                                      int *timeouts)
+{
+    if (!c) return GH_ERR_ARG;
+    const bool on = lonsym_harmonic(c) && c->ls->res.state > 0;
+    if (workgroups) *workgroups = on ? c->ls->hgrid : 0;
+    if (launches) *launches = c->ls ? c->ls->res.launches : 0;
+    if (evaluations) *evaluations = c->ls ? c->ls->res.evals : 0;
+    if (trajectories) *trajectories = c->ls ? c->ls->res.trajectories : 0;
+    if (timeouts) *timeouts = c->ls ? c->ls->res.aborts : 0;
     return GH_OK;
 }
 
@@ -1075,6 +1095,19 @@ int gh_chain_run(gh_ctx *c, int K, const int *L, const double *p0s, const double
     *n_run = 0;
     // already there (a caller that submits batches ahead of looking at the results)
     if (stop_at_accepts > 0 && c->accept_count >= stop_at_accepts) return GH_OK;
+    if (lonres_usable(c)) {
+        // the shift-invariant store in the harmonic domain: the whole batch in one persistent launch (lonres.hip.h)
+        int64_t steps = 0;
+        for (int k = 0; k < K; ++k) {
+            if (L[k] < 1) return fail(c, GH_ERR_ARG, "gh_chain_run: L must be >= 1");
+            steps += L[k];
+        }
+        if (steps < ((int64_t)1 << 28)) {
+            const int rc = chain_run_lonres(c, K, L, p0s, us, dt, stop_at_accepts, record_from, accepted, out5s, x_out, n_run);
+            if (rc != GH_RESIDENT_ABORTED) return rc;
+            *n_run = 0;
+        }
+    }
     if (resident_usable(c)) {
         int64_t steps = 0;
         bool ok = true;
@@ -1228,6 +1261,8 @@ static int kids_make(gh_ctx *c, int C, const double *x0s, const double *low, con
         k->beta = c->beta;
         k->ls = new LonSymHost(*c->ls);  // (the tables are the parent's; the pass's work buffers are its own)
         k->ls->Rhat = k->ls->Dpart = nullptr;
+        k->ls->res = LonSymHost::Res();
+        k->ls->res.state = -1;  // (the persistent pass takes every CU: not for chains that share the GPU)
         k->ls->dbg = nullptr;
         k->ls->csum = nullptr;
         k->ls->epi_abort = nullptr;
@@ -1897,6 +1932,18 @@ int gh_debug_lonsym_timing(gh_ctx *c, long long out8[8])
     for (int i = 0; i < 8; ++i) out8[i] = 0;
     if (!c->ls || !c->ls->dbg) return GH_OK;
     HIPCHK(c, hipMemcpyAsync(out8, c->ls->dbg, 8 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+// Diagnostic (not in the public header): accumulated phase times of workgroup 0 of the persistent harmonic pass
+// (GRAVHMC_LONSYM_TIMING=1; lonres.hip.h), 100 MHz ticks.
+int gh_debug_lonres_timing(gh_ctx *c, long long out16[16])
+{
+    if (!c || !out16) return GH_ERR_ARG;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    if (!c->ls || !c->ls->res.dbg) return GH_OK;
+    HIPCHK(c, hipMemcpyAsync(out16, c->ls->res.dbg, 16 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GH_OK;
 }

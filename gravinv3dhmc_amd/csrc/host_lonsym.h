@@ -9,7 +9,7 @@ struct LonSymHost {
     double *T = nullptr;
     int *slot_first = nullptr, *xslot = nullptr, *xptr = nullptr, *xobs = nullptr, *lds_of = nullptr, *a_of = nullptr,
         *m_of = nullptr;
-    int n_xslots = 0;
+    int n_xslots = 0, max_extra = 0;  // max_extra: most observations a slot holds beyond its first
     long long *dbg = nullptr;  // GRAVHMC_LONSYM_TIMING: per-phase clocks of one workgroup
     // the same store in the longitude-harmonic domain (lonsymh.hip.h): default where it applies
     bool harm = false;
@@ -24,6 +24,26 @@ struct LonSymHost {
     unsigned long long *csum = nullptr;
     unsigned *epi_abort = nullptr;
     unsigned epi_tag = 0;
+    // the harmonic pass as one persistent launch per batch of trajectories (lonres.hip.h, host_lonres.h)
+    struct Res {
+        int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
+        size_t lds = 0;
+        ghk::d2 *slab = nullptr, *mhat = nullptr;
+        ghk::u64 *flagg = nullptr, *xccg = nullptr;
+        ghk::u32x4 *xslabg = nullptr, *rhatg = nullptr, *clsg = nullptr, *scalg = nullptr, *ppg = nullptr;
+        unsigned *abort_w = nullptr;
+        unsigned tag = 0, tagE = 0, ltag = 0;
+        bool dirty = false;
+        int Kcap = 0;
+        int *L = nullptr, *accepted = nullptr, *n_run = nullptr;
+        double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr, *ucur = nullptr;
+        double *h_stage = nullptr;
+        size_t h_stage_n = 0;
+        int64_t launches = 0, evals = 0, trajectories = 0;
+        int aborts = 0;
+        long long *dbg = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    } res;
     size_t lds = 0;
     int grid = 0, items = 1, W = 8, thr = 1024;  // items: work items per wave, W: longitudes per work item (instantiation of the kernel)
     std::string why;  // why the geometry does not qualify (gh_last_error text)
@@ -206,6 +226,7 @@ static int lonsym_build(gh_ctx *c)
         for (int64_t sl = 0; sl < Np; ++sl)
             if (!more[(size_t)sl].empty()) {
                 xslot.push_back((int)sl);
+                h.max_extra = std::max(h.max_extra, (int)more[(size_t)sl].size());
                 xobs.insert(xobs.end(), more[(size_t)sl].begin(), more[(size_t)sl].end());
                 xptr.push_back((int)xobs.size());
             }

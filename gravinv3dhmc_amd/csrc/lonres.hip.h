@@ -1,0 +1,691 @@
+// The longitude-harmonic pass of the shift-invariant store as ONE persistent launch per batch of trajectories
+// (gfx950): lonsymh.hip.h's leapfrog step is four dependent, latency-bound launches (R^ -> sweep -> sum of the
+// sweep's partials -> epilogue: 48 us of kernels + their gaps at C4, the table read from the Infinity Cache in
+// every step).  Here a workgroup keeps ITS cell rows' part of the table T^ in REGISTERS for the whole launch
+// (C4: 35.7 MB over 200 workgroups -- the chip's register files hold it), the chain's state of its cells with
+// it, and the workgroups exchange per evaluation what the launches exchanged through memory:
+//
+//   forward product of the workgroup's rows: D^ partial (na x nf complex)  -> slab row, untagged, one flag
+//   hop 1   the workgroups of a cluster (same XCD) sum a chunk of the entries over the cluster's members
+//           -> cluster sums, tagged granules ("the data is the flag", resident.hip.h)
+//   hop 2   the OWNER of observation class a (na of the workgroups) sums the 8 clusters' D^[a][:], inverse
+//           transform -> the class's predicted data; the classes' sums of d meet in a one-hop all-gather (the
+//           mean of potential.py:700-706); residuals, |r|^2 share, forward transform -> R^[a][:] published
+//   hop 3   every workgroup collects R^ (59.5 KB at C4) and the scalars: U_data, the regulariser's value,
+//           the kinetic energy of the trajectory's momentum
+//   adjoint product, gradient, leapfrog update (hmc.py:114-152) -- and round again.
+//
+// Trajectories end inside the launch: the final momentum's sum of squares in a one-hop all-gather, the
+// Metropolis test (hmc.py:159-177) evaluated identically by every workgroup.  Same contract as
+// resident_chain_kernel (K trajectories per launch, the host draws the momenta and variates in the reference's
+// order; every wait bounded, an aborted launch leaves the chain untouched).  Element-wise regularisers
+// (Damping, MS); the stencil kinds stay on the launches of lonsymh.hip.h.
+// Reference arithmetic: inversion/hmc.py:85-177, inversion/potential.py:698-736, gravmag/_tesseroid_numba.py:207-222.
+#pragma once
+#include "lonsymh.hip.h"
+#include "resbatch.hip.h"
+
+namespace ghk {
+
+constexpr int LR_THREADS = 256;
+constexpr int LR_MAXWG = 256;
+
+struct LonResArgs {
+    LonHarmGeom g;
+    int64_t N, M;
+    int nwg, try_local;
+    const double *wm;             // column weights (nullptr: none)
+    const double *low, *high, *mwapr, *wm2;
+    int kind, ms_grad_den_mw;
+    double alpha, beta;
+    const double *dobs_c, *gfix;  // gfix: nullptr without a fixed part of the data term
+    double gfix_sum;
+    const d2 *Mhat;               // [na][nf]: transform of the slots' observation counts (R^ of a residual of ones)
+    // chain
+    double *x_cur;                // M: in = current sample, out = current sample after the last trajectory run
+    int K;
+    const int *L;
+    const double *p0s;            // K x M
+    const double *us;             // K
+    double dt;
+    long long stop_at_accepts, accept_count0;
+    int *accepted;                // K
+    double *out5s;                // K x {U, U_data, R, H_current, H_proposal}
+    double *xacc;                 // K x M accepted samples (nullptr: not wanted)
+    int *n_run;                   // [0] trajectories run, [1] evaluations, [2] trajectory-end exchanges
+    double *ucur;                 // 3: {U, U_data, R} of the current sample at the end
+    // exchange (tags continue over launches)
+    d2 *slab;                     // (nwg + 8) x E forward partials, untagged
+    u64 *flagg;                   // nwg + 8
+    u32x4 *xslabg;                // 2 x 8 x E x 2 cluster sums
+    u32x4 *rhatg;                 // 2 x E x 2
+    u32x4 *clsg;                  // 2 x 64 x 4: per class {sum of d, sum of q, sum of q^2} (q: residual against the previous mean)
+    u32x4 *scalg;                 // 2 x LR_MAXWG x 2: per workgroup {regulariser share, p0'p0 share}
+    u32x4 *ppg;                   // 2 x LR_MAXWG: per workgroup p'p share at the end of a trajectory
+    u64 *xccg;
+    unsigned tag0, tagE0, ltag;
+    unsigned *abort_w;
+    long long *dbg;               // optional: 16 accumulated phase times (100 MHz ticks) of workgroup 0
+};
+
+static inline size_t lonres_lds_doubles(int n, int nf, int na, int rw)
+{
+    return lonsymh_lds_doubles(n, nf, na, rw) + 2 * 64 + 128 + 8 * 64 + 2 * 64 + 3 * LR_MAXWG + 64;
+}
+
+// Sums of NV values over the workgroup's four waves in a fixed tree (the same bits wherever the same values meet),
+// valid in every thread.  redn: 4 NV doubles of LDS; two barriers.
+template <int NV>
+__device__ __forceinline__ void block_sums(double (&v)[NV], double *redn)
+{
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_allreduce_sum(v[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) redn[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ((redn[i] + redn[NV + i]) + redn[2 * NV + i]) + redn[3 * NV + i];
+}
+
+template <int RW>
+__global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const LonHarmGeom &g = a.g;
+    const int tid = threadIdx.x, f = tid & 63, ag = tid >> 6, lane = tid & 63, wave = tid >> 6;
+    const int n = g.n, nf = g.nf, na = g.na, E = na * nf;
+    const int w = blockIdx.x, nwg = a.nwg;
+    const bool fv = f < nf;
+    d2 *Rh = reinterpret_cast<d2 *>(smem);                   // na x nf
+    d2 *tws = Rh + (size_t)na * nf;                           // n
+    d2 *Gp = tws + n;                                         // RW x 4 x nf
+    d2 *Gh = Gp + RW * 4 * nf;                                // RW x nf
+    double *xs = reinterpret_cast<double *>(Gh + RW * nf);    // RW x n
+    d2 *Xp = reinterpret_cast<d2 *>(xs + RW * n);             // RW x 4 x nf
+    double *red = reinterpret_cast<double *>(Xp + RW * 4 * nf);  // 16
+    d2 *Dh = reinterpret_cast<d2 *>(red + 16);                // 64: the owner's D^[a][:]
+    double *row = reinterpret_cast<double *>(Dh + 64);        // 128: slot sums of the class's residuals
+    d2 *Rp = reinterpret_cast<d2 *>(row + 128);               // 4 x 64 quarters of the owner's forward transform
+    double *cls = reinterpret_cast<double *>(Rp + 4 * 64);    // 2 x 64 class scalars
+    double *scs = cls + 2 * 64;                               // 3 x LR_MAXWG (block_sums' scratch in front)
+    double *redn = scs;
+    d2 *Cr = reinterpret_cast<d2 *>(scs + 64);                // RW x nf: sum_a conj(T^_r[a][f]) M^[a][f], see the mean
+    int *flag_s = reinterpret_cast<int *>(scs + 3 * LR_MAXWG);
+    long long *tacc_s = reinterpret_cast<long long *>(scs + 3 * LR_MAXWG + 2);
+
+    long long tlast = 0;
+    const bool timing = a.dbg != nullptr && tid == 0 && w == 0;
+    auto tick = [&](int slot) {
+        if (timing) {
+            const long long now = wall_clock64();
+            tacc_s[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    if (timing) {
+        for (int i = 0; i < 16; ++i) tacc_s[i] = 0;
+        tlast = wall_clock64();
+    }
+
+    // ---- resident operands: the rows' table (registers), twiddles (LDS), the cells' constants (registers)
+    d2 th[RW][LH_AK];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int c = w + r * nwg;
+        const d2 *Tg = g.That + (int64_t)(c < g.nc ? c : w) * na * nf;
+#pragma unroll
+        for (int u = 0; u < LH_AK; ++u) {
+            const int aa = ag * LH_AK + u;
+            th[r][u] = (fv && aa < na && c < g.nc) ? Tg[aa * nf + f] : d2{0.0, 0.0};
+        }
+    }
+    for (int e = tid; e < n; e += LR_THREADS) tws[e] = g.tw[e];
+    if (tid == 0) *flag_s = 1;
+    constexpr int NI = (RW * 128 + LR_THREADS - 1) / LR_THREADS;  // (row, longitude) items per thread (n <= 126)
+    int64_t ij[NI];
+    bool iv[NI];
+    double iw[NI], hi[NI], lo[NI], apr[NI], w2[NI], xc[NI], gc[NI], x[NI], p[NI], grad[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int it = tid + q * LR_THREADS, r = it / n, k = it - r * n;
+        const int c = w + r * nwg;
+        iv[q] = r < RW && c < g.nc;
+        ij[q] = (int64_t)(iv[q] ? c : 0) * n + k;
+        iw[q] = 1.0;
+        hi[q] = lo[q] = apr[q] = xc[q] = gc[q] = x[q] = p[q] = grad[q] = 0.0;
+        w2[q] = 1.0;
+        if (iv[q]) {
+            const int64_t j = ij[q];
+            const double wj = a.wm ? a.wm[j] : 1.0;
+            iw[q] = (wj != 0.0) ? 1.0 / wj : 1.0;
+            hi[q] = a.high[j];
+            lo[q] = a.low[j];
+            apr[q] = a.mwapr[j];
+            if (a.kind == 2) w2[q] = a.wm2[j];
+            xc[q] = a.x_cur[j];
+            x[q] = xc[q];
+        }
+    }
+
+    // ---- clusters and placement (resident.hip.h)
+    const int ncl = nwg < RES_CLUSTERS ? nwg : RES_CLUSTERS;
+    const int cg = w % RES_CLUSTERS, crank = w / RES_CLUSTERS;
+    const int cn = (nwg - cg + RES_CLUSTERS - 1) / RES_CLUSTERS;
+    const int ch = (E + cn - 1) / cn;  // entries of the cluster sum this workgroup produces
+    bool local = false;
+    {
+        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;  // HW_REG_XCC_ID[3:0]
+        if (tid == 0)
+            __hip_atomic_store(a.xccg + w, ((u64)a.ltag << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (wave == 0) {
+            bool same = true;
+            const bool got = res_poll(a.abort_w, [&]() -> bool {
+                bool ok = true;
+                if (lane < cn) {
+                    const u64 e = __hip_atomic_load(a.xccg + cg + RES_CLUSTERS * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned)(e >> 32) == a.ltag;
+                    same = ((unsigned)e & 0xfu) == xcc;
+                }
+                return ok;
+            });
+            if (lane == 0) red[8] = (got && __all(same) && a.try_local) ? 1.0 : 0.0;
+            if (!got) *flag_s = 0;
+        }
+        __syncthreads();
+        local = red[8] != 0.0;
+        if (*flag_s == 0) return;
+    }
+    const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.slab, 0, (int)((size_t)(nwg + 8) * E * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_xs = __builtin_amdgcn_make_buffer_rsrc(a.xslabg, 0, 2 * RES_CLUSTERS * E * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rh = __builtin_amdgcn_make_buffer_rsrc(a.rhatg, 0, 2 * E * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cls = __builtin_amdgcn_make_buffer_rsrc(a.clsg, 0, 2 * 64 * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(a.scalg, 0, 2 * LR_MAXWG * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_pp = __builtin_amdgcn_make_buffer_rsrc(a.ppg, 0, 2 * LR_MAXWG * 16, 0x00020000);
+
+    // ---- the class this workgroup owns (at most one: nwg >= na), the observations of its slots
+    int own = -1;
+    {
+        const int a0 = (int)(((long long)w * na + nwg - 1) / nwg);
+        if (a0 < na && (int)(((long long)a0 * nwg) / na) == w) own = a0;
+    }
+    int o_i[3] = {-1, -1, -1};
+    double o_dobs[3] = {0.0, 0.0, 0.0}, o_gfix[3] = {0.0, 0.0, 0.0};
+    if (own >= 0 && tid < n) {
+        const int e = own * n + tid;
+        o_i[0] = g.slot_first[e];
+        int nx = 1;
+        for (int xx = 0; xx < g.n_xslots; ++xx)
+            if (g.xslot[xx] == e)
+                for (int qq = g.xptr[xx]; qq < g.xptr[xx + 1] && nx < 3; ++qq) o_i[nx++] = g.xobs[qq];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (o_i[u] >= 0) {
+                o_dobs[u] = a.dobs_c[o_i[u]];
+                o_gfix[u] = a.gfix ? a.gfix[o_i[u]] : 0.0;
+            }
+    }
+    const int qn = (n + 3) / 4;
+    __syncthreads();
+    // What a change dm of the data's mean does to the adjoint product: r -> r - dm in every observation is
+    // R^ -> R^ - dm M^, S^_r[f] -> S^_r[f] - dm C_r[f] with C_r[f] = sum_a conj(T^_r[a][f]) M^[a][f]: a constant of the row.
+    if (fv) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            d2 gp = d2{0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < LH_AK; ++u) {
+                const int aa = ag * LH_AK + u;
+                const d2 m = a.Mhat[(aa < na ? aa : na - 1) * nf + f];
+                gp.x += th[r][u].x * m.x + th[r][u].y * m.y;
+                gp.y += th[r][u].x * m.y - th[r][u].y * m.x;
+            }
+            Gp[(r * 4 + ag) * nf + f] = gp;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < RW * nf; e += LR_THREADS) {
+        const int r = e / nf, ff = e - r * nf;
+        d2 sres = Gp[(r * 4) * nf + ff];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            sres.x += Gp[(r * 4 + q) * nf + ff].x;
+            sres.y += Gp[(r * 4 + q) * nf + ff].y;
+        }
+        Cr[e] = sres;
+    }
+    __syncthreads();
+
+    // ---- the chain
+    // (k = -2: a first evaluation at the current sample for the mean of its data alone -- the residuals of an
+    // evaluation are formed against the mean of the one before)
+    int k = -2, s = 0, Lk = 0, n_done = 0;
+    double mean_prev = 0.0, sc5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double uk = 0.0, pp0 = 0.0, pp0_share = 0.0, U0 = 0.0, U1 = 0.0, U2 = 0.0;
+    long long accepts = a.accept_count0;
+    unsigned ev = 0, evE = 0;
+    bool stop = false;
+    tick(0);
+    for (;;) {
+        ev += 1;
+        const unsigned tag = a.tag0 + ev;
+        const int par = (int)(ev & 1u);
+        // ================= evaluation at x: forward product of the rows, the exchange, adjoint product -> grad
+        // regulariser (potential.py:719-736): value share, alpha dR/dx per cell
+        double greg[NI], rval = 0.0;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const double v = x[q] - apr[q];
+            double gq = 0.0, val = 0.0;
+            if (a.kind == 0) {
+                val = v * v;
+                gq = 2.0 * v;
+            } else {
+                const double v2 = v * v, den = v2 + a.beta;
+                val = (w2[q] * v2) / den;
+                const double deng = a.ms_grad_den_mw ? x[q] * x[q] + a.beta : den;
+                gq = (2.0 * a.beta * w2[q] * v) / (deng * deng);
+            }
+            greg[q] = iv[q] ? a.alpha * gq : 0.0;
+            rval += iv[q] ? val : 0.0;
+            const int it = tid + q * LR_THREADS, r = it / n, kk = it - r * n;
+            if (r < RW) xs[r * n + kk] = iv[q] ? x[q] * iw[q] : 0.0;
+        }
+        tick(10);
+        const double rsh = block_allreduce_sum(rval, red, LR_THREADS / 64);  // (barriers: xs is in place)
+        tick(11);
+        // X^_r[f]: quarter ag of the longitudes, then the four quarters; D^ partial of the workgroup
+        if (fv) {
+            const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) Xp[(r * 4 + ag) * nf + f] = lh_dft_part(xs + r * n, tws, k0 < n ? k0 : n, k1, f, n);
+        }
+        __syncthreads();
+        tick(12);
+        d2 dacc[LH_AK];
+#pragma unroll
+        for (int u = 0; u < LH_AK; ++u) dacc[u] = d2{0.0, 0.0};
+        if (fv) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                d2 xh = Xp[(r * 4) * nf + f];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    xh.x += Xp[(r * 4 + q) * nf + f].x;
+                    xh.y += Xp[(r * 4 + q) * nf + f].y;
+                }
+#pragma unroll
+                for (int u = 0; u < LH_AK; ++u) {
+                    dacc[u].x += th[r][u].x * xh.x - th[r][u].y * xh.y;
+                    dacc[u].y += th[r][u].x * xh.y + th[r][u].y * xh.x;
+                }
+            }
+        }
+        tick(1);
+        // ---- publish: the partial behind one flag, the scalars as granules
+        if (fv) {
+#pragma unroll
+            for (int u = 0; u < LH_AK; ++u) {
+                const int aa = ag * LH_AK + u;
+                if (aa < na) rb_store2(rs_slab, (unsigned)(((size_t)w * E + aa * nf + f) * 16), dacc[u].x, dacc[u].y, local);
+            }
+        }
+        if (tid == 0) {
+            rb_store(rs_sc, (unsigned)(((par * LR_MAXWG + w) * 2 + 0) * 16), rb_pack(tag, rsh), false);
+            rb_store(rs_sc, (unsigned)(((par * LR_MAXWG + w) * 2 + 1) * 16), rb_pack(tag, pp0_share), false);
+        }
+        pp0_share = 0.0;  // (p0'p0 of a trajectory rides on its first evaluation only)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (local)
+                __hip_atomic_store(a.flagg + w, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else
+                __hip_atomic_store(a.flagg + w, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tick(2);
+        // ---- hop 1: this workgroup's chunk of the entries, summed over the cluster's members in order
+        if (wave == 0) {
+            const bool got = res_poll(a.abort_w, [&]() -> bool {
+                bool ok = true;
+                if (lane < cn) {
+                    const u64 e = __hip_atomic_load(a.flagg + cg + RES_CLUSTERS * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned)e == tag;
+                }
+                return ok;
+            });
+            if (!got) *flag_s = 0;
+        }
+        __syncthreads();
+        if (*flag_s == 0) return;
+        tick(3);
+        for (int t0 = 0; t0 < ch; t0 += LR_THREADS) {
+            const int e = crank * ch + t0 + tid;
+            if (t0 + tid < ch && e < E) {
+                d2 sum = d2{0.0, 0.0};
+                int m = 0;
+                for (; m + 8 <= cn; m += 8) {
+                    d2 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = rb_load2(rs_slab, (unsigned)(((size_t)(cg + RES_CLUSTERS * (m + u)) * E + e) * 16));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        sum.x += v[u].x;
+                        sum.y += v[u].y;
+                    }
+                }
+                for (; m < cn; ++m) {
+                    const d2 v = rb_load2(rs_slab, (unsigned)(((size_t)(cg + RES_CLUSTERS * m) * E + e) * 16));
+                    sum.x += v.x;
+                    sum.y += v.y;
+                }
+                const unsigned off = (unsigned)((((size_t)par * RES_CLUSTERS + cg) * E + e) * 32);
+                rb_store(rs_xs, off, rb_pack(tag, sum.x), false);
+                rb_store(rs_xs, off + 16, rb_pack(tag, sum.y), false);
+            }
+        }
+        tick(4);
+        // ---- hop 2: the owner of a class
+        if (own >= 0) {
+            if (wave == 0) {
+                unsigned off[16];
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    off[u] = (unsigned)((((size_t)par * RES_CLUSTERS + (u >> 1)) * E + own * nf + (fv ? f : 0)) * 32 + (u & 1) * 16);
+                const bool got = rb_poll<16>(a.abort_w, rs_xs, tag, fv ? 2 * ncl : 0, off, v);
+                if (!got) *flag_s = 0;
+                if (fv) {
+                    double sx = 0.0, sy = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < ncl) {
+                            sx += v[2 * u];
+                            sy += v[2 * u + 1];
+                        }
+                    const double wf = (f == 0 || (2 * f == n)) ? 1.0 : 2.0;
+                    Dh[f] = d2{sx * wf, sy * wf};
+                }
+            }
+            __syncthreads();
+            if (*flag_s == 0) return;
+            // the class's predicted data; residuals against the PREVIOUS evaluation's mean (potential.py:700-706:
+            // r = d + grav_fix - mean - dobs; the mean of this evaluation needs every class -- the consumers correct for
+            // the difference, below), slot sums, the class's sums
+            double ds = 0.0, q1 = 0.0, q2 = 0.0;
+            if (tid < n) {
+                const double dk = lh_idft_part(Dh, tws, 0, nf, tid, n) / (double)n;
+                double rs_ = 0.0;
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (o_i[u] >= 0) {
+                        const double qi = ((dk + o_gfix[u]) - mean_prev) - o_dobs[u];
+                        ds += dk;
+                        rs_ += qi;
+                        q1 += qi;
+                        q2 += qi * qi;
+                    }
+                row[tid] = rs_;
+            }
+            double cs[3] = {ds, q1, q2};
+            block_sums<3>(cs, redn);  // (barriers: row is in place)
+            if (fv) {
+                const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
+                Rp[ag * 64 + f] = lh_dft_part(row, tws, k0 < n ? k0 : n, k1, f, n);
+            }
+            __syncthreads();
+            if (tid < nf) {
+                d2 sres = Rp[tid];
+#pragma unroll
+                for (int u = 1; u < 4; ++u) {
+                    sres.x += Rp[u * 64 + tid].x;
+                    sres.y += Rp[u * 64 + tid].y;
+                }
+                const unsigned off = (unsigned)(((size_t)par * E + own * nf + tid) * 32);
+                rb_store(rs_rh, off, rb_pack(tag, sres.x), false);
+                rb_store(rs_rh, off + 16, rb_pack(tag, sres.y), false);
+            }
+            if (tid < 3) rb_store(rs_cls, (unsigned)(((par * 64 + own) * 4 + tid) * 16), rb_pack(tag, cs[tid]), false);
+        }
+        tick(5);
+        // ---- hop 3: R^ and the scalars, everybody
+        {
+            bool okall = true;
+            for (int e0 = 0; e0 < E; e0 += 8 * LR_THREADS) {
+                unsigned off[16];
+                double v[16];
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * LR_THREADS + tid;
+                    const int ee = e < E ? e : 0;
+                    off[2 * u] = (unsigned)(((size_t)par * E + ee) * 32);
+                    off[2 * u + 1] = off[2 * u] + 16;
+                    if (e < E) cnt = 2 * (u + 1);
+                }
+                okall = rb_poll<16>(a.abort_w, rs_rh, tag, cnt, off, v) && okall;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * LR_THREADS + tid;
+                    if (e < E) Rh[e] = d2{v[2 * u], v[2 * u + 1]};
+                }
+            }
+            double v5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            {
+                unsigned off[3];
+                double v[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) off[u] = (unsigned)(((par * 64 + (tid < na ? tid : 0)) * 4 + u) * 16);
+                okall = rb_poll<3>(a.abort_w, rs_cls, tag, tid < na ? 3 : 0, off, v) && okall;
+                if (tid < na) {
+                    v5[2] = v[0];
+                    v5[3] = v[1];
+                    v5[4] = v[2];
+                }
+            }
+            {
+                unsigned off[2] = {(unsigned)(((par * LR_MAXWG + (tid < nwg ? tid : 0)) * 2) * 16),
+                                   (unsigned)(((par * LR_MAXWG + (tid < nwg ? tid : 0)) * 2 + 1) * 16)};
+                double v[2];
+                okall = rb_poll<2>(a.abort_w, rs_sc, tag, tid < nwg ? 2 : 0, off, v) && okall;
+                if (tid < nwg) {
+                    v5[0] = v[0];
+                    v5[1] = v[1];
+                }
+            }
+            if (!okall) *flag_s = 0;
+            // (sums over the workgroups / classes in a fixed tree: the same bits in every workgroup; the barriers inside
+            // also publish R^ and the flag)
+            block_sums<5>(v5, redn);
+            sc5[0] = v5[0];
+            sc5[1] = v5[1];
+            sc5[2] = v5[2];
+            sc5[3] = v5[3];
+            sc5[4] = v5[4];
+        }
+        if (*flag_s == 0) return;
+        tick(6);
+        const double Rtot = sc5[0], pp0tot = sc5[1];
+        const double mean = (sc5[2] + a.gfix_sum) / (double)a.N;
+        const double dmean = mean - mean_prev;
+        const double Ud = (sc5[4] - 2.0 * dmean * sc5[3]) + (double)a.N * dmean * dmean;
+        mean_prev = mean;
+        // ---- adjoint product: S^_r[f] = sum_a conj(T^_r[a][f]) R^[a][f]
+        if (fv) {
+            d2 rr[LH_AK];
+#pragma unroll
+            for (int u = 0; u < LH_AK; ++u) {
+                const int aa = ag * LH_AK + u;
+                rr[u] = Rh[(aa < na ? aa : na - 1) * nf + f];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                d2 gp = d2{0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < LH_AK; ++u) {
+                    gp.x += th[r][u].x * rr[u].x + th[r][u].y * rr[u].y;
+                    gp.y += th[r][u].x * rr[u].y - th[r][u].y * rr[u].x;
+                }
+                Gp[(r * 4 + ag) * nf + f] = gp;
+            }
+        }
+        tick(13);
+        __syncthreads();
+        for (int e = tid; e < RW * nf; e += LR_THREADS) {
+            const int r = e / nf, ff = e - r * nf;
+            d2 sres = Gp[(r * 4) * nf + ff];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                sres.x += Gp[(r * 4 + q) * nf + ff].x;
+                sres.y += Gp[(r * 4 + q) * nf + ff].y;
+            }
+            const double wf = (ff == 0 || (2 * ff == n)) ? 1.0 : 2.0;
+            Gh[e] = d2{(sres.x - dmean * Cr[e].x) * wf, (sres.y - dmean * Cr[e].y) * wf};
+        }
+        __syncthreads();
+        tick(14);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int it = tid + q * LR_THREADS, r = it / n, kk = it - r * n;
+            if (iv[q]) {
+                const double sv = lh_idft_part(Gh + r * nf, tws, 0, nf, kk, n);
+                grad[q] = 2.0 * ((sv / (double)n) * iw[q]) + greg[q];
+            }
+        }
+        tick(7);
+        // ================= what the evaluation was for
+        bool next_traj = false;
+        if (k == -2) {
+            k = -1;  // (the mean is known now: the same evaluation again, for good)
+        } else if (k < 0) {
+            // the chain's current sample: gradient and potential (hmc.py:85-93)
+#pragma unroll
+            for (int q = 0; q < NI; ++q) gc[q] = grad[q];
+            U1 = Ud;
+            U2 = Rtot;
+            U0 = Ud + a.alpha * Rtot;
+            next_traj = true;
+        } else if (s < Lk) {
+            // a full step (hmc.py:114-141)
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                double pj = p[q] - a.dt * grad[q];
+                double xj = x[q] + a.dt * pj;
+                if (xj > hi[q]) {
+                    xj = hi[q];
+                    pj = -pj;
+                } else if (xj < lo[q]) {
+                    xj = lo[q];
+                    pj = -pj;
+                }
+                p[q] = pj;
+                x[q] = xj;
+            }
+            if (s == 1) pp0 = pp0tot;  // (the trajectory's p0'p0 arrived with its first evaluation)
+            s += 1;
+        } else {
+            if (s == 1) pp0 = pp0tot;
+            // the last half step of the momentum, its sum of squares over all cells (hmc.py:151-157)
+            double pps = 0.0;
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const double pf = p[q] - 0.5 * a.dt * grad[q];
+                pps += iv[q] ? pf * pf : 0.0;
+            }
+            const double ppw = block_allreduce_sum(pps, red, LR_THREADS / 64);
+            evE += 1;
+            const unsigned tagE = a.tagE0 + evE;
+            const int parE = (int)(evE & 1u);
+            if (tid == 0) rb_store(rs_pp, (unsigned)((parE * LR_MAXWG + w) * 16), rb_pack(tagE, ppw), false);
+            double pp1v[1] = {0.0};
+            {
+                unsigned off[1] = {(unsigned)((parE * LR_MAXWG + (tid < nwg ? tid : 0)) * 16)};
+                double v[1];
+                const bool got = rb_poll<1>(a.abort_w, rs_pp, tagE, tid < nwg ? 1 : 0, off, v);
+                if (tid < nwg) pp1v[0] = v[0];
+                if (!got) *flag_s = 0;
+            }
+            block_sums<1>(pp1v, redn);
+            if (*flag_s == 0) return;
+            const double pp1 = pp1v[0];
+            // Metropolis (hmc.py:159-177): the same bits in every workgroup
+            const double Unew = Ud + a.alpha * Rtot;
+            const double Hcur = 0.5 * pp0 + U0, Hnew = 0.5 * pp1 + Unew;
+            const bool acc = (Hnew < Hcur) || (uk < exp(-(Hnew - Hcur)));
+            if (acc) {
+#pragma unroll
+                for (int q = 0; q < NI; ++q) {
+                    xc[q] = x[q];
+                    gc[q] = grad[q];
+                    if (a.xacc && iv[q]) a.xacc[(int64_t)k * a.M + ij[q]] = x[q];
+                }
+                U0 = Unew;
+                U1 = Ud;
+                U2 = Rtot;
+                accepts += 1;
+            }
+            if (w == 0 && tid == 0) {
+                a.accepted[k] = acc ? 1 : 0;
+                double *o = a.out5s + 5 * (int64_t)k;
+                o[0] = U0;
+                o[1] = U1;
+                o[2] = U2;
+                o[3] = Hcur;
+                o[4] = Hnew;
+            }
+            n_done = k + 1;
+            if (acc && a.stop_at_accepts > 0 && accepts >= a.stop_at_accepts) stop = true;
+            next_traj = true;
+        }
+        tick(8);
+        if (next_traj) {
+            k += 1;
+            if (k >= a.K || stop) break;
+            // the next trajectory: its momentum, first half step from the current sample (hmc.py:95-113)
+            Lk = a.L[k];
+            uk = a.us[k];
+            double pps = 0.0;
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const double p0 = iv[q] ? a.p0s[(int64_t)k * a.M + ij[q]] : 0.0;
+                pps += p0 * p0;
+                double pj = p0 - 0.5 * a.dt * gc[q];
+                double xj = xc[q] + a.dt * pj;
+                if (xj > hi[q]) {
+                    xj = hi[q];
+                    pj = -pj;
+                } else if (xj < lo[q]) {
+                    xj = lo[q];
+                    pj = -pj;
+                }
+                p[q] = pj;
+                x[q] = xj;
+            }
+            pp0_share = block_allreduce_sum(pps, red, LR_THREADS / 64);  // this workgroup's share: published with the evaluation
+            s = 1;
+            tick(9);
+        }
+    }
+    // ---- the chain's state
+#pragma unroll
+    for (int q = 0; q < NI; ++q)
+        if (iv[q]) a.x_cur[ij[q]] = xc[q];
+    if (w == 0 && tid == 0) {
+        a.n_run[0] = n_done;
+        a.n_run[1] = (int)ev;
+        a.n_run[2] = (int)evE;
+        a.ucur[0] = U0;
+        a.ucur[1] = U1;
+        a.ucur[2] = U2;
+    }
+    if (timing)
+        for (int i = 0; i < 16; ++i) a.dbg[i] += tacc_s[i];
+}
+
+}  // namespace ghk

@@ -511,6 +511,16 @@ class Engine(object):
             return acc.astype(bool), out5, xs, ns, nd
         return acc.astype(bool), out5, xs
 
+    def shift_invariant_resident_stats(self):
+        """The harmonic pass of the shift-invariant store as one persistent launch per run_chain call
+        (csrc/lonres.hip.h): grid, launches, evaluations, trajectories, time-outs."""
+        wg, t = C.c_int(0), C.c_int(0)
+        l, e, tr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.gh_shift_invariant_resident_stats(self._h, C.byref(wg), C.byref(l), C.byref(e), C.byref(tr),
+                                                              C.byref(t)))
+        return {"workgroups": wg.value, "launches": l.value, "evaluations": e.value, "trajectories": tr.value,
+                "timeouts": t.value}
+
     def pinned_empty(self, shape):
         """A float64 array in page-locked host memory of the library (gh_pinned_alloc): momentum rows drawn into
         it go to the device without a gather on the host.  It lives until pinned_free(array) or close()."""

@@ -128,6 +128,15 @@ int gh_shift_invariant_info(const gh_ctx *ctx, int *n_lon, int *n_classes, int *
  * of the pass.  gh_batch_* on a shift-invariant context (BASELINE configs[3]: 8 chains) runs every chain as a
  * light context of its own -- stream, chain state, work buffers -- on the shared tables, one host thread per
  * chain; nothing stays in flight between calls (n_started = n_done = T in carry-over mode). */
+/* The harmonic pass as ONE persistent launch per gh_chain_run call (csrc/lonres.hip.h): every workgroup keeps its cell
+ * rows' part of the table in registers for the whole batch of trajectories and the workgroups exchange the forward
+ * partials, the residuals' transforms and the Metropolis sums through memory (bounded waits; a launch that gives up
+ * leaves the chain untouched and the call runs on the launches per phase).  Element-wise regularisers (Damping, MS),
+ * one chain per GPU (example/global/run_main.sh:16 runs one chain per rank).  workgroups: grid of the launch (0: not
+ * in use); launches, evaluations (forward + adjoint product each), trajectories so far, timeouts.
+ * GRAVHMC_LONSYM_RESIDENT=0 switches it off. */
+int gh_shift_invariant_resident_stats(gh_ctx *ctx, int *workgroups, int64_t *launches, int64_t *evaluations,
+                                      int64_t *trajectories, int *timeouts);
 int gh_shift_invariant_harmonic(const gh_ctx *ctx, int *on, int *n_freq, int64_t *table_bytes, int *workgroups);
 /* Work of the matrix-free passes since gh_profile_enable(ctx, 1) (fused form only): entries
  * evaluated, 2x2x2 Gauss-Legendre leaves evaluated (tesseroids; = entries for prisms), launches.

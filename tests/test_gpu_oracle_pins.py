@@ -373,3 +373,125 @@ def test_shift_invariant_batch_of_chains_against_the_oracle(G, orc):
     assert worst < 1e-10
     tb.close()
     ts.close()
+
+
+def _run_chain_lists(t, Ls, p0s, us, dt):
+    """Engine.run_chain over the given trajectories in ONE library call; per trajectory (accepted, out5, x)."""
+    got = []
+    t.run_chain(iter([(int(L), p, float(u)) for L, p, u in zip(Ls, p0s, us)]), dt,
+                lambda L, acc, o5, x: got.append((bool(acc), np.array(o5), None if x is None else x.copy())),
+                want_x=True, batch=len(Ls))
+    return got
+
+
+@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size"])
+def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkeypatch):
+    """lonsymh_resident_kernel (csrc/lonres.hip.h): a batch of trajectories of the chain on the shift-invariant store
+    in ONE persistent launch -- the table in the workgroups' registers, forward partials / R^ / Metropolis sums
+    exchanged through memory.  coarse (36 longitudes, duplicated +-180 observations, two observation heights,
+    shuffled order): every trajectory against oracle.Problem.leapfrog on the oracle's dense tesseroid kernel
+    (inversion/hmc.py:85-177 over potential.py:688-736), Damping and MS, decisions included.  C4 at full size
+    (BASELINE configs[3]: one chain per GPU): against the same chain on the launches per phase
+    (GRAVHMC_LONSYM_RESIDENT=0), which test_shift_invariant_store_against_the_oracle pins to the oracle's rows."""
+    rng = np.random.default_rng(17)
+    if case == "coarse_odd_sizes":
+        mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
+        h[::3] = 45000.0
+        perm = rng.permutation(lon.size)
+        lon, lat, h = lon[perm], lat[perm], h[perm]
+    else:
+        mesh, lon, lat, h = _global_model(G, 3.0, 3.0, -300000, 5000.0)
+    N, M = lon.size, mesh.size
+    bounds = mesh.cell_bounds()
+
+    def engine():
+        t = G.Engine(N, M)
+        t.set_shift_invariant(True)
+        t.set_obs(lon, lat, h)
+        t.set_cells(bounds, 1, 1.6)
+        t.build_G()
+        return t
+
+    t = engine()
+    wm = t.weight(0.5)
+    rho = np.zeros(mesh.shape)
+    rho[:, mesh.shape[1] // 3: mesh.shape[1] // 2, 2: mesh.shape[2] // 3] = 0.4
+    Aw = None
+    if case == "coarse_odd_sizes":
+        K = orc.tess_gz_kernel(lon, lat, h, bounds)
+        Aw, wmo = orc.col_weight(K)
+        assert relmax(wm, wmo) < 1e-11
+        d_true = K @ rho.ravel()
+    else:
+        t0 = engine()
+        d_true = t0.forward(rho.ravel())
+        t0.close()
+    dobs = d_true + 0.02 * np.abs(d_true).max() * rng.normal(size=N)
+    low, high = 0.0 * wm, 0.8 * wm
+    nK = 7
+    Ls = [int(v) for v in rng.integers(1, 7, nK)]
+    Ls[2] = 1                                                  # (a trajectory of a single step)
+    p0s = [rng.normal(size=M) * 0.001 for _ in range(nK)]
+    us = [float(v) for v in rng.uniform(size=nK)]
+    us[4] = 1.0 - 1e-12                                        # (as good as certainly rejected unless H drops)
+    for reg in ("Damping", "MS"):
+        t.set_data(dobs)
+        t.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wm)
+        t.chain_init(0.3 * wm * rng.uniform(0.1, 1.0, M), low, high)
+        x0 = t.chain_get_x()
+        got = _run_chain_lists(t, Ls, p0s, us, 0.005)
+        st = t.shift_invariant_resident_stats()
+        assert st["workgroups"] > 0 and st["launches"] >= 1 and st["timeouts"] == 0, st
+        assert st["evaluations"] >= sum(Ls) + 1
+        x_end = t.chain_get_x()
+        if case == "coarse_odd_sizes":
+            P = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.05, 0.01, wm=wm, shape=mesh.shape)
+            xo, worst, nacc = x0, 0.0, 0
+            for k in range(nK):
+                xo, ao, oo, _ = P.leapfrog(xo, p0s[k], 0.005, Ls[k], low, high, us[k])
+                assert got[k][0] == ao, (reg, k)
+                worst = max(worst, relmax(got[k][1], oo))
+                if ao:
+                    nacc += 1
+                    worst = max(worst, relmax(got[k][2], xo))
+            worst = max(worst, relmax(x_end, xo))
+            print("persistent harmonic pass [coarse, %s] vs oracle.Problem trajectories: %.2e, %d of %d accepted"
+                  % (reg, worst, nacc, nK))
+            assert worst < 1e-10
+        else:
+            monkeypatch.setenv("GRAVHMC_LONSYM_RESIDENT", "0")
+            t2 = engine()
+            t2.weight(0.5)
+            t2.set_data(dobs)
+            t2.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wm)
+            t2.chain_init(x0, low, high)
+            if reg == "MS":
+                # (MS at this step size is stiff in some cells: rounding differences grow ~30x per trajectory -- measured
+                # 1.6e-16, 2.3e-13, 1.2e-12, 8.8e-10 ... along the list above -- so every trajectory starts from the
+                # reference chain's sample again; Damping runs the whole list in one launch.  The switch is read when a
+                # context plans its first run: t has planned, t2 plans under it)
+                got, ref, xk = [], [], x0
+                for k in range(nK):
+                    t.chain_init(xk, low, high)
+                    t2.chain_init(xk, low, high)
+                    got += _run_chain_lists(t, Ls[k:k + 1], p0s[k:k + 1], us[k:k + 1], 0.005)
+                    ref += _run_chain_lists(t2, Ls[k:k + 1], p0s[k:k + 1], us[k:k + 1], 0.005)
+                    xk = t2.chain_get_x()
+                x_end = t.chain_get_x()
+                assert t.shift_invariant_resident_stats()["launches"] >= 1 + nK
+            else:
+                ref = _run_chain_lists(t2, Ls, p0s, us, 0.005)
+            monkeypatch.delenv("GRAVHMC_LONSYM_RESIDENT")
+            assert t2.shift_invariant_resident_stats()["launches"] == 0
+            worst = 0.0
+            for k in range(nK):
+                assert got[k][0] == ref[k][0], (reg, k)
+                worst = max(worst, relmax(got[k][1], ref[k][1]))
+                if ref[k][0]:
+                    worst = max(worst, relmax(got[k][2], ref[k][2]))
+            worst = max(worst, relmax(x_end, t2.chain_get_x()))
+            print("persistent harmonic pass [C4 size, %s] vs the launches per phase: %.2e, %d of %d accepted"
+                  % (reg, worst, sum(g[0] for g in got), nK))
+            assert worst < 1e-10
+            t2.close()
+    t.close()
