@@ -21,7 +21,7 @@ static bool lonres_plan(gh_ctx *c)
     r.state = -1;
     if (env_int("GRAVHMC_LONSYM_RESIDENT", 1) == 0) return false;
     if (c->sh.kind != 0 || c->wv.on) return false;
-    if (h.hgrid > LR_MAXWG || h.hgrid < h.na || (int64_t)h.hgrid * h.rw < h.nc || h.na > 64 || h.n > 126 || h.max_extra > 2) return false;
+    if (h.hgrid > LR_MAXWG || h.hgrid < h.na || (int64_t)h.hgrid * h.rw < h.nc || h.na > 64 || h.n > 126 || h.n < 2 || h.max_extra > 2) return false;
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) return false;
     r.lds = lonres_lds_doubles(h.n, h.nf, h.na, h.rw) * sizeof(double);
@@ -64,7 +64,7 @@ static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, c
         TRY(dalloc(c, &r.flagg, (size_t)nwg + 8));
         TRY(dalloc(c, &r.xccg, (size_t)nwg + 8));
         TRY(dalloc(c, &r.xslabg, 2 * (size_t)RES_CLUSTERS * E * 2));
-        TRY(dalloc(c, &r.rhatg, 2 * E * 2));
+        TRY(dalloc(c, &r.rhatg, 2 * E));
         TRY(dalloc(c, &r.clsg, 2 * 64 * 4));
         TRY(dalloc(c, &r.scalg, 2 * (size_t)LR_MAXWG * 2));
         TRY(dalloc(c, &r.ppg, 2 * (size_t)LR_MAXWG));
@@ -108,7 +108,6 @@ static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, c
         HIPCHK(c, hipMemsetAsync(r.flagg, 0, ((size_t)nwg + 8) * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.xccg, 0, ((size_t)nwg + 8) * sizeof(ghk::u64), c->stream));
         HIPCHK(c, hipMemsetAsync(r.xslabg, 0, 2 * (size_t)RES_CLUSTERS * E * 2 * sizeof(ghk::u32x4), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.rhatg, 0, 2 * E * 2 * sizeof(ghk::u32x4), c->stream));
         HIPCHK(c, hipMemsetAsync(r.clsg, 0, 2 * 64 * 4 * sizeof(ghk::u32x4), c->stream));
         HIPCHK(c, hipMemsetAsync(r.scalg, 0, 2 * (size_t)LR_MAXWG * 2 * sizeof(ghk::u32x4), c->stream));
         HIPCHK(c, hipMemsetAsync(r.ppg, 0, 2 * (size_t)LR_MAXWG * sizeof(ghk::u32x4), c->stream));

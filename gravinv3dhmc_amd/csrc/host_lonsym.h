@@ -28,9 +28,9 @@ struct LonSymHost {
     struct Res {
         int state = 0;  // 0 not planned yet, 1 usable, -1 not applicable
         size_t lds = 0;
-        ghk::d2 *slab = nullptr, *mhat = nullptr;
+        ghk::d2 *slab = nullptr, *mhat = nullptr, *rhatg = nullptr;
         ghk::u64 *flagg = nullptr, *xccg = nullptr;
-        ghk::u32x4 *xslabg = nullptr, *rhatg = nullptr, *clsg = nullptr, *scalg = nullptr, *ppg = nullptr;
+        ghk::u32x4 *xslabg = nullptr, *clsg = nullptr, *scalg = nullptr, *ppg = nullptr;
         unsigned *abort_w = nullptr;
         unsigned tag = 0, tagE = 0, ltag = 0;
         bool dirty = false;

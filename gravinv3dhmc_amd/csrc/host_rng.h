@@ -23,6 +23,7 @@ struct gh_rng {
     int has_gauss;
     double gauss;
     std::vector<double> r2;          // squared radii of one call's accepted points
+    int threads = 0;                 // helpers of the scale pass (0: GRAVHMC_RNG_THREADS, default 4)
 };
 
 static void rng_twist(const uint32_t *in, uint32_t *mt)
@@ -137,6 +138,41 @@ int gh_rng_create(gh_rng **out, uint32_t seed)
 
 void gh_rng_destroy(gh_rng *r) { delete r; }
 
+// Host cores this process may really use: the affinity mask capped by the cgroup's CPU quota (a container sees all
+// cores of its host and is granted a few: a thread team of the visible size is throttled to a crawl).
+static int rng_usable_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64] = {0};
+        long long per = 0;
+        if (fscanf(f, "%63s %lld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, atoll(a) / per));
+        fclose(f);
+    } else if (FILE *q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long long quota = -1, per = 0;
+        if (fscanf(q, "%lld", &quota) != 1) quota = -1;
+        fclose(q);
+        if (FILE *pf = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(pf, "%lld", &per) != 1) per = 0;
+            fclose(pf);
+        }
+        if (quota > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, quota / per));
+    }
+    return std::max(1, n);
+}
+
+// threads: helpers of the scale pass (the logarithms: most of a draw's time) for this generator.  0: the default
+// (GRAVHMC_RNG_THREADS, else 4 -- right for several generators drawing side by side); -1: as many as the process may
+// use, less two for the threads that feed the GPU (ONE chain whose draws are what the GPU waits for).
+int gh_rng_set_threads(gh_rng *r, int threads)
+{
+    if (!r) return GH_ERR_ARG;
+    r->threads = threads < 0 ? std::max(1, std::min(16, rng_usable_cores() - 2)) : threads;
+    return GH_OK;
+}
+
 int gh_rng_set_state(gh_rng *r, const uint32_t *key624, int pos, int has_gauss, double cached)
 {
     if (!r || !key624 || pos < 0 || pos > 624) return GH_ERR_ARG;
@@ -223,7 +259,7 @@ int gh_rng_draw_trajectories(gh_rng *r, int K, int Lmin, int Lmax, int64_t M, do
             if (o + 1 < total) p0s[o + 1] = (f * p0s[o + 1]) * sigma;
         }
     };
-    int nt = env_int("GRAVHMC_RNG_THREADS", 4);
+    int nt = r->threads > 0 ? r->threads : env_int("GRAVHMC_RNG_THREADS", 4);
     nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(nt, 64), npairs / 8192));
     if (nt <= 1) {
         scale(0, npairs);

@@ -58,7 +58,7 @@ struct LonResArgs {
     d2 *slab;                     // (nwg + 8) x E forward partials, untagged
     u64 *flagg;                   // nwg + 8
     u32x4 *xslabg;                // 2 x 8 x E x 2 cluster sums
-    u32x4 *rhatg;                 // 2 x E x 2
+    d2 *rhatg;                    // 2 x E, untagged: complete behind the classes' scalars
     u32x4 *clsg;                  // 2 x 64 x 4: per class {sum of d, sum of q, sum of q^2} (q: residual against the previous mean)
     u32x4 *scalg;                 // 2 x LR_MAXWG x 2: per workgroup {regulariser share, p0'p0 share}
     u32x4 *ppg;                   // 2 x LR_MAXWG: per workgroup p'p share at the end of a trajectory
@@ -89,6 +89,83 @@ __device__ __forceinline__ void block_sums(double (&v)[NV], double *redn)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = ((redn[i] + redn[NV + i]) + redn[2 * NV + i]) + redn[3 * NV + i];
+}
+
+// lh_idft_part for NQ coefficient rows H + roff[q] at the SAME longitude k: one twiddle read per frequency serves all rows
+template <int NQ>
+__device__ __forceinline__ void lh_idft_rows(const d2 *H, const int (&roff)[NQ], const d2 *tws, int nf, int k, int n, double (&sum)[NQ])
+{
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sum[q] = 0.0;
+    int idx = 0, ff = 0;
+    for (; ff + 4 <= nf; ff += 4) {
+        d2 w[4], h[NQ][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = tws[idx];
+            idx += k;
+            if (idx >= n) idx -= n;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) h[q][u] = H[roff[q] + ff + u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) sum[q] += h[q][u].x * w[u].x - h[q][u].y * w[u].y;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; ff < nf; ++ff) {
+        const d2 w = tws[idx];
+        idx += k;
+        if (idx >= n) idx -= n;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const d2 h = H[roff[q] + ff];
+            sum[q] += h.x * w.x - h.y * w.y;
+        }
+    }
+}
+
+// lh_dft_part for NR sequences v + r * stride at the SAME frequency f
+template <int NR>
+__device__ __forceinline__ void lh_dft_rows(const double *v, int stride, const d2 *tws, int k0, int k1, int f, int n, d2 (&acc)[NR])
+{
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = d2{0.0, 0.0};
+    int idx = (int)(((long long)f * k0) % n);
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        d2 w[4];
+        double xv[NR][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = tws[idx];
+            idx += f;
+            if (idx >= n) idx -= n;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) xv[r][u] = v[r * stride + k + u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                acc[r].x += xv[r][u] * w[u].x;
+                acc[r].y -= xv[r][u] * w[u].y;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; k < k1; ++k) {
+        const d2 w = tws[idx];
+        idx += f;
+        if (idx >= n) idx -= n;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            acc[r].x += v[r * stride + k] * w.x;
+            acc[r].y -= v[r * stride + k] * w.y;
+        }
+    }
 }
 
 template <int RW>
@@ -145,16 +222,19 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
     }
     for (int e = tid; e < n; e += LR_THREADS) tws[e] = g.tw[e];
     if (tid == 0) *flag_s = 1;
-    constexpr int NI = (RW * 128 + LR_THREADS - 1) / LR_THREADS;  // (row, longitude) items per thread (n <= 126)
+    // items of a thread: longitude kt of the rows ht + q HT (64 <= n <= 126: HT = 2 or 3 thread groups of n) -- a thread's
+    // rows share their twiddle factors in the inverse transform
+    constexpr int NI = (RW + 1) / 2;
+    const int HT = LR_THREADS / n, kt = tid % n, ht = tid / n;
     int64_t ij[NI];
     bool iv[NI];
     double iw[NI], hi[NI], lo[NI], apr[NI], w2[NI], xc[NI], gc[NI], x[NI], p[NI], grad[NI];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
-        const int it = tid + q * LR_THREADS, r = it / n, k = it - r * n;
+        const int r = ht + q * HT;
         const int c = w + r * nwg;
-        iv[q] = r < RW && c < g.nc;
-        ij[q] = (int64_t)(iv[q] ? c : 0) * n + k;
+        iv[q] = ht < HT && r < RW && c < g.nc;
+        ij[q] = (int64_t)(iv[q] ? c : 0) * n + kt;
         iw[q] = 1.0;
         hi[q] = lo[q] = apr[q] = xc[q] = gc[q] = x[q] = p[q] = grad[q] = 0.0;
         w2[q] = 1.0;
@@ -202,7 +282,7 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
     }
     const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.slab, 0, (int)((size_t)(nwg + 8) * E * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_xs = __builtin_amdgcn_make_buffer_rsrc(a.xslabg, 0, 2 * RES_CLUSTERS * E * 32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_rh = __builtin_amdgcn_make_buffer_rsrc(a.rhatg, 0, 2 * E * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rh = __builtin_amdgcn_make_buffer_rsrc(a.rhatg, 0, 2 * E * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_cls = __builtin_amdgcn_make_buffer_rsrc(a.clsg, 0, 2 * 64 * 64, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(a.scalg, 0, 2 * LR_MAXWG * 32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_pp = __builtin_amdgcn_make_buffer_rsrc(a.ppg, 0, 2 * LR_MAXWG * 16, 0x00020000);
@@ -292,20 +372,19 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             }
             greg[q] = iv[q] ? a.alpha * gq : 0.0;
             rval += iv[q] ? val : 0.0;
-            const int it = tid + q * LR_THREADS, r = it / n, kk = it - r * n;
-            if (r < RW) xs[r * n + kk] = iv[q] ? x[q] * iw[q] : 0.0;
+            const int r = ht + q * HT;
+            if (ht < HT && r < RW) xs[r * n + kt] = iv[q] ? x[q] * iw[q] : 0.0;
         }
-        tick(10);
         const double rsh = block_allreduce_sum(rval, red, LR_THREADS / 64);  // (barriers: xs is in place)
-        tick(11);
         // X^_r[f]: quarter ag of the longitudes, then the four quarters; D^ partial of the workgroup
         if (fv) {
             const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
+            d2 xq[RW];
+            lh_dft_rows<RW>(xs, n, tws, k0 < n ? k0 : n, k1, f, n, xq);
 #pragma unroll
-            for (int r = 0; r < RW; ++r) Xp[(r * 4 + ag) * nf + f] = lh_dft_part(xs + r * n, tws, k0 < n ? k0 : n, k1, f, n);
+            for (int r = 0; r < RW; ++r) Xp[(r * 4 + ag) * nf + f] = xq[r];
         }
         __syncthreads();
-        tick(12);
         d2 dacc[LH_AK];
 #pragma unroll
         for (int u = 0; u < LH_AK; ++u) dacc[u] = d2{0.0, 0.0};
@@ -414,6 +493,7 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             }
             __syncthreads();
             if (*flag_s == 0) return;
+            tick(10);
             // the class's predicted data; residuals against the PREVIOUS evaluation's mean (potential.py:700-706:
             // r = d + grav_fix - mean - dobs; the mean of this evaluation needs every class -- the consumers correct for
             // the difference, below), slot sums, the class's sums
@@ -434,6 +514,7 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             }
             double cs[3] = {ds, q1, q2};
             block_sums<3>(cs, redn);  // (barriers: row is in place)
+            tick(11);
             if (fv) {
                 const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
                 Rp[ag * 64 + f] = lh_dft_part(row, tws, k0 < n ? k0 : n, k1, f, n);
@@ -446,35 +527,18 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
                     sres.x += Rp[u * 64 + tid].x;
                     sres.y += Rp[u * 64 + tid].y;
                 }
-                const unsigned off = (unsigned)(((size_t)par * E + own * nf + tid) * 32);
-                rb_store(rs_rh, off, rb_pack(tag, sres.x), false);
-                rb_store(rs_rh, off + 16, rb_pack(tag, sres.y), false);
+                rb_store2(rs_rh, (unsigned)(((size_t)par * E + own * nf + tid) * 16), sres.x, sres.y, false);
             }
+            // (R^[a][:] is untagged: complete once the class's scalars -- written behind the storing wave's drain and a
+            // barrier -- carry the tag)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             if (tid < 3) rb_store(rs_cls, (unsigned)(((par * 64 + own) * 4 + tid) * 16), rb_pack(tag, cs[tid]), false);
         }
         tick(5);
         // ---- hop 3: R^ and the scalars, everybody
         {
             bool okall = true;
-            for (int e0 = 0; e0 < E; e0 += 8 * LR_THREADS) {
-                unsigned off[16];
-                double v[16];
-                int cnt = 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * LR_THREADS + tid;
-                    const int ee = e < E ? e : 0;
-                    off[2 * u] = (unsigned)(((size_t)par * E + ee) * 32);
-                    off[2 * u + 1] = off[2 * u] + 16;
-                    if (e < E) cnt = 2 * (u + 1);
-                }
-                okall = rb_poll<16>(a.abort_w, rs_rh, tag, cnt, off, v) && okall;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * LR_THREADS + tid;
-                    if (e < E) Rh[e] = d2{v[2 * u], v[2 * u + 1]};
-                }
-            }
             double v5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
             {
                 unsigned off[3];
@@ -502,6 +566,23 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             // (sums over the workgroups / classes in a fixed tree: the same bits in every workgroup; the barriers inside
             // also publish R^ and the flag)
             block_sums<5>(v5, redn);
+            if (*flag_s != 0) {
+                // every class's scalars carry the tag: R^ is complete (59.5 KB at C4, write-through stores, L2-served loads)
+                for (int e0 = 0; e0 < E; e0 += 8 * LR_THREADS) {
+                    d2 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u * LR_THREADS + tid;
+                        v[u] = rb_load2(rs_rh, (unsigned)(((size_t)par * E + (e < E ? e : 0)) * 16));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u * LR_THREADS + tid;
+                        if (e < E) Rh[e] = v[u];
+                    }
+                }
+            }
+            __syncthreads();
             sc5[0] = v5[0];
             sc5[1] = v5[1];
             sc5[2] = v5[2];
@@ -550,13 +631,18 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
         }
         __syncthreads();
         tick(14);
+        {
+            int roff[NI];
+            double sv[NI];
 #pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const int it = tid + q * LR_THREADS, r = it / n, kk = it - r * n;
-            if (iv[q]) {
-                const double sv = lh_idft_part(Gh + r * nf, tws, 0, nf, kk, n);
-                grad[q] = 2.0 * ((sv / (double)n) * iw[q]) + greg[q];
+            for (int q = 0; q < NI; ++q) {
+                const int r = ht + q * HT;
+                roff[q] = (r < RW ? r : 0) * nf;
             }
+            lh_idft_rows<NI>(Gh, roff, tws, nf, kt, n, sv);
+#pragma unroll
+            for (int q = 0; q < NI; ++q)
+                if (iv[q]) grad[q] = 2.0 * ((sv[q] / (double)n) * iw[q]) + greg[q];
         }
         tick(7);
         // ================= what the evaluation was for

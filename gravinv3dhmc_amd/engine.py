@@ -48,6 +48,7 @@ class Engine(object):
 
     # -- lifetime -----------------------------------------------------------------
     def close(self):
+        self.__dict__.pop("_p0_pool", None)     # (the blocks go with the context)
         if getattr(self, "_h", None):
             self._lib.gh_destroy(self._h)
             self._h = None
@@ -109,6 +110,7 @@ class Engine(object):
         spacing): keep K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] instead of G (gh_set_shift_invariant);
         build_G raises NotImplementedError with the reason if the geometry lacks the structure."""
         self._chk(self._lib.gh_set_shift_invariant(self._h, 1 if on else 0))
+        self._shift_invariant = bool(on)
 
     def shift_invariant_info(self):
         n, na, nc, tb = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
@@ -304,6 +306,10 @@ class Engine(object):
         ~0.5 ms of idle GPU per call at C2; momentum upload; for small problems the launch of the
         resident chain kernel), few enough that the host draw of the next batch still overlaps the
         GPU (C2: 4, C1: 128)."""
+        if getattr(self, "_shift_invariant", False):
+            # (the shift-invariant store's passes take tens of microseconds: a call's fixed costs -- two extra evaluations
+            # of the persistent launch, the staging of the momenta -- want more trajectories to spread over)
+            return int(max(4, min(128, (24 << 20) // (8 * max(1, self.M)))))
         return int(max(4, min(128, (6 << 20) // (8 * max(1, self.M)))))
 
     def _vec_any(self, v):
@@ -336,13 +342,33 @@ class Engine(object):
         import threading
         if batch is None:
             batch = self.default_batch()
+        # The momenta of a batch are drawn / gathered into page-locked blocks of the library (three of them in
+        # rotation: the batch that runs, the one being drawn, one spare): the library sends them to the GPU from there
+        # -- a copy from ordinary memory goes through a staging buffer first, 23 MB per call at 72 000 cells.
+        # (kept with the engine between calls: page-locking tens of MB costs milliseconds)
+        pool = self.__dict__.setdefault("_p0_pool", {"i": 0, "blocks": []})
+
+        def p0_block(n, width):
+            if n * width * 8 * 3 > (2 << 30) or n < 2:
+                return np.empty((n, width))
+            if not pool["blocks"] or pool["blocks"][0].shape[1] != width or pool["blocks"][0].shape[0] < n:
+                for b in pool["blocks"]:
+                    self.pinned_free(b)
+                pool["blocks"] = [self.pinned_empty((max(n, batch), width)) for _ in range(3)]
+            pool["i"] = (pool["i"] + 1) % 3
+            return pool["blocks"][pool["i"]][:n]
+
         if hasattr(draws, "take_block"):
             # a source that fills blocks itself (inversion.rng.LegacyDraws): rows after the lookahead
             # are drawn straight into the batch's arrays
             def take(n, head=None):
                 if head is None:
-                    return draws.take_block(n)
-                out = (np.empty(n, dtype=np.int32), np.empty((n, head[1].shape[1])), np.empty(n))
+                    if n < 2:
+                        return draws.take_block(n)
+                    out = (np.empty(n, dtype=np.int32), p0_block(n, draws.M), np.empty(n))
+                    got = len(draws.take_block(n, out=out, at=0)[0])
+                    return tuple(o[:got] for o in out)
+                out = (np.empty(n, dtype=np.int32), p0_block(n, head[1].shape[1]), np.empty(n))
                 out[0][0], out[1][0], out[2][0] = head[0][0], head[1][0], head[2][0]
                 got = len(draws.take_block(n - 1, out=out, at=1)[0]) if n > 1 else 0
                 return tuple(o[:1 + got] for o in out)
@@ -364,7 +390,10 @@ class Engine(object):
                 us += [float(d[2]) for d in rows]
                 if not Ls:
                     return (np.empty(0, dtype=np.int32), np.empty((0, 0)), np.empty(0))
-                return (np.asarray(Ls, dtype=np.int32), np.stack(ps), np.asarray(us, dtype=np.float64))
+                blk = p0_block(len(ps), ps[0].shape[0])
+                for i, pv in enumerate(ps):
+                    blk[i] = pv
+                return (np.asarray(Ls, dtype=np.int32), blk, np.asarray(us, dtype=np.float64))
 
         # one worker thread for the whole chain takes the library calls (a thread per call costs
         # ~0.1 ms of idle device between two batches of a small problem)

@@ -40,6 +40,10 @@ class LegacyDraws(object):
             raise RuntimeError("gh_rng_create failed")
         if not self._own:
             self.adopt()
+            # (ONE chain on the global stream: its draws are what the GPU waits for -- at 72 000 cells a trajectory's
+            # normals cost 340 us with four helpers against 250 us of GPU time -- so the logarithms get every core
+            # the process may use; the seeded generators of a batch of chains draw side by side and keep the default)
+            self._lib.gh_rng_set_threads(self._h, -1)
         self._row = None
 
     # -- exchange with np.random --------------------------------------------------------

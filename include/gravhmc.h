@@ -434,6 +434,8 @@ int gh_rng_create(gh_rng **out, uint32_t seed);
 void gh_rng_destroy(gh_rng *rng);
 int gh_rng_set_state(gh_rng *rng, const uint32_t *key624, int pos, int has_gauss, double cached);
 int gh_rng_get_state(const gh_rng *rng, uint32_t *key624, int *pos, int *has_gauss, double *cached);
+/* helpers of a draw's scale pass: 0 = default (GRAVHMC_RNG_THREADS, else 4), -1 = all the process may use less two */
+int gh_rng_set_threads(gh_rng *rng, int threads);
 int gh_rng_draw_trajectories(gh_rng *rng, int K, int Lmin, int Lmax, int64_t M, double sigma, int *L,
                              double *p0s /* K x M */, double *us /* K */);
 

@@ -36,7 +36,7 @@ trajs = [(L, rng.normal(size=M) * 0.001, float(rng.uniform())) for _ in range(st
 e.run_chain(iter(trajs[:20]), 0.005, lambda *a: None, batch=batch)
 e.synchronize()
 NAMES = ["prologue", "forward", "publish", "flags", "hop1", "hop2 (class owner)", "hop3", "adjoint + gradient", "update / decision",
-         "next trajectory", "(forward: regulariser + xs)", "(forward: block sum)", "(forward: transform)", "(adjoint: products)",
+         "next trajectory", "(hop2: cluster sums arrive)", "(hop2: inverse transform, sums)", "-", "(adjoint: products)",
          "(adjoint: quarter sums)", "-"]
 out0 = (C.c_longlong * 16)()
 e._lib.gh_debug_lonres_timing(e._h, out0)
