@@ -912,6 +912,30 @@ def main():
                             "the last one's end)" + ("; %d chains on their own streams: the passes overlap, their "
                                                      "durations are summed" % CPG if CPG > 1 else ""),
                     "dense_G_equiv_GBps": N * M * 8 / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None}
+                rst = eng.shift_invariant_resident_stats()
+                if CPG == 1 and rst["launches"] > 0:
+                    # ONE persistent launch per batch of trajectories (csrc/lonres.hip.h): the table never leaves the
+                    # workgroups' registers; what moves per evaluation is the exchange -- every workgroup's D^ partial
+                    # out, the clusters' sums, R^ back to every workgroup -- through the memory system ("all bytes
+                    # leave L2"), in four dependent hops
+                    E16 = 16.0 * si["n_classes"] * hm["n_freq"]
+                    xbytes = rst["workgroups"] * E16 * 2 + 8 * 2 * E16 * 2
+                    ach = xbytes * prof["sweeps"] / secs / 1e9 if secs > 0 else None
+                    line["roofline"].update({
+                        "achieved": ach, "frac": ach / 8000.0 if ach else None,
+                        "kernel": "lonsymh_resident_kernel (ONE persistent launch per batch of trajectories: %d workgroups "
+                                  "keep their cell rows' part of the complex table T^ (%.1f MB) in REGISTERS; per evaluation "
+                                  "forward partials -> cluster sums -> class owners (inverse transform, residuals, forward "
+                                  "transform) -> R^ to every workgroup -> adjoint, gradient, leapfrog update; Metropolis "
+                                  "test inside)" % (rst["workgroups"], byts / 1e6),
+                        "algorithmic_bytes_per_launch": xbytes,
+                        "byte_model": "exchange of one evaluation: %d workgroups x %d complex entries (16 B) out and R^ back, "
+                                      "8 cluster sums of tagged granules (32 B per entry); the table itself is not read again"
+                                      % (rst["workgroups"], si["n_classes"] * hm["n_freq"]),
+                        "note": "launches = evaluations inside the persistent launches (forward + adjoint product each), avg_ms "
+                                "= kernel time per evaluation; the floor is the latency of the dependent exchange hops "
+                                "(DESIGN 4.9), not bandwidth",
+                        "persistent": rst})
             else:
                 flops = 4.0 * N * M * prof["sweeps"]
                 line["roofline"] = {

@@ -59,8 +59,10 @@ if [ $which = all ] || [ $which = c1b ]; then
   fi
 fi
 if [ $which = all ] || [ $which = c4s ]; then
-  # C4 on the shift-invariant store, harmonic domain: one chain, and 8 chains on the shared tables
+  # C4 on the shift-invariant store, harmonic domain, one launch per phase (GRAVHMC_LONSYM_RESIDENT=0: what runs with
+  # a stencil regulariser or when the persistent launch gives up): one chain, and 8 chains on the shared tables
   A="--workload c4_global_tesseroid --shift-invariant --no-cpu-baseline --no-extra"
+  export GRAVHMC_LONSYM_RESIDENT=0
   if prof c4s_trace --kernel-trace --stats -- $A --steps 2000 --warmup 200 \
      && prof c4s_sq --pmc $SQ1 --kernel-trace -- $A --steps 200 --warmup 0 \
      && prof c4s_fetch --pmc FETCH_SIZE --kernel-trace -- $A --steps 200 --warmup 0; then
@@ -68,9 +70,23 @@ if [ $which = all ] || [ $which = c4s ]; then
     python3 $REPO/profiles/summarize.py pmc $SUM/c4_shift_invariant_harmonic_pmc_summary.json "rocprofv3 --pmc passes (SQ counters; FETCH_SIZE in its own pass; with --kernel-trace only) of python3 bench.py $A --steps 200 --warmup 0 $NOTE" $OUT/c4s_sq $OUT/c4s_fetch
     cp $OUT/c4s_trace.json $SUM/bench_c4_shift_invariant_harmonic_under_rocprof_trace.json
   fi
+  unset GRAVHMC_LONSYM_RESIDENT
   if prof c4s8_trace --kernel-trace --stats -- $A --chains-per-gpu 8 --steps 2000 --warmup 200; then
     python3 $REPO/profiles/summarize.py stats $OUT/c4s8_trace $SUM/c4_shift_invariant_8chains_kernel_stats.csv
     cp $OUT/c4s8_trace.json $SUM/bench_c4_shift_invariant_8chains_under_rocprof_trace.json
+  fi
+fi
+if [ $which = all ] || [ $which = c4p ]; then
+  # C4, one chain (BASELINE configs[3]: one chain per GPU): the harmonic pass as ONE persistent launch per batch of
+  # trajectories (lonsymh_resident_kernel, csrc/lonres.hip.h)
+  A="--workload c4_global_tesseroid --shift-invariant --no-cpu-baseline --no-extra"
+  if prof c4p_trace --kernel-trace --stats -- $A --steps 8000 --warmup 800 \
+     && prof c4p_sq --pmc $SQ1 --kernel-trace -- $A --steps 2000 --warmup 0 \
+     && prof c4p_fetch --pmc FETCH_SIZE --kernel-trace -- $A --steps 2000 --warmup 0 \
+     && prof c4p_write --pmc WRITE_SIZE --kernel-trace -- $A --steps 2000 --warmup 0; then
+    python3 $REPO/profiles/summarize.py stats $OUT/c4p_trace $SUM/c4_shift_invariant_persistent_kernel_stats.csv
+    python3 $REPO/profiles/summarize.py pmc $SUM/c4_shift_invariant_persistent_pmc_summary.json "rocprofv3 --pmc passes (SQ counters; FETCH_SIZE, WRITE_SIZE in passes of their own; with --kernel-trace only) of python3 bench.py $A --steps 2000 --warmup 0 $NOTE" $OUT/c4p_sq $OUT/c4p_fetch $OUT/c4p_write
+    cp $OUT/c4p_trace.json $SUM/bench_c4_shift_invariant_persistent_under_rocprof_trace.json
   fi
 fi
 if [ $which = all ] || [ $which = c5r ]; then

@@ -495,3 +495,45 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
             assert worst < 1e-10
             t2.close()
     t.close()
+
+
+def test_shift_invariant_persistent_pass_gives_up_cleanly(G, orc, monkeypatch):
+    """A launch of lonsymh_resident_kernel whose workgroups wait for partners that never come (test hook: eight
+    phantom workgroups) times out within its bound (2 s), leaves the chain untouched, and the same call runs on the
+    launches per phase: every trajectory still matches oracle.Problem.leapfrog; the next call uses the persistent
+    launch again."""
+    rng = np.random.default_rng(23)
+    mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
+    N, M = lon.size, mesh.size
+    bounds = mesh.cell_bounds()
+    t = G.Engine(N, M)
+    t.set_shift_invariant(True)
+    t.set_obs(lon, lat, h)
+    t.set_cells(bounds, 1, 1.6)
+    t.build_G()
+    wm = t.weight(0.5)
+    K = orc.tess_gz_kernel(lon, lat, h, bounds)
+    Aw, _ = orc.col_weight(K)
+    d_true = K @ rng.uniform(0.0, 0.4, M)
+    dobs = d_true + 0.02 * np.abs(d_true).max() * rng.normal(size=N)
+    low, high = 0.0 * wm, 0.8 * wm
+    t.set_data(dobs)
+    t.set_reg("Damping", 0.05, 0.01, mesh.shape, 0.001 * wm)
+    t.chain_init(0.2 * wm, low, high)
+    P = orc.Problem(Aw, dobs, 0.001 * wm, "Damping", 0.05, 0.01, wm=wm, shape=mesh.shape)
+    xo = t.chain_get_x()
+    for call in range(3):
+        if call == 1:
+            monkeypatch.setenv("GRAVHMC_LONRES_TEST_ABORT", "1")
+        Ls = [int(v) for v in rng.integers(1, 6, 4)]
+        p0s = [rng.normal(size=M) * 0.001 for _ in range(4)]
+        us = [float(v) for v in rng.uniform(size=4)]
+        got = _run_chain_lists(t, Ls, p0s, us, 0.005)
+        monkeypatch.delenv("GRAVHMC_LONRES_TEST_ABORT", raising=False)
+        for k in range(4):
+            xo, ao, oo, _ = P.leapfrog(xo, p0s[k], 0.005, Ls[k], low, high, us[k])
+            assert got[k][0] == ao and relmax(got[k][1], oo) < 1e-10, (call, k)
+        assert relmax(t.chain_get_x(), xo) < 1e-10
+        st = t.shift_invariant_resident_stats()
+        assert st["timeouts"] == (0 if call == 0 else 1) and st["launches"] == (1 if call < 2 else 2), (call, st)
+    t.close()
