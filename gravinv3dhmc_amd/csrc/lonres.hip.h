@@ -355,27 +355,12 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
         const unsigned tag = a.tag0 + ev;
         const int par = (int)(ev & 1u);
         // ================= evaluation at x: forward product of the rows, the exchange, adjoint product -> grad
-        // regulariser (potential.py:719-736): value share, alpha dR/dx per cell
-        double greg[NI], rval = 0.0;
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
-            const double v = x[q] - apr[q];
-            double gq = 0.0, val = 0.0;
-            if (a.kind == 0) {
-                val = v * v;
-                gq = 2.0 * v;
-            } else {
-                const double v2 = v * v, den = v2 + a.beta;
-                val = (w2[q] * v2) / den;
-                const double deng = a.ms_grad_den_mw ? x[q] * x[q] + a.beta : den;
-                gq = (2.0 * a.beta * w2[q] * v) / (deng * deng);
-            }
-            greg[q] = iv[q] ? a.alpha * gq : 0.0;
-            rval += iv[q] ? val : 0.0;
             const int r = ht + q * HT;
             if (ht < HT && r < RW) xs[r * n + kt] = iv[q] ? x[q] * iw[q] : 0.0;
         }
-        const double rsh = block_allreduce_sum(rval, red, LR_THREADS / 64);  // (barriers: xs is in place)
+        __syncthreads();
         // X^_r[f]: quarter ag of the longitudes, then the four quarters; D^ partial of the workgroup
         if (fv) {
             const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
@@ -413,11 +398,6 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
                 if (aa < na) rb_store2(rs_slab, (unsigned)(((size_t)w * E + aa * nf + f) * 16), dacc[u].x, dacc[u].y, local);
             }
         }
-        if (tid == 0) {
-            rb_store(rs_sc, (unsigned)(((par * LR_MAXWG + w) * 2 + 0) * 16), rb_pack(tag, rsh), false);
-            rb_store(rs_sc, (unsigned)(((par * LR_MAXWG + w) * 2 + 1) * 16), rb_pack(tag, pp0_share), false);
-        }
-        pp0_share = 0.0;  // (p0'p0 of a trajectory rides on its first evaluation only)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -425,6 +405,33 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
                 __hip_atomic_store(a.flagg + w, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else
                 __hip_atomic_store(a.flagg + w, (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (behind the flag, while the partials travel) the regulariser (potential.py:719-736): alpha dR/dx per cell, this
+        // workgroup's share of its value; with the trajectory's p0'p0 share as granules -- read in hop 3
+        double greg[NI], rval = 0.0;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const double v = x[q] - apr[q];
+            double gq = 0.0, val = 0.0;
+            if (a.kind == 0) {
+                val = v * v;
+                gq = 2.0 * v;
+            } else {
+                const double v2 = v * v, den = v2 + a.beta;
+                val = (w2[q] * v2) / den;
+                const double deng = a.ms_grad_den_mw ? x[q] * x[q] + a.beta : den;
+                gq = (2.0 * a.beta * w2[q] * v) / (deng * deng);
+            }
+            greg[q] = iv[q] ? a.alpha * gq : 0.0;
+            rval += iv[q] ? val : 0.0;
+        }
+        {
+            const double rsh = block_allreduce_sum(rval, red, LR_THREADS / 64);
+            if (tid == 0) {
+                rb_store(rs_sc, (unsigned)(((par * LR_MAXWG + w) * 2 + 0) * 16), rb_pack(tag, rsh), false);
+                rb_store(rs_sc, (unsigned)(((par * LR_MAXWG + w) * 2 + 1) * 16), rb_pack(tag, pp0_share), false);
+            }
+            pp0_share = 0.0;  // (p0'p0 of a trajectory rides on its first evaluation only)
         }
         tick(2);
         // ---- hop 1: this workgroup's chunk of the entries, summed over the cluster's members in order
@@ -498,8 +505,14 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             // r = d + grav_fix - mean - dobs; the mean of this evaluation needs every class -- the consumers correct for
             // the difference, below), slot sums, the class's sums
             double ds = 0.0, q1 = 0.0, q2 = 0.0;
+            {
+                // (two halves of the frequencies on 2 n threads)
+                const int hh = tid / n, kk = tid - hh * n, fm = (nf + 1) / 2;
+                if (hh < 2) row[hh * 128 + kk] = lh_idft_part(Dh, tws, hh * fm, hh ? nf : fm, kk, n);
+            }
+            __syncthreads();
             if (tid < n) {
-                const double dk = lh_idft_part(Dh, tws, 0, nf, tid, n) / (double)n;
+                const double dk = (row[tid] + row[128 + tid]) / (double)n;
                 double rs_ = 0.0;
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
