@@ -721,11 +721,11 @@ def main():
         # ---- several chains per GPU: one RandomState per chain (seed 100 + global chain index,
         # the stream np.random.seed gives the reference's rank), lock-step rounds of L steps
         from concurrent.futures import ThreadPoolExecutor
-        from gravinv3dhmc_amd.inversion.rng import LegacyDraws
+        from gravinv3dhmc_amd.inversion.rng import LegacyDraws, draw_workers
         pool = ThreadPoolExecutor(max_workers=2)
-        # (the chains' draws on a few threads: sixteen of them, each with the generator's own helpers, crowd the
-        # thread that launches the GPU work off the box's 16 cores)
-        draw_pool = ThreadPoolExecutor(max_workers=min(4, CPG))
+        # (a draw is mostly sequential: one generator per core, no helpers -- rng.draw_workers)
+        n_draw = draw_workers(CPG)
+        draw_pool = ThreadPoolExecutor(max_workers=n_draw)
         x0s = np.stack([0.001 * wm for _ in range(CPG)])
         eng.batch_init(x0s, low, high)
         # (trajectories offered per chain and call: the sampler's rule, inversion/hmc.py HMCSampleBatch)
@@ -742,7 +742,8 @@ def main():
             def __init__(self, total_steps, seed0):
                 self.plan = [L] * (total_steps // L) + ([total_steps % L] if total_steps % L else [])
                 # (each chain draws into a ring of page-locked rows: the library sends them to the GPU from there)
-                self.draws = [LegacyDraws(M, (L, L), Sigma, fixed_L=self.plan, seed=seed0 + k).use_ring(eng, 2 * Tmax)
+                self.draws = [LegacyDraws(M, (L, L), Sigma, fixed_L=self.plan, seed=seed0 + k,
+                                          helpers=1 if n_draw >= 8 else None).use_ring(eng, 2 * Tmax)
                               for k in range(CPG)]
                 self.queue = [[] for _ in range(CPG)]      # per chain: (n, p0, u) drawn, not started yet
                 self.top_up()                              # a sampler in steady state has its next offer drawn

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "gh_rng_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
     "gh_rng_destroy": (None, [C.c_void_p]),
     "gh_rng_set_threads": (C.c_int, [C.c_void_p, C.c_int]),
+    "gh_host_cores": (C.c_int, []),
     "gh_rng_set_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_double]),
     "gh_rng_get_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_double)]),

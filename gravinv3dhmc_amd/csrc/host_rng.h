@@ -166,6 +166,8 @@ static int rng_usable_cores()
 // threads: helpers of the scale pass (the logarithms: most of a draw's time) for this generator.  0: the default
 // (GRAVHMC_RNG_THREADS, else 4 -- right for several generators drawing side by side); -1: as many as the process may
 // use, less two for the threads that feed the GPU (ONE chain whose draws are what the GPU waits for).
+int gh_host_cores(void) { return rng_usable_cores(); }
+
 int gh_rng_set_threads(gh_rng *r, int threads)
 {
     if (!r) return GH_ERR_ARG;

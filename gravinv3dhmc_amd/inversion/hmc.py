@@ -325,7 +325,7 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     # one legacy stream per chain, bit for bit np.random.RandomState(seed + rank), drawn by the library (a
     # trajectory's 6000 normals cost NumPy 57 us on a GPU box's core -- with 16 chains in lock-step the GPU
     # needs 23 us for a step of ALL chains; the native draws take half of NumPy's time and run one thread per chain)
-    from .rng import LegacyDraws
+    from .rng import LegacyDraws, draw_workers
     # Trajectories offered per chain and library call.  The chains run desynchronised
     # (gh_batch_run, carry-over mode): a call ends when the first chain has used up its offer, the
     # others keep their trajectory in flight; what a chain has not started is offered again next
@@ -334,7 +334,8 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     # are 2 ms of kernel against ~1.5 ms of staging, copies and Python per call)
     T = int(max(2, min(32, (256 << 20) // (8 * M * n_chains))))
     # (each chain draws into a ring of 2 T page-locked rows: the library sends them to the GPU from where they lie)
-    rs = [LegacyDraws(M, Lrange, Sigma, seed=seed + r).use_ring(eng, 2 * T) for r in ranks]
+    n_draw = draw_workers(n_chains)
+    rs = [LegacyDraws(M, Lrange, Sigma, seed=seed + r, helpers=1 if n_draw >= 8 else None).use_ring(eng, 2 * T) for r in ranks]
     folders = [save_folder + str(r) for r in ranks]
     for f in folders:
         os.makedirs(f, exist_ok=True)
@@ -351,9 +352,8 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
     target = ndraws + nsamples
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=2)
-    # (the chains' draws on a few threads: one per chain plus the generator's own helpers crowd the thread that
-    # launches the GPU work off a 16-core share)
-    draw_pool = ThreadPoolExecutor(max_workers=min(4, n_chains))
+    # (a draw is mostly sequential: one generator per core, rng.draw_workers)
+    draw_pool = ThreadPoolExecutor(max_workers=n_draw)
 
     import collections
     import queue

@@ -17,11 +17,19 @@ import numpy as np
 from .. import _lib
 
 
+def draw_workers(n_chains):
+    """Threads for the draws of n_chains generators side by side: a draw is mostly SEQUENTIAL (the twists of MT19937
+    and the polar method's rejections: ~13 ns per normal on one core, 9 with helpers for its logarithms), so the
+    chains' draws go on as many cores as the process may use less three (the thread that feeds the GPU, the one that
+    reports, the interpreter) -- one generator per core, no helpers."""
+    return int(max(1, min(int(n_chains), _lib.load().gh_host_cores() - 3)))
+
+
 class LegacyDraws(object):
     """Iterator of (L, p0, u) in the reference's stream order, with a block interface for
     Engine.run_chain (``take_block``)."""
 
-    def __init__(self, M, Lrange, Sigma, fixed_L=None, limit=None, seed=None):
+    def __init__(self, M, Lrange, Sigma, fixed_L=None, limit=None, seed=None, helpers=None):
         """seed=None: adopt (and on release() hand back) the state of NumPy's GLOBAL legacy generator, as
         HamitonianMC.sample uses it.  seed=int: an independent stream, bit for bit the one
         ``np.random.RandomState(seed)`` produces (a chain of HMCSampleBatch: the reference's rank seeds its
@@ -44,6 +52,8 @@ class LegacyDraws(object):
             # normals cost 340 us with four helpers against 250 us of GPU time -- so the logarithms get every core
             # the process may use; the seeded generators of a batch of chains draw side by side and keep the default)
             self._lib.gh_rng_set_threads(self._h, -1)
+        if helpers is not None:
+            self._lib.gh_rng_set_threads(self._h, int(helpers))
         self._row = None
 
     # -- exchange with np.random --------------------------------------------------------

@@ -436,6 +436,8 @@ int gh_rng_set_state(gh_rng *rng, const uint32_t *key624, int pos, int has_gauss
 int gh_rng_get_state(const gh_rng *rng, uint32_t *key624, int *pos, int *has_gauss, double *cached);
 /* helpers of a draw's scale pass: 0 = default (GRAVHMC_RNG_THREADS, else 4), -1 = all the process may use less two */
 int gh_rng_set_threads(gh_rng *rng, int threads);
+/* host cores this process may use: the affinity mask capped by the cgroup's CPU quota */
+int gh_host_cores(void);
 int gh_rng_draw_trajectories(gh_rng *rng, int K, int Lmin, int Lmax, int64_t M, double sigma, int *L,
                              double *p0s /* K x M */, double *us /* K */);
 
