@@ -295,8 +295,8 @@ def run_single_chain(eng, M, Sigma, dt, L, steps, warmup, seed, barrier=lambda: 
 #: (same script, its own workload) and summarised under `extra`, so one driver record carries them
 EXTRA_RUNS = [
     ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
-    ("c1_uniform_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--steps", "8000",
-                              "--warmup", "800"]),
+    ("c1_uniform_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--steps", "16000",
+                              "--warmup", "1600"]),
     ("c1_hmcsample_batch_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--hmcsample-batch", "600"]),
     ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                               "--warmup", "20"]),
@@ -308,8 +308,8 @@ EXTRA_RUNS = [
     ("c4_global_tesseroid_matrix_free", ["--workload", "c4_global_tesseroid", "--matrix-free", "--steps", "100",
                                          "--warmup", "10"]),
     ("c4_global_tesseroid_dense", ["--workload", "c4_global_tesseroid", "--steps", "2000", "--warmup", "200"]),
-    ("c4_global_tesseroid_shift_invariant", ["--workload", "c4_global_tesseroid", "--shift-invariant", "--steps", "4000",
-                                             "--warmup", "400"]),
+    ("c4_global_tesseroid_shift_invariant", ["--workload", "c4_global_tesseroid", "--shift-invariant", "--steps", "16000",
+                                             "--warmup", "1600"]),
     ("c4_global_tesseroid_shift_invariant_8_chains", ["--workload", "c4_global_tesseroid", "--shift-invariant",
                                                       "--chains-per-gpu", "8", "--steps", "2000", "--warmup", "200"]),
     ("c4_global_tesseroid_matrix_free_8_chains", ["--workload", "c4_global_tesseroid", "--matrix-free",
