@@ -50,8 +50,11 @@ static bool lonres_usable(gh_ctx *c)
 
 // K trajectories of the context's chain in one launch (same contract as gh_chain_run / chain_run_resident).
 // GH_RESIDENT_ABORTED: the kernel gave up waiting for its workgroups, nothing was changed.
-static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, const double *us, double dt, int64_t stop_at_accepts,
-                            int64_t record_from, int *accepted, double *out5s, double *x_out, int *n_run)
+// st: the context whose chain runs (c itself, or one of the light contexts of a batch of chains: the launch, its
+// tables and exchange buffers are c's).  p0rows (or nullptr): the K momentum rows where they lie, instead of p0s.
+static int chain_run_lonres(gh_ctx *c, gh_ctx *st, int K, const int *L, const double *p0s, const double *const *p0rows, const double *us,
+                            double dt, int64_t stop_at_accepts, int64_t record_from, int *accepted, double *out5s, double *x_out,
+                            int *n_run)
 {
     LonSymHost &h = *c->ls;
     LonSymHost::Res &r = h.res;
@@ -88,7 +91,7 @@ static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, c
         HIPCHK(c, hipEventCreate(&r.ev0));
         HIPCHK(c, hipEventCreate(&r.ev1));
     }
-    const bool want_x = x_out != nullptr || c->ring != nullptr;
+    const bool want_x = x_out != nullptr || st->ring != nullptr;
     if (K > r.Kcap) {
         const int cap = std::max(K, 32);
         r.L = r.accepted = nullptr;
@@ -123,21 +126,40 @@ static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, c
         HIPCHK(c, hipHostMalloc((void **)&r.h_stage, r.h_stage_n * sizeof(double)));
     }
     {
-        bool pinned = false;
-        const char *lo = (const char *)p0s, *hi = lo + (size_t)K * M * sizeof(double);
-        for (const gh_ctx::Pinned &pm : c->pinned)
-            if (lo >= pm.base && hi <= pm.base + pm.bytes) pinned = true;
-        const double *from = p0s;
-        if (!pinned) {
-            const int nthr = (size_t)K * M * sizeof(double) >= ((size_t)1 << 20) ? std::min(4, K) : 1;
-            auto part = [&](int k0, int k1) { memcpy(r.h_stage + (size_t)k0 * M, p0s + (size_t)k0 * M, (size_t)(k1 - k0) * M * sizeof(double)); };
+        // rows inside a block of gh_pinned_alloc go straight from where they lie, adjacent ones in one copy; the others
+        // are gathered into the pinned staging buffer first (host_resbatch.h)
+        std::vector<const double *> src((size_t)K);
+        std::vector<char> direct((size_t)K, 0);
+        int n_staged = 0;
+        for (int k = 0; k < K; ++k) {
+            src[(size_t)k] = p0rows ? p0rows[(size_t)k] : p0s + (size_t)k * M;
+            const char *lo = (const char *)src[(size_t)k], *hi = lo + M * sizeof(double);
+            for (const gh_ctx::Pinned &pm : c->pinned)
+                if (lo >= pm.base && hi <= pm.base + pm.bytes) {
+                    direct[(size_t)k] = 1;
+                    break;
+                }
+            n_staged += direct[(size_t)k] ? 0 : 1;
+        }
+        if (n_staged > 0) {
+            auto part = [&](int k0, int k1) {
+                for (int k = k0; k < k1; ++k)
+                    if (!direct[(size_t)k]) memcpy(r.h_stage + (size_t)k * M, src[(size_t)k], M * sizeof(double));
+            };
+            const int nthr = (size_t)n_staged * M * sizeof(double) >= ((size_t)1 << 20) ? std::min(4, K) : 1;
             std::vector<std::thread> pool;
             for (int i = 1; i < nthr; ++i) pool.emplace_back(part, (int)((int64_t)K * i / nthr), (int)((int64_t)K * (i + 1) / nthr));
             part(0, K / nthr);
             for (std::thread &th : pool) th.join();
-            from = r.h_stage;
         }
-        HIPCHK(c, hipMemcpyAsync(r.p0s, from, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        for (int k0 = 0; k0 < K;) {
+            int k1 = k0 + 1;
+            const double *from = direct[(size_t)k0] ? src[(size_t)k0] : r.h_stage + (size_t)k0 * M;
+            while (k1 < K && direct[(size_t)k1] == direct[(size_t)k0] && (direct[(size_t)k0] ? src[(size_t)k1] == src[(size_t)k1 - 1] + M : true))
+                ++k1;
+            HIPCHK(c, hipMemcpyAsync(r.p0s + (size_t)k0 * M, from, (size_t)(k1 - k0) * M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            k0 = k1;
+        }
         HIPCHK(c, hipMemcpyAsync(r.us, us, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(r.L, L, (size_t)K * sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
@@ -149,27 +171,27 @@ static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, c
     a.nwg = nwg;
     if (env_int("GRAVHMC_LONRES_TEST_ABORT", 0)) a.nwg += 8;  // test hook: partners that do not exist
     a.try_local = env_int("GRAVHMC_RESIDENT_LOCAL", 1);
-    a.wm = c->weighted ? c->wm : nullptr;
-    a.low = c->low;
-    a.high = c->high;
-    a.mwapr = c->mwapr;
-    a.wm2 = c->wm2;
-    a.kind = c->reg_kind;
+    a.wm = st->weighted ? st->wm : nullptr;
+    a.low = st->low;
+    a.high = st->high;
+    a.mwapr = st->mwapr;
+    a.wm2 = st->wm2;
+    a.kind = st->reg_kind;
     a.ms_grad_den_mw = 0;
-    a.alpha = c->alpha;
-    a.beta = c->beta;
-    a.dobs_c = c->dobs_c;
-    a.gfix = c->have_fix ? c->gfix : nullptr;
-    a.gfix_sum = c->have_fix ? c->gfix_sum : 0.0;
+    a.alpha = st->alpha;
+    a.beta = st->beta;
+    a.dobs_c = st->dobs_c;
+    a.gfix = st->have_fix ? st->gfix : nullptr;
+    a.gfix_sum = st->have_fix ? st->gfix_sum : 0.0;
     a.Mhat = r.mhat;
-    a.x_cur = c->xb[c->xcur];
+    a.x_cur = st->xb[st->xcur];
     a.K = K;
     a.L = r.L;
     a.p0s = r.p0s;
     a.us = r.us;
     a.dt = dt;
     a.stop_at_accepts = stop_at_accepts;
-    a.accept_count0 = c->accept_count;
+    a.accept_count0 = st->accept_count;
     a.accepted = r.accepted;
     a.out5s = r.out5s;
     a.xacc = want_x ? r.xacc : nullptr;
@@ -228,12 +250,12 @@ static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, c
     *n_run = h_run[0];
     for (int k = 0; k < h_run[0]; ++k) {
         if (!accepted[k]) continue;
-        c->accept_count += 1;
-        if (c->ring && c->accept_count > record_from) {
+        st->accept_count += 1;
+        if (st->ring && st->accept_count > record_from) {
             ring_store_kernel<<<dim3((unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream>>>(
-                r.xacc + (size_t)k * M, c->weighted ? c->wm : nullptr, c->M, c->ring + (size_t)c->ring_next * M);
-            c->ring_next = (c->ring_next + 1) % c->ring_K;
-            c->ring_count += 1;
+                r.xacc + (size_t)k * M, c->weighted ? c->wm : nullptr, c->M, st->ring + (size_t)st->ring_next * M);
+            st->ring_next = (st->ring_next + 1) % st->ring_K;
+            st->ring_count += 1;
         }
         if (x_out)
             HIPCHK(c, hipMemcpyAsync(x_out + (size_t)k * M, r.xacc + (size_t)k * M, M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -241,10 +263,10 @@ static int chain_run_lonres(gh_ctx *c, int K, const int *L, const double *p0s, c
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // (d, r and the scalars of the current sample are behind x now: chain_state_fresh brings them up to date for
     // whoever reads them next)
-    c->U_cur[0] = h_u[0];
-    c->U_cur[1] = h_u[1];
-    c->U_cur[2] = h_u[2];
-    c->spec_valid = c->pn_valid = false;
-    c->st_stale = true;
+    st->U_cur[0] = h_u[0];
+    st->U_cur[1] = h_u[1];
+    st->U_cur[2] = h_u[2];
+    st->spec_valid = st->pn_valid = false;
+    st->st_stale = true;
     return GH_OK;
 }

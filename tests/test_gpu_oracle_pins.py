@@ -282,7 +282,9 @@ def test_c5_share_full_size_oracle_columns(G, orc):
 
 def test_shift_invariant_batch_of_chains_against_the_oracle(G, orc):
     """BASELINE configs[3] names 8 chains: gh_batch_* on the shift-invariant store runs every chain as a light
-    context of its own on the shared tables (own stream and thread).  Coarse geometry: every chain against
+    context of its own on the shared tables -- with an element-wise regulariser (MS, Damping: here) the chains take
+    turns in the persistent launch of csrc/lonres.hip.h, otherwise each on its own stream and thread
+    (tests/test_gpu_mfbatch.py covers those).  Coarse geometry: every chain against
     oracle.Problem.leapfrog on the oracle's dense kernel, rounds (gh_batch_trajectory) and lists (gh_batch_run,
     with and without carry-over); C4 geometry: chains 0 and 5 of 8 against a single chain on the table."""
     rng = np.random.default_rng(17)
