@@ -29,14 +29,18 @@
  *     inside the pass instead of the near-field table), GRAVHMC_MFB_FUSED=0 (matrix-free batch: two
  *     passes instead of teams), GRAVHMC_MFB_RU=0 (no one-height specialisation), GRAVHMC_BATCH_SPEC=0,
  *     GRAVHMC_BATCH_RELAYOUT=0, GRAVHMC_BATCH_TEAM=0 (stored-kernel batch: two reads of G per step with a second
- *     copy of G instead of teams reading it once),
+ *     copy of G instead of teams reading it once), GRAVHMC_RESIDENT_BATCH=0 (chains of a batch take turns in the
+ *     resident kernel instead of running in lock-step), GRAVHMC_LONSYM_HARMONIC=0 / GRAVHMC_LONSYM_FUSED=1 /
+ *     GRAVHMC_LONSYM_RESIDENT=0 (shift-invariant store: direct correlations / one-launch epilogue / one launch per
+ *     phase instead of the persistent launch), GRAVHMC_LONSYM_W,
  *     GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
  *   arithmetic of an entry (within the path's stated 1e-10, ~1e-14 measured): GRAVHMC_MF_EXACT -- the
  *     DEFAULT of gh_set_matrix_free_exact only; that call overrides it;
  *   tuning without any effect on results: GRAVHMC_PF, _NT, _TW, _TW8, _WG_PER_CU, _MIN_COLS,
  *     _INFLIGHT_MB, GRAVHMC_MF_T, _MF_WG_PER_CU, GRAVHMC_MFB_WG_PER_CU, _MFB_RANGES, GRAVHMC_RNG_THREADS;
  *   test hooks (force a time-out path): GRAVHMC_TEAM_TEST_ABORT, GRAVHMC_RESIDENT_TEST_ABORT,
- *     GRAVHMC_MFB_TEST_ABORT, GRAVHMC_BATCH_TEAM_TEST_ABORT, GRAVHMC_MF_TEAM_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, GRAVHMC_BT_BREAK, and
+ *     GRAVHMC_MFB_TEST_ABORT, GRAVHMC_BATCH_TEAM_TEST_ABORT, GRAVHMC_MF_TEAM_TEST_ABORT, GRAVHMC_RESBATCH_TEST_ABORT,
+ *     GRAVHMC_LONRES_TEST_ABORT; timing experiments that BREAK results: GRAVHMC_MFB_DBG, GRAVHMC_BT_BREAK, and
  *     GRAVHMC_RESIDENT_TIMING, GRAVHMC_MFB_TIMING (+ GRAVHMC_BT_DBG_MEM / _WAVE: whose), GRAVHMC_LONSYM_TIMING
  *     (per-phase clocks, results intact).
  * (Python side: GRAVHMC_HOST_RNG=numpy draws with np.random itself -- same stream; GRAVHMC_LIB = path
