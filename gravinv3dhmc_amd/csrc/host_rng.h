@@ -15,6 +15,15 @@
 
 static const int RNG_BLOCKS = 8;
 
+// The generator's two block loops (624 states per twist, 624 tempered outputs) are most of a draw's sequential time:
+// ~10 integer operations per 32-bit output, five outputs per normal.  They vectorise; compiled once more for the wider
+// vectors of the host that runs them (the resolver picks at load time; the integer arithmetic is the same bit for bit).
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define GH_HOST_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define GH_HOST_CLONES
+#endif
+
 struct gh_rng {
     uint32_t keys[RNG_BLOCKS][624];  // generator state after each twist (what np.random.get_state holds)
     uint32_t out[RNG_BLOCKS * 624];  // tempered outputs of those states
@@ -23,10 +32,10 @@ struct gh_rng {
     int has_gauss;
     double gauss;
     std::vector<double> r2;          // squared radii of one call's accepted points
-    int threads = 0;                 // helpers of the scale pass (0: GRAVHMC_RNG_THREADS, default 4)
+    int threads = 0;                 // threads of a draw (gh_rng_set_threads; 0: GRAVHMC_RNG_THREADS, default 2)
 };
 
-static void rng_twist(const uint32_t *in, uint32_t *mt)
+GH_HOST_CLONES static void rng_twist(const uint32_t *in, uint32_t *mt)
 {
     if (mt != in) memcpy(mt, in, 624 * sizeof(uint32_t));
     int i;
@@ -42,7 +51,7 @@ static void rng_twist(const uint32_t *in, uint32_t *mt)
     mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
 }
 
-static void rng_temper(const uint32_t *mt, uint32_t *o)
+GH_HOST_CLONES static void rng_temper(const uint32_t *mt, uint32_t *o)
 {
     for (int i = 0; i < 624; ++i) {
         uint32_t y = mt[i];
@@ -227,6 +236,39 @@ int gh_rng_draw_trajectories(gh_rng *r, int K, int Lmin, int Lmax, int64_t M, do
     double *r2 = r->r2.data();
     double last[2] = {0.0, 0.0};
     size_t at = first, ip = 0;
+    // The scale pass (sqrt(-2 log(r2) / r2) per accepted point: libm's log, as NumPy) runs BEHIND the generation on a
+    // second thread, a trajectory's points at a time: the generation itself is sequential (MT19937's twists, the
+    // rejections), ~2 of a draw's 3.5 ns per normal.  (Splitting the scale pass over several threads AFTER the
+    // generation, as before, was slower than one thread on a GPU box's host: 4.3 against 3.5 ns per normal.)
+    auto scale = [&](size_t p_lo, size_t p_hi) {
+        for (size_t i = p_lo; i < p_hi; ++i) {
+            const double f = rng_disc_factor(r2[i]);
+            const size_t o = first + 2 * i;
+            p0s[o] = (f * p0s[o]) * sigma;
+            if (o + 1 < total) p0s[o + 1] = (f * p0s[o + 1]) * sigma;
+        }
+    };
+    int nt = r->threads > 0 ? r->threads : env_int("GRAVHMC_RNG_THREADS", 2);
+    const bool piped = nt > 1 && npairs >= 16384;
+    std::atomic<size_t> produced{0};
+    std::atomic<bool> finished{false};
+    std::thread helper;
+    if (piped)
+        helper = std::thread([&]() {
+            size_t lo = 0;
+            for (;;) {
+                const bool fin = finished.load(std::memory_order_acquire);
+                const size_t hi = produced.load(std::memory_order_acquire);
+                if (hi > lo) {
+                    scale(lo, hi);
+                    lo = hi;
+                } else if (fin) {
+                    break;
+                } else {
+                    std::this_thread::yield();
+                }
+            }
+        });
     for (int k = 0; k < K; ++k) {
         // masked rejection on 32-bit outputs (none drawn when there is one possible value)
         uint32_t v = 0;
@@ -252,24 +294,13 @@ int gh_rng_draw_trajectories(gh_rng *r, int K, int Lmin, int Lmax, int64_t M, do
             }
         }
         us[k] = rng_double(r);
+        if (piped) produced.store(ip, std::memory_order_release);
     }
-    auto scale = [&](size_t p_lo, size_t p_hi) {
-        for (size_t i = p_lo; i < p_hi; ++i) {
-            const double f = rng_disc_factor(r2[i]);
-            const size_t o = first + 2 * i;
-            p0s[o] = (f * p0s[o]) * sigma;
-            if (o + 1 < total) p0s[o + 1] = (f * p0s[o + 1]) * sigma;
-        }
-    };
-    int nt = r->threads > 0 ? r->threads : env_int("GRAVHMC_RNG_THREADS", 4);
-    nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(nt, 64), npairs / 8192));
-    if (nt <= 1) {
-        scale(0, npairs);
+    if (piped) {
+        finished.store(true, std::memory_order_release);
+        helper.join();
     } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(scale, npairs * t / nt, npairs * (t + 1) / nt);
-        scale(0, npairs / nt);
-        for (auto &x : th) x.join();
+        scale(0, npairs);
     }
     if (tail) {
         r->gauss = rng_disc_factor(r2[npairs - 1]) * last[1];

@@ -19,7 +19,7 @@ from .. import _lib
 
 def draw_workers(n_chains):
     """Threads for the draws of n_chains generators side by side: a draw is mostly SEQUENTIAL (the twists of MT19937
-    and the polar method's rejections: ~13 ns per normal on one core, 9 with helpers for its logarithms), so the
+    and the polar method's rejections: 3.5 ns per normal on one core of a GPU box's host, the logarithms included), so the
     chains' draws go on as many cores as the process may use less three (the thread that feeds the GPU, the one that
     reports, the interpreter) -- one generator per core, no helpers."""
     return int(max(1, min(int(n_chains), _lib.load().gh_host_cores() - 3)))
@@ -49,8 +49,8 @@ class LegacyDraws(object):
         if not self._own:
             self.adopt()
             # (ONE chain on the global stream: its draws are what the GPU waits for -- at 72 000 cells a trajectory's
-            # normals cost 340 us with four helpers against 250 us of GPU time -- so the logarithms get every core
-            # the process may use; the seeded generators of a batch of chains draw side by side and keep the default)
+            # normals cost 250 us on one core against 250 us of GPU time -- so the scale pass runs on a second thread
+            # behind the sequential generation; the seeded generators of a batch of chains draw side by side, one per core)
             self._lib.gh_rng_set_threads(self._h, -1)
         if helpers is not None:
             self._lib.gh_rng_set_threads(self._h, int(helpers))

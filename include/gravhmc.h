@@ -438,7 +438,8 @@ int gh_rng_create(gh_rng **out, uint32_t seed);
 void gh_rng_destroy(gh_rng *rng);
 int gh_rng_set_state(gh_rng *rng, const uint32_t *key624, int pos, int has_gauss, double cached);
 int gh_rng_get_state(const gh_rng *rng, uint32_t *key624, int *pos, int *has_gauss, double *cached);
-/* helpers of a draw's scale pass: 0 = default (GRAVHMC_RNG_THREADS, else 4), -1 = all the process may use less two */
+/* threads of a draw: 1 = the calling thread alone, 2 = the scale pass (the logarithms) on a second thread behind the
+ * sequential generation; 0 = default (GRAVHMC_RNG_THREADS, else 2); -1 = 2 where the process has four cores or more */
 int gh_rng_set_threads(gh_rng *rng, int threads);
 /* host cores this process may use: the affinity mask capped by the cgroup's CPU quota */
 int gh_host_cores(void);
