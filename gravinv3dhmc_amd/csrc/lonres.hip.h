@@ -70,7 +70,7 @@ struct LonResArgs {
 
 static inline size_t lonres_lds_doubles(int n, int nf, int na, int rw)
 {
-    return lonsymh_lds_doubles(n, nf, na, rw) + 2 * 64 + 128 + 8 * 64 + 2 * 64 + 3 * LR_MAXWG + 64;
+    return lonsymh_lds_doubles(n, nf, na, rw) + 2 * (size_t)rw + 2 * 64 + 128 + 8 * 64 + 2 * 64 + 3 * LR_MAXWG + 64;
 }
 
 // Sums of NV values over the workgroup's four waves in a fixed tree (the same bits wherever the same values meet),
@@ -91,45 +91,12 @@ __device__ __forceinline__ void block_sums(double (&v)[NV], double *redn)
     for (int i = 0; i < NV; ++i) v[i] = ((redn[i] + redn[NV + i]) + redn[2 * NV + i]) + redn[3 * NV + i];
 }
 
-// lh_idft_part for NQ coefficient rows H + roff[q] at the SAME longitude k: one twiddle read per frequency serves all rows
-template <int NQ>
-__device__ __forceinline__ void lh_idft_rows(const d2 *H, const int (&roff)[NQ], const d2 *tws, int nf, int k, int n, double (&sum)[NQ])
-{
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) sum[q] = 0.0;
-    int idx = 0, ff = 0;
-    for (; ff + 4 <= nf; ff += 4) {
-        d2 w[4], h[NQ][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            w[u] = tws[idx];
-            idx += k;
-            if (idx >= n) idx -= n;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) h[q][u] = H[roff[q] + ff + u];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) sum[q] += h[q][u].x * w[u].x - h[q][u].y * w[u].y;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (; ff < nf; ++ff) {
-        const d2 w = tws[idx];
-        idx += k;
-        if (idx >= n) idx -= n;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const d2 h = H[roff[q] + ff];
-            sum[q] += h.x * w.x - h.y * w.y;
-        }
-    }
-}
-
-// lh_dft_part for NR sequences v + r * stride at the SAME frequency f
+// X^[f] = sum_k x[k] e^{-2 pi i f k / n} of NR real sequences given as their even and odd parts over the pairs (k, n - k):
+// ev[kp] = x[kp] + x[n - kp], od[kp] = x[kp] - x[n - kp] (kp = 0 and 2 kp = n: the cell itself, od = 0), kp in [k0, k1):
+//     x[k] e^{-i t} + x[n - k] e^{+i t} = ev cos t - i od sin t  -- half the terms of the plain sum (lh_dft_part).
 template <int NR>
-__device__ __forceinline__ void lh_dft_rows(const double *v, int stride, const d2 *tws, int k0, int k1, int f, int n, d2 (&acc)[NR])
+__device__ __forceinline__ void lh_dft_eo_rows(const double *ev, const double *od, int stride, const d2 *tws, int k0, int k1, int f,
+                                               int n, d2 (&acc)[NR])
 {
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = d2{0.0, 0.0};
@@ -137,22 +104,25 @@ __device__ __forceinline__ void lh_dft_rows(const double *v, int stride, const d
     int k = k0;
     for (; k + 4 <= k1; k += 4) {
         d2 w[4];
-        double xv[NR][4];
+        double e[NR][4], o[NR][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             w[u] = tws[idx];
             idx += f;
             if (idx >= n) idx -= n;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) xv[r][u] = v[r * stride + k + u];
+            for (int r = 0; r < NR; ++r) {
+                e[r][u] = ev[r * stride + k + u];
+                o[r][u] = od[r * stride + k + u];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                acc[r].x += xv[r][u] * w[u].x;
-                acc[r].y -= xv[r][u] * w[u].y;
+                acc[r].x += e[r][u] * w[u].x;
+                acc[r].y -= o[r][u] * w[u].y;
             }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -162,9 +132,42 @@ __device__ __forceinline__ void lh_dft_rows(const double *v, int stride, const d
         if (idx >= n) idx -= n;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            acc[r].x += v[r * stride + k] * w.x;
-            acc[r].y -= v[r * stride + k] * w.y;
+            acc[r].x += ev[r * stride + k] * w.x;
+            acc[r].y -= od[r * stride + k] * w.y;
         }
+    }
+}
+
+// sum_f Re(H[f] e^{+2 pi i f k / n}) at k = kp and at k = n - kp from ONE pass: cs = sum_f H[f].x cos, sn = sum_f H[f].y sin
+// (angle 2 pi f kp / n): the value at kp is cs - sn, at n - kp cs + sn.
+__device__ __forceinline__ void lh_idft_pair(const d2 *H, const d2 *tws, int nf, int kp, int n, double &cs, double &sn)
+{
+    cs = 0.0;
+    sn = 0.0;
+    int idx = 0, ff = 0;
+    for (; ff + 8 <= nf; ff += 8) {
+        d2 w[8], h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            w[u] = tws[idx];
+            idx += kp;
+            if (idx >= n) idx -= n;
+            h[u] = H[ff + u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            cs += h[u].x * w[u].x;
+            sn += h[u].y * w[u].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; ff < nf; ++ff) {
+        const d2 w = tws[idx], h = H[ff];
+        idx += kp;
+        if (idx >= n) idx -= n;
+        cs += h.x * w.x;
+        sn += h.y * w.y;
     }
 }
 
@@ -181,8 +184,9 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
     d2 *tws = Rh + (size_t)na * nf;                           // n
     d2 *Gp = tws + n;                                         // RW x 4 x nf
     d2 *Gh = Gp + RW * 4 * nf;                                // RW x nf
-    double *xs = reinterpret_cast<double *>(Gh + RW * nf);    // RW x n
-    d2 *Xp = reinterpret_cast<d2 *>(xs + RW * n);             // RW x 4 x nf
+    double *xs = reinterpret_cast<double *>(Gh + RW * nf);    // RW x nf even parts, RW x nf odd parts of the rows' x / w
+    double *xo = xs + RW * nf;
+    d2 *Xp = reinterpret_cast<d2 *>(xs + RW * (n + 2));       // RW x 4 x nf
     double *red = reinterpret_cast<double *>(Xp + RW * 4 * nf);  // 16
     d2 *Dh = reinterpret_cast<d2 *>(red + 16);                // 64: the owner's D^[a][:]
     double *row = reinterpret_cast<double *>(Dh + 64);        // 128: slot sums of the class's residuals
@@ -222,19 +226,20 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
     }
     for (int e = tid; e < n; e += LR_THREADS) tws[e] = g.tw[e];
     if (tid == 0) *flag_s = 1;
-    // items of a thread: longitude kt of the rows ht + q HT (64 <= n <= 126: HT = 2 or 3 thread groups of n) -- a thread's
-    // rows share their twiddle factors in the inverse transform
-    constexpr int NI = (RW + 1) / 2;
-    const int HT = LR_THREADS / n, kt = tid % n, ht = tid / n;
+    // items of a thread: the cells at the longitudes kp = lane and n - kp of row `wave` (a wave per row: RW <= 4) -- the
+    // pair shares every term of both transforms (cos even, sin odd about the pair)
+    constexpr int NI = 2;
+    const int kp = lane, rt = wave;
+    const bool pair_ok = rt < RW && kp < nf;
     int64_t ij[NI];
     bool iv[NI];
     double iw[NI], hi[NI], lo[NI], apr[NI], w2[NI], xc[NI], gc[NI], x[NI], p[NI], grad[NI];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
-        const int r = ht + q * HT;
-        const int c = w + r * nwg;
-        iv[q] = ht < HT && r < RW && c < g.nc;
-        ij[q] = (int64_t)(iv[q] ? c : 0) * n + kt;
+        const int c = w + rt * nwg;
+        const int kq = q == 0 ? kp : n - kp;
+        iv[q] = pair_ok && c < g.nc && (q == 0 || (kp > 0 && 2 * kp != n));
+        ij[q] = (int64_t)(iv[q] ? c : 0) * n + (iv[q] ? kq : 0);
         iw[q] = 1.0;
         hi[q] = lo[q] = apr[q] = xc[q] = gc[q] = x[q] = p[q] = grad[q] = 0.0;
         w2[q] = 1.0;
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
                 o_gfix[u] = a.gfix ? a.gfix[o_i[u]] : 0.0;
             }
     }
-    const int qn = (n + 3) / 4;
+    const int qn = (n + 3) / 4, qf = (nf + 3) / 4;
     __syncthreads();
     // What a change dm of the data's mean does to the adjoint product: r -> r - dm in every observation is
     // R^ -> R^ - dm M^, S^_r[f] -> S^_r[f] - dm C_r[f] with C_r[f] = sum_a conj(T^_r[a][f]) M^[a][f]: a constant of the row.
@@ -355,17 +360,17 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
         const unsigned tag = a.tag0 + ev;
         const int par = (int)(ev & 1u);
         // ================= evaluation at x: forward product of the rows, the exchange, adjoint product -> grad
-#pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const int r = ht + q * HT;
-            if (ht < HT && r < RW) xs[r * n + kt] = iv[q] ? x[q] * iw[q] : 0.0;
+        if (pair_ok) {
+            const double x1 = iv[0] ? x[0] * iw[0] : 0.0, x2 = iv[1] ? x[1] * iw[1] : 0.0;
+            xs[rt * nf + kp] = x1 + x2;
+            xo[rt * nf + kp] = iv[1] ? x1 - x2 : 0.0;
         }
         __syncthreads();
-        // X^_r[f]: quarter ag of the longitudes, then the four quarters; D^ partial of the workgroup
+        // X^_r[f]: quarter ag of the longitude pairs, then the four quarters; D^ partial of the workgroup
         if (fv) {
-            const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
+            const int k0 = ag * qf, k1 = (k0 + qf < nf) ? k0 + qf : nf;
             d2 xq[RW];
-            lh_dft_rows<RW>(xs, n, tws, k0 < n ? k0 : n, k1, f, n, xq);
+            lh_dft_eo_rows<RW>(xs, xo, nf, tws, k0 < nf ? k0 : nf, k1, f, n, xq);
 #pragma unroll
             for (int r = 0; r < RW; ++r) Xp[(r * 4 + ag) * nf + f] = xq[r];
         }
@@ -645,17 +650,10 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
         __syncthreads();
         tick(14);
         {
-            int roff[NI];
-            double sv[NI];
-#pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                const int r = ht + q * HT;
-                roff[q] = (r < RW ? r : 0) * nf;
-            }
-            lh_idft_rows<NI>(Gh, roff, tws, nf, kt, n, sv);
-#pragma unroll
-            for (int q = 0; q < NI; ++q)
-                if (iv[q]) grad[q] = 2.0 * ((sv[q] / (double)n) * iw[q]) + greg[q];
+            double cs, sn;
+            lh_idft_pair(Gh + (rt < RW ? rt : 0) * nf, tws, nf, kp < nf ? kp : 0, n, cs, sn);
+            if (iv[0]) grad[0] = 2.0 * (((cs - sn) / (double)n) * iw[0]) + greg[0];
+            if (iv[1]) grad[1] = 2.0 * (((cs + sn) / (double)n) * iw[1]) + greg[1];
         }
         tick(7);
         // ================= what the evaluation was for
