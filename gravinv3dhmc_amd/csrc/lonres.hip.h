@@ -140,11 +140,11 @@ __device__ __forceinline__ void lh_dft_eo_rows(const double *ev, const double *o
 
 // sum_f Re(H[f] e^{+2 pi i f k / n}) at k = kp and at k = n - kp from ONE pass: cs = sum_f H[f].x cos, sn = sum_f H[f].y sin
 // (angle 2 pi f kp / n): the value at kp is cs - sn, at n - kp cs + sn.
-__device__ __forceinline__ void lh_idft_pair(const d2 *H, const d2 *tws, int nf, int kp, int n, double &cs, double &sn)
+__device__ __forceinline__ void lh_idft_pair(const d2 *H, const d2 *tws, int f0, int nf, int kp, int n, double &cs, double &sn)
 {
     cs = 0.0;
     sn = 0.0;
-    int idx = 0, ff = 0;
+    int idx = (int)(((long long)f0 * kp) % n), ff = f0;
     for (; ff + 8 <= nf; ff += 8) {
         d2 w[8], h[8];
 #pragma unroll
@@ -511,13 +511,23 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             // the difference, below), slot sums, the class's sums
             double ds = 0.0, q1 = 0.0, q2 = 0.0;
             {
-                // (two halves of the frequencies on 2 n threads)
-                const int hh = tid / n, kk = tid - hh * n, fm = (nf + 1) / 2;
-                if (hh < 2) row[hh * 128 + kk] = lh_idft_part(Dh, tws, hh * fm, hh ? nf : fm, kk, n);
+                // (the pair (k, n - k) from one pass, the frequencies in four quarters: thread (kp = lane, quarter ag))
+                double *csq = reinterpret_cast<double *>(Rp), *snq = csq + 4 * 64;
+                if (fv) {
+                    const int f0 = ag * qf, f1 = (f0 + qf < nf) ? f0 + qf : nf;
+                    double c_, s_;
+                    lh_idft_pair(Dh, tws, f0 < nf ? f0 : nf, f1, f, n, c_, s_);
+                    csq[ag * 64 + f] = c_;
+                    snq[ag * 64 + f] = s_;
+                }
             }
             __syncthreads();
             if (tid < n) {
-                const double dk = (row[tid] + row[128 + tid]) / (double)n;
+                const double *csq = reinterpret_cast<const double *>(Rp), *snq = csq + 4 * 64;
+                const int kq = (2 * tid <= n) ? tid : n - tid;
+                const double c_ = ((csq[kq] + csq[64 + kq]) + csq[128 + kq]) + csq[192 + kq];
+                const double s_ = ((snq[kq] + snq[64 + kq]) + snq[128 + kq]) + snq[192 + kq];
+                const double dk = ((2 * tid <= n) ? c_ - s_ : c_ + s_) / (double)n;
                 double rs_ = 0.0;
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
@@ -534,8 +544,20 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             block_sums<3>(cs, redn);  // (barriers: row is in place)
             tick(11);
             if (fv) {
-                const int k0 = ag * qn, k1 = (k0 + qn < n) ? k0 + qn : n;
-                Rp[ag * 64 + f] = lh_dft_part(row, tws, k0 < n ? k0 : n, k1, f, n);
+                // R^[a][f] from the slot sums' even and odd parts over the pairs (k, n - k): quarter ag of the pairs
+                const int k0 = ag * qf, k1 = (k0 + qf < nf) ? k0 + qf : nf;
+                d2 rq = d2{0.0, 0.0};
+                int idx = (int)(((long long)f * k0) % n);
+                for (int kk = k0; kk < k1; ++kk) {
+                    const bool self = (kk == 0) || (2 * kk == n);
+                    const double v1 = row[kk], v2 = self ? 0.0 : row[n - kk];
+                    const d2 wv = tws[idx];
+                    idx += f;
+                    if (idx >= n) idx -= n;
+                    rq.x += (v1 + v2) * wv.x;
+                    rq.y -= (self ? 0.0 : v1 - v2) * wv.y;
+                }
+                Rp[ag * 64 + f] = rq;
             }
             __syncthreads();
             if (tid < nf) {
@@ -651,7 +673,7 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
         tick(14);
         {
             double cs, sn;
-            lh_idft_pair(Gh + (rt < RW ? rt : 0) * nf, tws, nf, kp < nf ? kp : 0, n, cs, sn);
+            lh_idft_pair(Gh + (rt < RW ? rt : 0) * nf, tws, 0, nf, kp < nf ? kp : 0, n, cs, sn);
             if (iv[0]) grad[0] = 2.0 * (((cs - sn) / (double)n) * iw[0]) + greg[0];
             if (iv[1]) grad[1] = 2.0 * (((cs + sn) / (double)n) * iw[1]) + greg[1];
         }
