@@ -720,6 +720,7 @@ def main():
     if CPG > 1:
         # ---- several chains per GPU: one RandomState per chain (seed 100 + global chain index,
         # the stream np.random.seed gives the reference's rank), lock-step rounds of L steps
+        import threading
         from concurrent.futures import ThreadPoolExecutor
         from gravinv3dhmc_amd.inversion.rng import LegacyDraws, draw_workers
         pool = ThreadPoolExecutor(max_workers=2)
@@ -765,9 +766,14 @@ def main():
                         acc, _, _, ns, nd = eng.batch_run([[] for _ in range(CPG)], dt, np.zeros((CPG, 0)),
                                                           np.zeros((CPG, 0)), carry=True)
                     else:
+                        entered = threading.Event()
                         fut = pool.submit(eng.batch_run, [[tr[1] for tr in q[:T]] for q in queue], dt,
                                           [[tr[0] for tr in q[:T]] for q in queue],
-                                          [[tr[2] for tr in q[:T]] for q in queue], False, True)
+                                          [[tr[2] for tr in q[:T]] for q in queue], False, True, entered)
+                        # (the GPU has its work before a dozen drawing threads compete for the interpreter lock)
+                        while not entered.wait(0.05):
+                            if fut.done():
+                                break
                         self.top_up()                      # (the offers after this one, while the GPU runs)
                         t_b = time.perf_counter()
                         acc, _, _, ns, nd = fut.result()

@@ -503,14 +503,16 @@ class Engine(object):
                                                 ptr(out5)))
         return [bool(a) for a in acc], out5
 
-    def batch_run(self, p0s, dt, Ls, us, want_x=False, carry=False):
+    def batch_run(self, p0s, dt, Ls, us, want_x=False, carry=False, entered=None):
         """Up to T further trajectories of every chain, the chains desynchronised (gh_batch_run).
         p0s: (C, T, M) array, or C lists of T momentum vectors (not copied); Ls (C, T), us (C, T):
         the trajectories each chain has not started yet.  Returns accepted (C, S) bool, out5
         (C, S, 5), xs (C, S, M) or None -- per chain in order of completion, S = T slots, T + 1
         with carry -- and, with carry=True, (n_started, n_done): the call then ends as soon as a chain has nothing left to
         start, the others keep their trajectory in flight for the next call (T = 0, i.e. C empty
-        lists, drains them)."""
+        lists, drains them).  `entered` (threading.Event) is set right before the library call, which releases the
+        interpreter lock: a caller that runs this on a worker thread waits for it before it starts drawing the next
+        offers on a dozen threads, so the GPU has its work first."""
         Cn = len(p0s)
         T = len(p0s[0]) if Cn else 0
         if any(len(r) != T for r in p0s):
@@ -533,6 +535,8 @@ class Engine(object):
         ns = np.zeros(Cn, dtype=np.int32)
         nd = np.zeros(Cn, dtype=np.int32)
         ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        if entered is not None:
+            entered.set()
         self._chk(self._lib.gh_batch_run(self._h, int(T), ip(Ls) if T else None, ptrs if T else None,
                                          ptr(us) if T else None, float(dt), ip(acc), ptr(out5), ptr(xs),
                                          ip(ns) if carry else None, ip(nd) if carry else None))

@@ -440,7 +440,12 @@ def HMCSampleBatch(model, n_chains, nsamples, ndraws, delta, Lrange,
         while acc_fast.min() < target and not failure:
             p0s, Ls, us = offer()
             # more is drawn on the host while the GPU runs (appended behind what has been offered)
-            fut = pool.submit(eng.batch_run, p0s, delta, Ls, us, want_x, True)
+            entered = threading.Event()
+            fut = pool.submit(eng.batch_run, p0s, delta, Ls, us, want_x, True, entered)
+            # (the GPU has its work before the drawing threads compete for the interpreter lock)
+            while not entered.wait(0.05):
+                if fut.done():
+                    break
             top_up()
             accepted, out5, xs, n_started, n_done = fut.result()
             for c in range(n_chains):
