@@ -386,7 +386,7 @@ def _run_chain_lists(t, Ls, p0s, us, dt):
     return got
 
 
-@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size"])
+@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size", "two_rows_per_workgroup", "four_rows_per_workgroup"])
 def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkeypatch):
     """lonsymh_resident_kernel (csrc/lonres.hip.h): a batch of trajectories of the chain on the shift-invariant store
     in ONE persistent launch -- the table in the workgroups' registers, forward partials / R^ / Metropolis sums
@@ -394,7 +394,9 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
     shuffled order): every trajectory against oracle.Problem.leapfrog on the oracle's dense tesseroid kernel
     (inversion/hmc.py:85-177 over potential.py:688-736), Damping and MS, decisions included.  C4 at full size
     (BASELINE configs[3]: one chain per GPU): against the same chain on the launches per phase
-    (GRAVHMC_LONSYM_RESIDENT=0), which test_shift_invariant_store_against_the_oracle pins to the oracle's rows."""
+    (GRAVHMC_LONSYM_RESIDENT=0), which test_shift_invariant_store_against_the_oracle pins to the oracle's rows.  The
+    other two: the 3 degree grid with 5 and 15 layers (300 / 900 cell rows: two / four rows per workgroup, the other
+    instantiations of the kernel), Damping, against the launches per phase."""
     rng = np.random.default_rng(17)
     if case == "coarse_odd_sizes":
         mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
@@ -402,7 +404,8 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
         perm = rng.permutation(lon.size)
         lon, lat, h = lon[perm], lat[perm], h[perm]
     else:
-        mesh, lon, lat, h = _global_model(G, 3.0, 3.0, -300000, 5000.0)
+        dr = {"c4_full_size": -300000, "two_rows_per_workgroup": -600000, "four_rows_per_workgroup": -200000}[case]
+        mesh, lon, lat, h = _global_model(G, 3.0, 3.0, dr, 5000.0)
     N, M = lon.size, mesh.size
     bounds = mesh.cell_bounds()
 
@@ -436,7 +439,7 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
     p0s = [rng.normal(size=M) * 0.001 for _ in range(nK)]
     us = [float(v) for v in rng.uniform(size=nK)]
     us[4] = 1.0 - 1e-12                                        # (as good as certainly rejected unless H drops)
-    for reg in ("Damping", "MS"):
+    for reg in (("Damping",) if case.endswith("per_workgroup") else ("Damping", "MS")):
         t.set_data(dobs)
         t.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wm)
         t.chain_init(0.3 * wm * rng.uniform(0.1, 1.0, M), low, high)
@@ -445,6 +448,9 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
         st = t.shift_invariant_resident_stats()
         assert st["workgroups"] > 0 and st["launches"] >= 1 and st["timeouts"] == 0, st
         assert st["evaluations"] >= sum(Ls) + 1
+        if case.endswith("per_workgroup"):
+            rows = t.shift_invariant_info()["n_rows"]
+            assert -(-rows // st["workgroups"]) == (2 if case.startswith("two") else 4), (rows, st)
         x_end = t.chain_get_x()
         if case == "coarse_odd_sizes":
             P = orc.Problem(Aw, dobs, 0.001 * wm, reg, 0.05, 0.01, wm=wm, shape=mesh.shape)
@@ -492,8 +498,8 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
                 if ref[k][0]:
                     worst = max(worst, relmax(got[k][2], ref[k][2]))
             worst = max(worst, relmax(x_end, t2.chain_get_x()))
-            print("persistent harmonic pass [C4 size, %s] vs the launches per phase: %.2e, %d of %d accepted"
-                  % (reg, worst, sum(g[0] for g in got), nK))
+            print("persistent harmonic pass [%s, %s] vs the launches per phase: %.2e, %d of %d accepted"
+                  % (case, reg, worst, sum(g[0] for g in got), nK))
             assert worst < 1e-10
             t2.close()
     t.close()
