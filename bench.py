@@ -297,6 +297,7 @@ EXTRA_RUNS = [
     ("c2_hmcsample", ["--workload", "c2_uniform_100x100x50", "--hmcsample", "60"]),
     ("c1_uniform_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--steps", "16000",
                               "--warmup", "1600"]),
+    ("c4_hmcsample", ["--workload", "c4_global_tesseroid", "--hmcsample", "1000"]),
     ("c1_hmcsample_batch_16_chains", ["--workload", "c1_uniform_20x30x10", "--chains-per-gpu", "16", "--hmcsample-batch", "600"]),
     ("c2_uniform_16_chains", ["--workload", "c2_uniform_100x100x50", "--chains-per-gpu", "16", "--steps", "60",
                               "--warmup", "20"]),
@@ -347,6 +348,54 @@ def extra_run(device, extra_args):
                                                         "wavelet_nnz", "dt", "traj_len", "accepted",
                                                         "trajectories")},
             "roofline": {k: r[k] for k in keep if k in r}}
+
+
+def hmcsample_global_block(device, nsamples=300):
+    """The SAMPLER on the reference's own global example (example/global/main_global.py + SetPMTS.txt: 3 degree
+    tesseroid mesh, Damping 0.05, Lrange [5, 20], delta 0.005, bounds [0, 0.8]; BASELINE configs[3] runs it one chain
+    per GPU): GravMagModule(coordinate="spherical", shift_invariant=True) -> HMCSample, draws in the reference's RNG
+    order, misfit.dat and the accepted models written, until `nsamples` proposals have been accepted -- with the binary
+    sample sink and with the reference's text rows (0.8 MB of '%.8f' per sample)."""
+    import contextlib
+    import shutil
+    import tempfile
+    import gravinv3dhmc_amd as g
+    mesh, obs, rho = make_extra("c4_global_tesseroid")
+    lon, lat, h = obs
+    N, M = lon.size, mesh.size
+    t0 = time.time()
+    gm = g.GravMagModule(np.zeros(N), (-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3), (lon, lat, h),
+                         coordinate="spherical", device=device, verbose=False, shift_invariant=True)
+    eng = gm._engine
+    wm = gm.Wm.diagonal()
+    d_true = eng.forward(wm * rho)
+    dobs = d_true + np.random.default_rng(0).normal(0.0, 0.02 * np.abs(d_true).max(), N)
+    eng.set_data(dobs)
+    gm.dobs = dobs
+    out = {"workload": "c4_global_tesseroid (shift-invariant store)", "N_obs": int(N), "M_cells": int(M), "nsamples": nsamples,
+           "Lrange": [5, 20], "dt": 0.005, "setup_s": round(time.time() - t0, 2)}
+    ones = np.ones(M)
+    tmp = tempfile.mkdtemp(prefix="gravhmc_bench_")
+    try:
+        for sink in ("binary", "text"):
+            with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+                t0 = time.perf_counter()
+                chain = g.HMCSample(gm, nsamples, 0, 0.005, [5, 20], 0.01 * ones, 0.001 * ones,
+                                    np.c_[0.0 * ones, 0.8 * ones], "mandatory", 1000, dobs, "Fixed", 0.8, 0.05, "Damping",
+                                    0.01, 100, 0.001, save_folder=os.path.join(tmp, sink + "_chain"),
+                                    sample_sink=sink, posterior_last=0)
+                eng.synchronize()
+                el = time.perf_counter() - t0
+            folder = os.path.join(tmp, sink + "_chain0")
+            written = sum(os.path.getsize(os.path.join(folder, f)) for f in os.listdir(folder))
+            out[sink + "_sink"] = {"seconds": el, "accepted_samples_per_s": nsamples / el,
+                                   "leapfrog_steps": chain.leapfrog_steps, "trajectories": chain.trajectories,
+                                   "leapfrog_steps_per_s": chain.leapfrog_steps / el, "bytes_written": int(written)}
+        out["persistent_launch"] = eng.shift_invariant_resident_stats()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    eng.close()
+    return out
 
 
 def hmcsample_block(device, workload, nsamples=60):
@@ -563,6 +612,9 @@ def config_values(line):
     hb = (line.get("extra") or {}).get("c1_hmcsample_batch_16_chains")
     if isinstance(hb, dict) and "none_sink" in hb:
         out["c1_16_sampler"] = [round(hb["none_sink"]["leapfrog_steps_per_s"], 1), None]
+    h4 = (line.get("extra") or {}).get("c4_hmcsample")
+    if isinstance(h4, dict) and "binary_sink" in h4:
+        out["c4_sampler"] = [round(h4["binary_sink"]["leapfrog_steps_per_s"], 1), None]
     hs = (line.get("extra") or {}).get("c2_hmcsample")
     if isinstance(hs, dict) and "binary_sink" in hs:
         out["c2_sampler"] = [round(hs["binary_sink"]["leapfrog_steps_per_s"], 1),
@@ -644,6 +696,9 @@ def main():
     if args.batch_team != "auto":
         os.environ["GRAVHMC_BATCH_TEAM"] = "1" if args.batch_team == "on" else "0"
 
+    if args.hmcsample > 0 and args.workload == "c4_global_tesseroid":
+        print(json.dumps({"hmcsample": hmcsample_global_block(int(os.environ.get("LOCAL_RANK", "0")), args.hmcsample)}))
+        return
     if args.hmcsample > 0:
         print(json.dumps({"hmcsample": hmcsample_block(int(os.environ.get("LOCAL_RANK", "0")), args.workload,
                                                        args.hmcsample)}))
