@@ -106,14 +106,28 @@ class HamitonianMC(object):
         return xcur, U, dsyn, AcceptFlag, U_data, U_model
 
     # ------------------------------------------------------------------ sample files
+    def _sink(self, name):
+        """The chain's file `name`, appended to.  sample() keeps the files it writes open for the run (an open() per
+        row costs more than a trajectory of a small problem on the GPU) and closes them when it returns."""
+        fh = getattr(self, "_sink_fh", None)
+        if fh is None:
+            return open(self.save_folder + "/" + name, "ab"), True
+        if name not in fh:
+            fh[name] = open(self.save_folder + "/" + name, "ab")
+        return fh[name], False
+
     def _save_models_add(self, x):
         # the bytes np.savetxt(f, x, fmt='%.8f', delimiter=' ') writes (hmc.py:241-245)
-        with open(self.save_folder + "/" + "model" + ".dat", "ab") as f:
-            write_rows_fixed8(f, x)
+        f, own = self._sink("model.dat")
+        write_rows_fixed8(f, x)
+        if own:
+            f.close()
 
     def _save_misfit_add(self, misfit):
-        with open(self.save_folder + "/" + "misfit" + ".dat", "ab") as f:
-            write_rows_fixed8(f, misfit)
+        f, own = self._sink("misfit.dat")
+        write_rows_fixed8(f, misfit)
+        if own:
+            f.close()
 
     def _to_mw(self, x):
         if self.constraint == 'logarithmic':
@@ -161,6 +175,9 @@ class HamitonianMC(object):
             os.remove(self.save_folder + "/model.bin")
 
         fused = self.constraint == 'mandatory' and ndraws + nsamples > 0
+        # (WmInv is diagonal: hmc.py:328's WmInv @ mw is an element-wise product, the same bits)
+        wdiag = WmInv.diagonal() if hasattr(WmInv, "diagonal") and getattr(WmInv, "nnz", -1) == WmInv.shape[0] else None
+        unweight = (lambda v: wdiag * v) if wdiag is not None else (lambda v: WmInv @ v)
 
         def record(U, U_data, U_model, AcceptFlag, get_x):
             """Bookkeeping of one finished trajectory (hmc.py:299-342)."""
@@ -176,12 +193,14 @@ class HamitonianMC(object):
                                     alpha)
                     self._save_misfit_add(misfit)
                     if self.sample_sink == "text":
-                        m = WmInv @ self._to_mw(state["x"])
+                        m = unweight(self._to_mw(state["x"]))
                         m_cache[0, :] = m.copy()
                         self._save_models_add(m_cache)
                     elif self.sample_sink == "binary":
-                        with open(self.save_folder + "/model.bin", "ab") as f:
-                            np.ascontiguousarray(WmInv @ self._to_mw(state["x"])).tofile(f)
+                        f, own = self._sink("model.bin")
+                        np.ascontiguousarray(unweight(self._to_mw(state["x"]))).tofile(f)
+                        if own:
+                            f.close()
                     if window and not fused:
                         self.model._engine.posterior_add()
                 state["i"] += 1
@@ -220,11 +239,15 @@ class HamitonianMC(object):
                 return record(o[0], o[1], o[2], acc, lambda: xs)
 
             self.trajectories = self.leapfrog_steps = 0
+            self._sink_fh = {}
             try:
                 eng.run_chain(source, self.dt, on_result,
                               stop_at_accepts=ndraws + nsamples, record_from=ndraws,
                               want_x=self.sample_sink != "none", overlap=True)
             finally:
+                for fh in self._sink_fh.values():
+                    fh.close()
+                self._sink_fh = None
                 if hasattr(source, "release"):
                     source.release()
             self._chain_x = state["x"]
