@@ -1296,7 +1296,7 @@ static int kids_run(gh_ctx *c, int T, const int *L, const double *const *p0rows,
     const int C = (int)c->kids.size();
     const size_t M = (size_t)c->M;
     std::vector<int> rcs((size_t)C, GH_OK);
-    // Element-wise regulariser on the harmonic store: the chains TAKE TURNS in the persistent launch (lonres.hip.h) -- a
+    // On the harmonic store the chains TAKE TURNS in the persistent launch (lonres.hip.h) -- a
     // chain's whole list in one launch with the table in the workgroups' registers: one chain alone runs faster that way
     // (35 k steps/s at C4) than eight side by side on the launches per phase (29-32 k together).  A launch that gives up
     // leaves its chain untouched: that chain and the ones behind it run on their own streams as below.

@@ -41,11 +41,11 @@ static bool lonres_plan(gh_ctx *c)
     return true;
 }
 
-// lonres_plan + what depends on the regulariser set at the moment (element-wise kinds only)
+// lonres_plan + what depends on the regulariser set at the moment (the stencil kinds need the model's shape)
 static bool lonres_usable(gh_ctx *c)
 {
     if (!lonres_plan(c)) return false;
-    return c->reg_kind == 0 || c->reg_kind == 2;
+    return c->reg_kind >= 0 && c->reg_kind <= 3 && (c->reg_kind == 0 || c->reg_kind == 2 || c->shape[0] > 0);
 }
 
 // K trajectories of the context's chain in one launch (same contract as gh_chain_run / chain_run_resident).
@@ -70,7 +70,8 @@ static int chain_run_lonres(gh_ctx *c, gh_ctx *st, int K, const int *L, const do
         TRY(dalloc(c, &r.rhatg, 2 * E));
         TRY(dalloc(c, &r.clsg, 2 * 64 * 4));
         TRY(dalloc(c, &r.scalg, 2 * (size_t)LR_MAXWG * 2));
-        TRY(dalloc(c, &r.ppg, 2 * (size_t)LR_MAXWG));
+        TRY(dalloc(c, &r.ppg, 2 * (size_t)LR_MAXWG * 2));
+        TRY(dalloc(c, &r.xpub, 2 * (size_t)c->M));
         TRY(dalloc(c, &r.abort_w, 4));
         TRY(dalloc(c, &r.n_run, 4));
         TRY(dalloc(c, &r.ucur, 4));
@@ -113,7 +114,7 @@ static int chain_run_lonres(gh_ctx *c, gh_ctx *st, int K, const int *L, const do
         HIPCHK(c, hipMemsetAsync(r.xslabg, 0, 2 * (size_t)RES_CLUSTERS * E * 2 * sizeof(ghk::u32x4), c->stream));
         HIPCHK(c, hipMemsetAsync(r.clsg, 0, 2 * 64 * 4 * sizeof(ghk::u32x4), c->stream));
         HIPCHK(c, hipMemsetAsync(r.scalg, 0, 2 * (size_t)LR_MAXWG * 2 * sizeof(ghk::u32x4), c->stream));
-        HIPCHK(c, hipMemsetAsync(r.ppg, 0, 2 * (size_t)LR_MAXWG * sizeof(ghk::u32x4), c->stream));
+        HIPCHK(c, hipMemsetAsync(r.ppg, 0, 2 * (size_t)LR_MAXWG * 2 * sizeof(ghk::u32x4), c->stream));
         r.tag = r.tagE = r.ltag = 0;
         r.dirty = false;
     }
@@ -177,6 +178,10 @@ static int chain_run_lonres(gh_ctx *c, gh_ctx *st, int K, const int *L, const do
     a.mwapr = st->mwapr;
     a.wm2 = st->wm2;
     a.kind = st->reg_kind;
+    a.nz = st->shape[0];
+    a.ny = st->shape[1];
+    a.nx = st->shape[2];
+    a.xpub = r.xpub;
     a.ms_grad_den_mw = 0;
     a.alpha = st->alpha;
     a.beta = st->beta;

@@ -36,7 +36,7 @@ struct LonSymHost {
         bool dirty = false;
         int Kcap = 0;
         int *L = nullptr, *accepted = nullptr, *n_run = nullptr;
-        double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr, *ucur = nullptr;
+        double *p0s = nullptr, *us = nullptr, *out5s = nullptr, *xacc = nullptr, *ucur = nullptr, *xpub = nullptr;
         double *h_stage = nullptr;
         size_t h_stage_n = 0;
         int64_t launches = 0, evals = 0, trajectories = 0;

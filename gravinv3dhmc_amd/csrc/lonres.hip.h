@@ -18,8 +18,10 @@
 // Trajectories end inside the launch: the final momentum's sum of squares in a one-hop all-gather, the
 // Metropolis test (hmc.py:159-177) evaluated identically by every workgroup.  Same contract as
 // resident_chain_kernel (K trajectories per launch, the host draws the momenta and variates in the reference's
-// order; every wait bounded, an aborted launch leaves the chain untouched).  Element-wise regularisers
-// (Damping, MS); the stencil kinds stay on the launches of lonsymh.hip.h.
+// order; every wait bounded, an aborted launch leaves the chain untouched).  All four regularisers: the element-wise
+// ones (Damping, MS) behind the publish flag; the stencil kinds (Smoothness, TV) read their neighbours' cells from
+// the positions every workgroup publishes (write-through) with an evaluation, behind hop 3, and their value
+// travels with the trajectory's p'p.
 // Reference arithmetic: inversion/hmc.py:85-177, inversion/potential.py:698-736, gravmag/_tesseroid_numba.py:207-222.
 #pragma once
 #include "lonsymh.hip.h"
@@ -37,7 +39,9 @@ struct LonResArgs {
     const double *wm;             // column weights (nullptr: none)
     const double *low, *high, *mwapr, *wm2;
     int kind, ms_grad_den_mw;
+    int nz, ny, nx;               // the model's shape (stencil regularisers)
     double alpha, beta;
+    double *xpub;                 // 2 x M: the models as the stencil regularisers see them (Smoothness, TV), by parity
     const double *dobs_c, *gfix;  // gfix: nullptr without a fixed part of the data term
     double gfix_sum;
     const d2 *Mhat;               // [na][nf]: transform of the slots' observation counts (R^ of a residual of ones)
@@ -61,7 +65,7 @@ struct LonResArgs {
     d2 *rhatg;                    // 2 x E, untagged: complete behind the classes' scalars
     u32x4 *clsg;                  // 2 x 64 x 4: per class {sum of d, sum of q, sum of q^2} (q: residual against the previous mean)
     u32x4 *scalg;                 // 2 x LR_MAXWG x 2: per workgroup {regulariser share, p0'p0 share}
-    u32x4 *ppg;                   // 2 x LR_MAXWG: per workgroup p'p share at the end of a trajectory
+    u32x4 *ppg;                   // 2 x LR_MAXWG x 2: per workgroup {p'p share, stencil regulariser's share} at the end of a trajectory
     u64 *xccg;
     unsigned tag0, tagE0, ltag;
     unsigned *abort_w;
@@ -290,7 +294,7 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
     const __amdgpu_buffer_rsrc_t rs_rh = __builtin_amdgcn_make_buffer_rsrc(a.rhatg, 0, 2 * E * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_cls = __builtin_amdgcn_make_buffer_rsrc(a.clsg, 0, 2 * 64 * 64, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(a.scalg, 0, 2 * LR_MAXWG * 32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_pp = __builtin_amdgcn_make_buffer_rsrc(a.ppg, 0, 2 * LR_MAXWG * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_pp = __builtin_amdgcn_make_buffer_rsrc(a.ppg, 0, 2 * LR_MAXWG * 32, 0x00020000);
 
     // ---- the class this workgroup owns (at most one: nwg >= na), the observations of its slots
     int own = -1;
@@ -315,6 +319,18 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             }
     }
     const int qn = (n + 3) / 4, qf = (nf + 3) / 4;
+    const bool stencil = a.kind == 1 || a.kind == 3;
+    RegArgs ra{};
+    ra.ms_grad_den_mw = a.ms_grad_den_mw;
+    ra.kind = a.kind;
+    ra.M = a.M;
+    ra.nz = a.nz;
+    ra.ny = a.ny;
+    ra.nx = a.nx;
+    ra.alpha = a.alpha;
+    ra.beta = a.beta;
+    ra.mwapr = a.mwapr;
+    ra.wm2 = a.wm2;
     __syncthreads();
     // What a change dm of the data's mean does to the adjoint product: r -> r - dm in every observation is
     // R^ -> R^ - dm M^, S^_r[f] -> S^_r[f] - dm C_r[f] with C_r[f] = sum_a conj(T^_r[a][f]) M^[a][f]: a constant of the row.
@@ -354,12 +370,45 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
     long long accepts = a.accept_count0;
     unsigned ev = 0, evE = 0;
     bool stop = false;
+    // one-hop all-gather of two scalars per workgroup (every workgroup reads every workgroup's pair; fixed-tree sums)
+    auto gather2 = [&](double v0, double v1, double &s0, double &s1) -> bool {
+        evE += 1;
+        const unsigned tagE = a.tagE0 + evE;
+        const int parE = (int)(evE & 1u);
+        if (tid == 0) {
+            rb_store(rs_pp, (unsigned)(((parE * LR_MAXWG + w) * 2 + 0) * 16), rb_pack(tagE, v0), false);
+            rb_store(rs_pp, (unsigned)(((parE * LR_MAXWG + w) * 2 + 1) * 16), rb_pack(tagE, v1), false);
+        }
+        double gsum[2] = {0.0, 0.0};
+        {
+            unsigned off[2] = {(unsigned)(((parE * LR_MAXWG + (tid < nwg ? tid : 0)) * 2) * 16),
+                               (unsigned)(((parE * LR_MAXWG + (tid < nwg ? tid : 0)) * 2 + 1) * 16)};
+            double v[2];
+            const bool got = rb_poll<2>(a.abort_w, rs_pp, tagE, tid < nwg ? 2 : 0, off, v);
+            if (tid < nwg) {
+                gsum[0] = v[0];
+                gsum[1] = v[1];
+            }
+            if (!got) *flag_s = 0;
+        }
+        block_sums<2>(gsum, redn);
+        s0 = gsum[0];
+        s1 = gsum[1];
+        return *flag_s != 0;
+    };
     tick(0);
     for (;;) {
         ev += 1;
         const unsigned tag = a.tag0 + ev;
         const int par = (int)(ev & 1u);
         // ================= evaluation at x: forward product of the rows, the exchange, adjoint product -> grad
+        if (stencil) {
+            // (the neighbours' cells belong to other workgroups: write-through, read behind hop 3 -- every workgroup's
+            // stores are drained before its flag, and no R^ exists before every flag does)
+#pragma unroll
+            for (int q = 0; q < NI; ++q)
+                if (iv[q]) st_wt(a.xpub + (int64_t)par * a.M + ij[q], x[q]);
+        }
         if (pair_ok) {
             const double x1 = iv[0] ? x[0] * iw[0] : 0.0, x2 = iv[1] ? x[1] * iw[1] : 0.0;
             xs[rt * nf + kp] = x1 + x2;
@@ -418,7 +467,9 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
         for (int q = 0; q < NI; ++q) {
             const double v = x[q] - apr[q];
             double gq = 0.0, val = 0.0;
-            if (a.kind == 0) {
+            if (stencil) {
+                // (behind hop 3, below)
+            } else if (a.kind == 0) {
                 val = v * v;
                 gq = 2.0 * v;
             } else {
@@ -631,11 +682,25 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
         }
         if (*flag_s == 0) return;
         tick(6);
-        const double Rtot = sc5[0], pp0tot = sc5[1];
+        double Rtot = sc5[0];
+        const double pp0tot = sc5[1];
         const double mean = (sc5[2] + a.gfix_sum) / (double)a.N;
         const double dmean = mean - mean_prev;
         const double Ud = (sc5[4] - 2.0 * dmean * sc5[3]) + (double)a.N * dmean * dmean;
         mean_prev = mean;
+        double rshare_st = 0.0;
+        if (stencil) {
+            // Smoothness / TV (potential.py:786-810) at the positions every workgroup published with this evaluation
+            ra.x = a.xpub + (int64_t)par * a.M;
+            double rv = 0.0;
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                double val = 0.0;
+                greg[q] = iv[q] ? a.alpha * reg_cell<false, true>(ra, ij[q], x[q], val) : 0.0;
+                rv += iv[q] ? val : 0.0;
+            }
+            rshare_st = block_allreduce_sum(rv, red, LR_THREADS / 64);  // (its total travels with the trajectory's p'p)
+        }
         // ---- adjoint product: S^_r[f] = sum_a conj(T^_r[a][f]) R^[a][f]
         if (fv) {
             d2 rr[LH_AK];
@@ -686,6 +751,10 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
             // the chain's current sample: gradient and potential (hmc.py:85-93)
 #pragma unroll
             for (int q = 0; q < NI; ++q) gc[q] = grad[q];
+            if (stencil) {
+                double unused = 0.0;
+                if (!gather2(0.0, rshare_st, unused, Rtot)) return;
+            }
             U1 = Ud;
             U2 = Rtot;
             U0 = Ud + a.alpha * Rtot;
@@ -718,21 +787,9 @@ __global__ void __launch_bounds__(LR_THREADS) lonsymh_resident_kernel(LonResArgs
                 pps += iv[q] ? pf * pf : 0.0;
             }
             const double ppw = block_allreduce_sum(pps, red, LR_THREADS / 64);
-            evE += 1;
-            const unsigned tagE = a.tagE0 + evE;
-            const int parE = (int)(evE & 1u);
-            if (tid == 0) rb_store(rs_pp, (unsigned)((parE * LR_MAXWG + w) * 16), rb_pack(tagE, ppw), false);
-            double pp1v[1] = {0.0};
-            {
-                unsigned off[1] = {(unsigned)((parE * LR_MAXWG + (tid < nwg ? tid : 0)) * 16)};
-                double v[1];
-                const bool got = rb_poll<1>(a.abort_w, rs_pp, tagE, tid < nwg ? 1 : 0, off, v);
-                if (tid < nwg) pp1v[0] = v[0];
-                if (!got) *flag_s = 0;
-            }
-            block_sums<1>(pp1v, redn);
-            if (*flag_s == 0) return;
-            const double pp1 = pp1v[0];
+            double pp1 = 0.0, rst = 0.0;
+            if (!gather2(ppw, rshare_st, pp1, rst)) return;
+            if (stencil) Rtot = rst;
             // Metropolis (hmc.py:159-177): the same bits in every workgroup
             const double Unew = Ud + a.alpha * Rtot;
             const double Hcur = 0.5 * pp0 + U0, Hnew = 0.5 * pp1 + Unew;

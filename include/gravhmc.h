@@ -135,8 +135,8 @@ int gh_shift_invariant_info(const gh_ctx *ctx, int *n_lon, int *n_classes, int *
 /* The harmonic pass as ONE persistent launch per gh_chain_run call (csrc/lonres.hip.h): every workgroup keeps its cell
  * rows' part of the table in registers for the whole batch of trajectories and the workgroups exchange the forward
  * partials, the residuals' transforms and the Metropolis sums through memory (bounded waits; a launch that gives up
- * leaves the chain untouched and the call runs on the launches per phase).  Element-wise regularisers (Damping, MS),
- * one chain per GPU (example/global/run_main.sh:16 runs one chain per rank).  workgroups: grid of the launch (0: not
+ * leaves the chain untouched and the call runs on the launches per phase).  All four regularisers; one chain at a time
+ * (example/global/run_main.sh:16 runs one chain per rank; the chains of a gh_batch_* batch take turns).  workgroups: grid of the launch (0: not
  * in use); launches, evaluations (forward + adjoint product each), trajectories so far, timeouts.
  * GRAVHMC_LONSYM_RESIDENT=0 switches it off. */
 int gh_shift_invariant_resident_stats(gh_ctx *ctx, int *workgroups, int64_t *launches, int64_t *evaluations,

@@ -282,9 +282,9 @@ def test_c5_share_full_size_oracle_columns(G, orc):
 
 def test_shift_invariant_batch_of_chains_against_the_oracle(G, orc):
     """BASELINE configs[3] names 8 chains: gh_batch_* on the shift-invariant store runs every chain as a light
-    context of its own on the shared tables -- with an element-wise regulariser (MS, Damping: here) the chains take
-    turns in the persistent launch of csrc/lonres.hip.h, otherwise each on its own stream and thread
-    (tests/test_gpu_mfbatch.py covers those).  Coarse geometry: every chain against
+    context of its own on the shared tables -- on the harmonic store the chains take turns in the persistent launch
+    of csrc/lonres.hip.h, on the direct form each runs on its own stream and thread (tests/test_gpu_mfbatch.py covers
+    those).  Coarse geometry: every chain against
     oracle.Problem.leapfrog on the oracle's dense kernel, rounds (gh_batch_trajectory) and lists (gh_batch_run,
     with and without carry-over); C4 geometry: chains 0 and 5 of 8 against a single chain on the table."""
     rng = np.random.default_rng(17)
@@ -392,7 +392,8 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
     in ONE persistent launch -- the table in the workgroups' registers, forward partials / R^ / Metropolis sums
     exchanged through memory.  coarse (36 longitudes, duplicated +-180 observations, two observation heights,
     shuffled order): every trajectory against oracle.Problem.leapfrog on the oracle's dense tesseroid kernel
-    (inversion/hmc.py:85-177 over potential.py:688-736), Damping and MS, decisions included.  C4 at full size
+    (inversion/hmc.py:85-177 over potential.py:688-810), all four regularisers -- the stencil kinds read their
+    neighbours' cells from the positions every workgroup publishes with an evaluation --, decisions included.  C4 at full size
     (BASELINE configs[3]: one chain per GPU): against the same chain on the launches per phase
     (GRAVHMC_LONSYM_RESIDENT=0), which test_shift_invariant_store_against_the_oracle pins to the oracle's rows.  The
     other two: the 3 degree grid with 5 and 15 layers (300 / 900 cell rows: two / four rows per workgroup, the other
@@ -439,7 +440,7 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
     p0s = [rng.normal(size=M) * 0.001 for _ in range(nK)]
     us = [float(v) for v in rng.uniform(size=nK)]
     us[4] = 1.0 - 1e-12                                        # (as good as certainly rejected unless H drops)
-    for reg in (("Damping",) if case.endswith("per_workgroup") else ("Damping", "MS")):
+    for reg in (("Damping",) if case.endswith("per_workgroup") else ("Damping", "MS", "TV", "Smoothness")):
         t.set_data(dobs)
         t.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wm)
         t.chain_init(0.3 * wm * rng.uniform(0.1, 1.0, M), low, high)
@@ -473,7 +474,7 @@ def test_shift_invariant_persistent_pass_against_the_oracle(G, orc, case, monkey
             t2.set_data(dobs)
             t2.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wm)
             t2.chain_init(x0, low, high)
-            if reg == "MS":
+            if reg != "Damping":
                 # (MS at this step size is stiff in some cells: rounding differences grow ~30x per trajectory -- measured
                 # 1.6e-16, 2.3e-13, 1.2e-12, 8.8e-10 ... along the list above -- so every trajectory starts from the
                 # reference chain's sample again; Damping runs the whole list in one launch.  The switch is read when a
