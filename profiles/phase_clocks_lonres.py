@@ -1,5 +1,5 @@
 """Per-phase clocks (GRAVHMC_LONSYM_TIMING=1, workgroup 0, thread 0) of the persistent harmonic pass at C4
-(csrc/lonres.hip.h):    python profiles/phase_clocks_lonres.py [steps] [trajectories per call]"""
+(csrc/lonres.hip.h):    python profiles/phase_clocks_lonres.py [steps] [trajectories per call, 0 = default] [regulariser]"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 import gravinv3dhmc_amd as g  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else None
+batch = (int(sys.argv[2]) or None) if len(sys.argv) > 2 else None
+reg = sys.argv[3] if len(sys.argv) > 3 else "Damping"
 mesh = g.mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))
 lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 3.0), np.arange(-90, 91, 3.0), indexing="ij")]
 h = np.full_like(lon, 5000.0)
@@ -28,7 +29,7 @@ rho[1:4, 20:30, 40:60] = 0.3
 d = e.forward(rho.ravel())
 wm = e.weight(0.5)
 e.set_data(d + 0.02 * np.abs(d).max() * np.random.default_rng(0).normal(size=N))
-e.set_reg("Damping", 0.05, 0.01, mesh.shape, 0.001 * wm)
+e.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wm)
 e.chain_init(0.001 * wm, 0.0 * wm, 0.8 * wm)
 rng = np.random.default_rng(1)
 L = 10
