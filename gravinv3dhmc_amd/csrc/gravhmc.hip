@@ -11,6 +11,7 @@
 #include "lonsym.hip.h"
 #include "lonsymh.hip.h"
 #include "lonres.hip.h"
+#include "lonsymw.hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -229,11 +230,12 @@ int gh_shift_invariant_info(const gh_ctx *c, int *n_lon, int *n_classes, int *n_
 int gh_shift_invariant_harmonic(const gh_ctx *c, int *on, int *n_freq, int64_t *table_bytes, int *workgroups)
 {
     if (!c) return GH_ERR_ARG;
-    const bool h = lonsym_harmonic(c);
-    if (on) *on = h ? 1 : 0;
+    // on: 1 = the register form (lonsymh.hip.h), 2 = the streamed form for large grids (lonsymw.hip.h)
+    const bool h = lonsym_one_row(c);
+    if (on) *on = !h ? 0 : c->ls->harm ? 1 : 2;
     if (n_freq) *n_freq = h ? c->ls->nf : 0;
     if (table_bytes) *table_bytes = h ? (int64_t)c->ls->nc * c->ls->na * c->ls->nf * 16 : 0;
-    if (workgroups) *workgroups = h ? c->ls->hgrid : 0;
+    if (workgroups) *workgroups = h ? lonsym_grid(c) : 0;
     return GH_OK;
 }
 
@@ -670,7 +672,6 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     gh_ctx::Wavelet &w = c->wv;
     if (w.on || w.indptr) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: already compressed");
     if (c->sh.kind != 0) return fail(c, GH_ERR_UNSUPPORTED, "wavelet forward on a sharded kernel is not supported");
-    if (lonsym_on(c)) return fail(c, GH_ERR_UNSUPPORTED, "wavelet compression on the shift-invariant store is not supported");
     if (dims == 3) {
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
             return fail(c, GH_ERR_ARG, "cannot reshape array of size %lld into shape (%d,%d,%d)",
@@ -763,6 +764,7 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     w.on = true;
     w.F_valid = false;
     c->rs.state = 0;  // plan the resident chain kernel again (it would need the dense form)
+    if (c->ls) c->ls->res.state = 0;  // (the persistent harmonic pass has no compressed forward: planned again, refused)
     c->chain_ready = false;
     c->bt.ready = false;
     if (nnz_out) *nnz_out = w.nnz;
@@ -1277,6 +1279,13 @@ static int kids_make(gh_ctx *c, int C, const double *x0s, const double *low, con
             if (rc == GH_OK && k->ls->fused) rc = dalloc(k, &k->ls->epi_abort, 4);
             if (rc != GH_OK) return fail(c, rc, "gh_batch_init: %s", gh_last_error(k));
         }
+        if (k->ls->wide) {
+            k->ls->Xhat = nullptr;
+            int rc = dalloc(k, &k->ls->Rhat, (size_t)k->ls->na * (size_t)k->ls->nf);
+            if (rc == GH_OK) rc = dalloc(k, &k->ls->Xhat, (size_t)k->ls->nc * (size_t)k->ls->nf);
+            if (rc == GH_OK) rc = dalloc(k, &k->ls->Dpart, (size_t)k->ls->wparts * (size_t)k->ls->na * (size_t)k->ls->nf);
+            if (rc != GH_OK) return fail(c, rc, "gh_batch_init: %s", gh_last_error(k));
+        }
         int rc = configure_mf(k);
         if (rc == GH_OK) rc = dalloc(k, &k->mf_stats, 1);
         if (rc == GH_OK) rc = gh_chain_init(k, x0s + (size_t)i * (size_t)c->M, low, high);
@@ -1355,7 +1364,11 @@ int gh_batch_init(gh_ctx *c, int C, const double *x0s, const double *low, const 
     if (c->sh.kind != 0)
         return fail(c, GH_ERR_UNSUPPORTED, "batched chains run on the unsharded kernel only");
     HIPCHK(c, hipSetDevice(c->device));
-    if (lonsym_on(c)) return kids_make(c, C, x0s, low, high);
+    if (lonsym_on(c)) {
+        // (the light contexts of the chains share the tables, not a compressed forward operator)
+        if (c->wv.on) return fail(c, GH_ERR_UNSUPPORTED, "batched chains on the shift-invariant store run without the wavelet-compressed forward");
+        return kids_make(c, C, x0s, low, high);
+    }
     // (the wavelet-compressed forward only where the resident chain kernel takes the batch: the MFMA
     // batch has no compressed forward)
     if (c->wv.on && !(resident_usable(c) && resident_lds_doubles(c->ld, c->rs.cpw, C, c->rs.lds_cols, c->rs.split) *

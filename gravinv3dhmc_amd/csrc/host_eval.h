@@ -240,7 +240,8 @@ static int ensure_work(gh_ctx *c)
     TRY(dalloc(c, &c->pn, M));
     if (c->n_panels > 1 || shard_rows(c)) TRY(dalloc(c, &c->gbuf, M));
     // (N > 16384: the team sweep writes one slab row per team, up to 128, whatever the panel grid)
-    TRY(dalloc(c, &c->slab, (size_t)(c->n_panels > 1 ? std::max(c->grid, 128) : c->grid) * ld));
+    // (the harmonic forms of the shift-invariant store deliver ONE finished slab row)
+    TRY(dalloc(c, &c->slab, (size_t)(lonsym_one_row(c) ? 1 : c->n_panels > 1 ? std::max(c->grid, 128) : c->grid) * ld));
     if (c->grid > 64) {
         // segments left for the single-block finish_kernel: as many as keep its read at ~128 KB
         // (C1: 16 x 608 rows; C2: 1 x 10^4 -- sixteen there made that one block read 1.3 MB, 57 us)
@@ -249,7 +250,7 @@ static int ensure_work(gh_ctx *c)
     }
     c->n_dpart = (int)((c->ld + 31) / 32);
     if (c->ld >= 2048 && ((c->TW > 1 && c->n_panels == 1 && !c->mf) || lonsym_on(c)) && env_int("GRAVHMC_EPILOGUE1", 1) != 0) {
-        TRY(dalloc(c, &c->dsum, (size_t)std::max(c->grid, 128)));
+        TRY(dalloc(c, &c->dsum, (size_t)std::max(std::max(c->grid, 128), lonsym_on(c) ? lonsym_classes(c) : 0)));
         for (int i = 0; i < 4; ++i) TRY(dalloc(c, &c->st[i].part, (size_t)c->n_dpart + (size_t)((c->M + 255) / 256)));
     }
     c->n_regpart = (int)((c->M + 255) / 256);

@@ -15,6 +15,11 @@ struct LonSymHost {
     bool harm = false;
     int nf = 0, hgrid = 0, rw = 1;   // rw: cell rows a workgroup of the pass works on at once
     ghk::d2 *That = nullptr, *tw = nullptr, *Rhat = nullptr, *Dpart = nullptr;
+    // the harmonic store as streaming passes over T^ (lonsymw.hip.h): grids beyond the register form's limits
+    bool wide = false, direct_ok = false;
+    int wgrid = 0, wparts = 0, wrows = 0;  // workgroups of the sweep; parts of the forward product, cell rows per part
+    ghk::d2 *Xhat = nullptr;
+    size_t wlds = 0;
     size_t hlds = 0;
     // the epilogue in one launch behind the sweep (lonsymh_epilogue_kernel): default with the harmonic form
     bool fused = false;
@@ -156,10 +161,17 @@ static int lonsym_build(gh_ctx *c)
     const int steps = h.KB * h.W;
     h.SW = (int)((steps + 15) / 16 * 16 + 1);
     h.lds = sizeof(double) * ((size_t)(2 * na + 1) * h.SW + steps + 8 + (size_t)h.AG * h.KB * h.W + 32);
-    if (n > LS_THREADS) return no("more than 1024 longitudes per cell row");
-    if (h.AG * h.KB > (h.thr / 64) * (h.W == 16 ? 1 : LS_MAXITEMS)) return no("too many (class, longitude block) work items for one workgroup");
-    if (h.lds > 160 * 1024 - 512) return no("a cell row's table and the residual grid do not fit the LDS");
-    if (na * n > (int64_t)8 * LS_THREADS) return no("a cell row's table has more than 8192 entries");
+    // (the direct correlations of lonsym.hip.h hold a cell row's table and the residual grid in LDS; grids beyond that
+    // run on the streamed harmonic form, lonsymw.hip.h, which only needs the transforms' tables there)
+    const char *direct_why = nullptr;
+    if (n > LS_THREADS) direct_why = "more than 1024 longitudes per cell row";
+    else if (h.AG * h.KB > (h.thr / 64) * (h.W == 16 ? 1 : LS_MAXITEMS)) direct_why = "too many (class, longitude block) work items for one workgroup";
+    else if (h.lds > 160 * 1024 - 512) direct_why = "a cell row's table and the residual grid do not fit the LDS";
+    else if (na * n > (int64_t)8 * LS_THREADS) direct_why = "a cell row's table has more than 8192 entries";
+    h.direct_ok = direct_why == nullptr;
+    const bool wide_can = n <= LW_NMAX && n >= 2 && env_int("GRAVHMC_LONSYM_WIDE", 1) != 0;
+    if (!h.direct_ok && !wide_can) return no(direct_why);
+    if ((int64_t)na * n > 0x7fffffffLL / 4) return no("more than 2^29 (class, longitude) slots");
     // the table: every class at every shift against the cells of longitude index 0 (reference engine)
     const int64_t Np = na * n;
     h.ldT = (Np + 15) / 16 * 16;
@@ -249,7 +261,7 @@ static int lonsym_build(gh_ctx *c)
     TRY(up(&h.m_of, m_of));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     h.items = (h.AG * h.KB + h.thr / 64 - 1) / (h.thr / 64);
-    HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsym_fn(h.items, h.W, h.thr)), h.lds));
+    if (h.direct_ok) HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsym_fn(h.items, h.W, h.thr)), h.lds));
     h.grid = (int)std::min<int64_t>(nc, c->cus);
     if (env_int("GRAVHMC_LONSYM_TIMING", 0)) TRY(dalloc(c, &h.dbg, 8));
     // The harmonic form (lonsymh.hip.h): n / 2 + 1 frequencies in the lanes of a wave, the classes in four
@@ -262,7 +274,8 @@ static int lonsym_build(gh_ctx *c)
     const int rp = (int)((nc + (int64_t)c->cus - 1) / (int64_t)c->cus);
     h.rw = std::min(rp, 4);
     h.hlds = lonsymh_lds_doubles((int)n, h.nf, (int)na, h.rw) * sizeof(double);
-    if (env_int("GRAVHMC_LONSYM_HARMONIC", 1) != 0 && h.nf <= 64 && na <= 4 * LH_AK && n <= 1024 && h.hlds <= 160 * 1024 - 512 &&
+    const int force_wide = env_int("GRAVHMC_LONSYM_WIDE", 1) == 2;  // (2: the streamed form also where the register form applies)
+    if (!force_wide && env_int("GRAVHMC_LONSYM_HARMONIC", 1) != 0 && h.nf <= 64 && na <= 4 * LH_AK && n <= 1024 && h.hlds <= 160 * 1024 - 512 &&
         allow_dynamic_lds(reinterpret_cast<const void *>(lonsymh_fn(h.rw)), h.hlds) == hipSuccess) {
         h.hgrid = (int)((nc + rp - 1) / rp);
         TRY(dalloc(c, &h.tw, (size_t)n, false));
@@ -286,8 +299,58 @@ static int lonsym_build(gh_ctx *c)
     } else {
         (void)hipGetLastError();
     }
+    // The streamed harmonic form (lonsymw.hip.h) where the register form does not apply: no limit on the classes,
+    // n <= 1024.  GRAVHMC_LONSYM_WIDE=0: off (the direct correlations, or a refusal), 2: also where the register form applies.
+    h.wide = false;
+    if (!h.harm && wide_can && (env_int("GRAVHMC_LONSYM_HARMONIC", 1) != 0 || force_wide || !h.direct_ok)) {
+        h.wlds = lonsymw_lds_doubles((int)n, h.nf) * sizeof(double);
+        HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsymw_sweep_kernel), h.wlds));
+        h.wgrid = (int)std::min<int64_t>(nc, (int64_t)c->cus * 8);
+        // parts of the forward product: ~8 waves per SIMD over the chip, at least 8 cell rows per part
+        const int64_t waves_row = ((int64_t)na * h.nf + 63) / 64;
+        int64_t parts = std::max<int64_t>(1, ((int64_t)c->cus * 32 + waves_row - 1) / waves_row);
+        parts = std::min<int64_t>(parts, std::max<int64_t>(1, nc / 8));
+        parts = std::min<int64_t>(parts, 64);
+        h.wrows = (int)((nc + parts - 1) / parts);
+        h.wparts = (int)((nc + h.wrows - 1) / h.wrows);
+        TRY(dalloc(c, &h.tw, (size_t)n, false));
+        TRY(dalloc(c, &h.That, (size_t)nc * (size_t)na * (size_t)h.nf, false));
+        TRY(dalloc(c, &h.Rhat, (size_t)na * (size_t)h.nf));
+        TRY(dalloc(c, &h.Xhat, (size_t)nc * (size_t)h.nf));
+        TRY(dalloc(c, &h.Dpart, (size_t)h.wparts * (size_t)na * (size_t)h.nf));
+        lonsymh_twiddle_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>((int)n, h.tw);
+        lonsymh_table_kernel<<<dim3((unsigned)(nc * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        h.wide = true;
+    }
+    if (!h.harm && !h.wide && !h.direct_ok) return no(direct_why);
     h.on = true;
     return GH_OK;
+}
+
+static LonWideGeom lonsymw_geom(const gh_ctx *c)
+{
+    const LonSymHost &h = *c->ls;
+    LonWideGeom g;
+    g.n = h.n;
+    g.nf = h.nf;
+    g.na = h.na;
+    g.nc = h.nc;
+    g.parts = h.wparts;
+    g.rows_per_part = h.wrows;
+    g.That = h.That;
+    g.tw = h.tw;
+    g.Rhat = h.Rhat;
+    g.Xhat = h.Xhat;
+    g.Dpart = h.Dpart;
+    g.slot_first = h.slot_first;
+    g.n_xslots = h.n_xslots;
+    g.xslot = h.xslot;
+    g.xptr = h.xptr;
+    g.xobs = h.xobs;
+    g.N = c->N;
+    return g;
 }
 
 static LonHarmGeom lonsymh_geom(const gh_ctx *c)
@@ -315,9 +378,11 @@ static LonHarmGeom lonsymh_geom(const gh_ctx *c)
 static bool lonsym_harmonic(const gh_ctx *c) { return c->ls && c->ls->on && c->ls->harm; }
 
 static bool lonsym_on(const gh_ctx *c) { return c->ls && c->ls->on; }
+// (harmonic forms: the pass delivers ONE finished slab row and the classes' sums)
+static bool lonsym_one_row(const gh_ctx *c) { return c->ls && c->ls->on && (c->ls->harm || c->ls->wide); }
 static int lonsym_classes(const gh_ctx *c) { return c->ls->na; }
 // (workgroups of the pass = rows of the partial sums of p'p the trajectory code reads back)
-static int lonsym_grid(const gh_ctx *c) { return c->ls->harm ? c->ls->hgrid : c->ls->grid; }
+static int lonsym_grid(const gh_ctx *c) { return c->ls->harm ? c->ls->hgrid : c->ls->wide ? c->ls->wgrid : c->ls->grid; }
 static int64_t lonsym_table_bytes(const gh_ctx *c) { return c->ls->ldT * c->ls->nc * (int64_t)sizeof(double); }
 
 static int launch_lonsym(gh_ctx *c, SweepArgs &a)
@@ -342,6 +407,21 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
             } else {
                 lonsymh_post_kernel<<<dim3((unsigned)h.na), dim3(512), 0, c->stream>>>(g, h.hgrid, c->ld, a.slab, a.dsum);
             }
+        }
+        return GH_OK;
+    }
+    if (h.wide) {
+        // streamed harmonic form: R^ in front, the forward product over ranges of cell rows and the classes' inverse
+        // transforms behind the row-parallel pass
+        const LonWideGeom g = lonsymw_geom(c);
+        if (a.mode & SW_ADJ) lonsymw_rhat_kernel<<<dim3((unsigned)h.na), dim3(LW_THREADS), 0, c->stream>>>(g, a.r);
+        hipLaunchKernelGGL(lonsymw_sweep_kernel, dim3((unsigned)h.wgrid), dim3(LW_THREADS), h.wlds, c->stream, g, a,
+                           c->weighted ? c->wm : nullptr);
+        if (a.mode & SW_FWD) {
+            const int64_t tot = (int64_t)h.na * h.nf;
+            lonsymw_forward_kernel<<<dim3((unsigned)((tot + LW_THREADS - 1) / LW_THREADS), (unsigned)h.wparts), dim3(LW_THREADS), 0,
+                                     c->stream>>>(g);
+            lonsymw_post_kernel<<<dim3((unsigned)h.na), dim3(LW_THREADS), 0, c->stream>>>(g, c->ld, a.slab, a.dsum);
         }
         return GH_OK;
     }

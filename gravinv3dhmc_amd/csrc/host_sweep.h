@@ -224,6 +224,9 @@ static int build_near_table(gh_ctx *c)
 {
     c->mf_near_on = false;
     if (env_int("GRAVHMC_MF_NEAR", 1) == 0) return GH_OK;
+    // (the shift-invariant store evaluates entries for its table and the compressor's rows only: on a large grid the
+    // near-field table -- a pass over all N M pairs -- would cost more than it saves)
+    if (c->ls && (double)c->N * (double)c->M > 2e10) return GH_OK;
     const MfGeom g = mf_geom(c);
     int *count = nullptr;
     HIPCHK(c, hipMalloc((void **)&count, sizeof(int) * (size_t)c->M));
@@ -267,6 +270,7 @@ static bool shard_rows(const gh_ctx *c);                            // host_comm
 static int comm_allreduce(gh_ctx *c, double *buf, int64_t count);
 static bool lonsym_on(const gh_ctx *c);
 static bool lonsym_harmonic(const gh_ctx *c);
+static bool lonsym_one_row(const gh_ctx *c);
 static int lonsym_post_now(gh_ctx *c);
 static int lonsym_epilogue_check(gh_ctx *c);
 static int lonsym_classes(const gh_ctx *c);
@@ -538,7 +542,7 @@ static int launch_sweep(gh_ctx *c, SweepArgs &a)
             a.dsum = c->dsum;  // (the shift-invariant pass delivers the sums of its slab rows as well)
             c->dsum_live = true;
         }
-        if (lonsym_harmonic(c) && (a.mode & SW_FWD)) {
+        if (lonsym_one_row(c) && (a.mode & SW_FWD)) {
             // (harmonic form: ONE finished slab row; the sums come per class of observations)
             c->slab_live = 1;
             c->dsum_n = lonsym_classes(c);

@@ -1,0 +1,249 @@
+// The longitude-harmonic shift-invariant store for grids BEYOND the register form of lonsymh.hip.h (gfx950):
+// more than 126 longitudes (nf = n / 2 + 1 > 64) or more than 64 observation classes -- a 1-degree global grid has
+// n = 360, 181 classes, 1 800 cell rows: T^ is 0.94 GB, a cell row's slab of it (n_a nf complex = 524 KB) fits no
+// workgroup's registers, R^ (same size) no LDS.  Same arithmetic as lonsymh.hip.h
+//     S^[c][f]  = sum_a conj(T^[c][a][f]) R^[a][f]          adjoint
+//     D^[a][f]  = sum_c T^[c][a][f] X^[c][f]                forward
+// as STREAMING passes over T^ -- an HBM-bound kernel pair, every load coalesced along f:
+//   lonsymw_rhat_kernel     R^ of the residual (block = class), as lonsymh_rhat_kernel without the 64-frequency limit
+//   lonsymw_sweep_kernel    block = cell row: S^ from the row's slab of T^ (read once, R^ from L2), inverse
+//                           transform, gradient + leapfrog update (hmc.py:114-152), transform of the new positions ->
+//                           X^[c][f] (n_c nf complex in memory: 5 MB on the 1-degree grid)
+//   lonsymw_forward_kernel  thread = (a, f) -- the flattened index of a row of T^, no idle lanes --, sum over a RANGE of
+//                           cell rows: D^ partials [parts][n_a][nf]
+//   lonsymw_post_kernel     sum of the parts, inverse transform per class, scatter to the class's observations
+// T^ is read twice per leapfrog step (the forward product needs every row's X^, which needs every row's update): 2 x 0.94 GB
+// on the 1-degree grid = 0.24 ms at 8 TB/s, where the dense kernel of that grid (65 341 x 648 000 doubles = 339 GB) fits no
+// GPU.  No inter-workgroup waits: four plain launches per step.  Sums in a fixed order: reproducible bit for bit.
+// Reference arithmetic: gravmag/_tesseroid_numba.py:207-222 (cos(lon - lon')), gravmag/tesseroid.py:189-232,
+// inversion/potential.py:698,708, inversion/hmc.py:114-152; geometry family example/global/SetPMTS.txt.
+#pragma once
+#include "lonsymh.hip.h"
+
+namespace ghk {
+
+struct LonWideGeom {
+    int n, nf, na, nc, parts, rows_per_part;
+    const d2 *That;          // [nc][na][nf]
+    const d2 *tw;            // n
+    d2 *Rhat;                // [na][nf]
+    d2 *Xhat;                // [nc][nf]
+    d2 *Dpart;               // [parts][na][nf]
+    const int *slot_first;   // na * n
+    int n_xslots;
+    const int *xslot, *xptr, *xobs;
+    int64_t N;
+};
+
+constexpr int LW_THREADS = 256;
+constexpr int LW_NMAX = 1024;  // longitudes per cell row (the transforms' tables live in LDS)
+
+static inline size_t lonsymw_lds_doubles(int n, int nf)
+{
+    return 2 * (size_t)n + 8 * (size_t)nf + 2 * (size_t)nf + (size_t)n + 16;
+}
+
+__global__ void __launch_bounds__(LW_THREADS) lonsymw_rhat_kernel(LonWideGeom g, const double *__restrict__ r)
+{
+    __shared__ double row[LW_NMAX];
+    __shared__ d2 tws[LW_NMAX];
+    const int a = blockIdx.x, n = g.n, nf = g.nf, tid = threadIdx.x;
+    for (int m = tid; m < n; m += LW_THREADS) {
+        const int e = a * n + m, idx = g.slot_first[e];
+        double v = idx >= 0 ? r[idx] : 0.0;
+        for (int x = 0; x < g.n_xslots; ++x)
+            if (g.xslot[x] == e)
+                for (int q = g.xptr[x]; q < g.xptr[x + 1]; ++q) v += r[g.xobs[q]];
+        row[m] = v;
+        tws[m] = g.tw[m];
+    }
+    __syncthreads();
+    for (int f = tid; f < nf; f += LW_THREADS) g.Rhat[(int64_t)a * nf + f] = lh_dft_part(row, tws, 0, n, f, n);
+}
+
+// modes of SweepArgs as lonsym_sweep_kernel / lonsymh_sweep_kernel; SW_FWD leaves X^ of every cell row in g.Xhat
+__global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g, SweepArgs a, const double *__restrict__ wm)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = g.n, nf = g.nf, na = g.na;
+    const int mode = a.mode;
+    d2 *tws = reinterpret_cast<d2 *>(smem);                   // n
+    d2 *Gp = tws + n;                                         // 4 x nf: partial S^ of the waves' classes
+    d2 *Gh = Gp + 4 * nf;                                     // nf
+    double *xs = reinterpret_cast<double *>(Gh + nf);         // n
+    double *red = xs + n;
+    for (int e = tid; e < n; e += LW_THREADS) tws[e] = g.tw[e];
+    double pp = 0.0;
+    for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
+        __syncthreads();  // tws in place; the previous row is done with Gp / Gh / xs
+        if (mode & SW_ADJ) {
+            // S^[f] = sum_a conj(T^[a][f]) R^[a][f]: wave wv takes the classes wv, wv + 4, ..., eight of them in flight
+            const d2 *Tg = g.That + (int64_t)c * na * nf;
+            for (int f0 = 0; f0 < nf; f0 += 64) {
+                const int f = f0 + lane;
+                const bool fv = f < nf;
+                const int fc = fv ? f : nf - 1;
+                d2 acc = d2{0.0, 0.0};
+                int aa = wv;
+                for (; aa + 28 < na; aa += 32) {
+                    d2 t[8], rr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        t[u] = Tg[(int64_t)(aa + 4 * u) * nf + fc];
+                        rr[u] = g.Rhat[(int64_t)(aa + 4 * u) * nf + fc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc.x += t[u].x * rr[u].x + t[u].y * rr[u].y;
+                        acc.y += t[u].x * rr[u].y - t[u].y * rr[u].x;
+                    }
+                }
+                for (; aa < na; aa += 4) {
+                    const d2 t = Tg[(int64_t)aa * nf + fc], rr = g.Rhat[(int64_t)aa * nf + fc];
+                    acc.x += t.x * rr.x + t.y * rr.y;
+                    acc.y += t.x * rr.y - t.y * rr.x;
+                }
+                if (fv) Gp[wv * nf + f] = acc;
+            }
+            __syncthreads();
+            for (int f = tid; f < nf; f += LW_THREADS) {
+                d2 s = Gp[f];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    s.x += Gp[q * nf + f].x;
+                    s.y += Gp[q * nf + f].y;
+                }
+                // weight of the frequency in the inverse transform of a real sequence
+                const double wf = (f == 0 || (2 * f == n)) ? 1.0 : 2.0;
+                Gh[f] = d2{s.x * wf, s.y * wf};
+            }
+            __syncthreads();
+        }
+        // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}), gradient, update (hmc.py:114-152)
+        for (int k = tid; k < n; k += LW_THREADS) {
+            const int64_t j = (int64_t)c * n + k;
+            const double wj = wm ? wm[j] : 1.0;
+            const double iwj = (wj != 0.0) ? 1.0 / wj : 1.0;
+            double xj = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+            if (mode & SW_ADJ) {
+                const double s = lh_idft_part(Gh, tws, 0, nf, k, n);
+                const double t = (s / (double)n) * iwj;
+                const double grad = 2.0 * t + (a.greg ? a.greg[j] : 0.0);
+                if (mode & SW_GOUT) a.g_out[j] = grad;
+                const double pin = (mode & (SW_PFIN | SW_UPD)) ? a.p_in[j] : 0.0;
+                if (mode & SW_PFIN) {
+                    const double pf = pin - a.c_p * grad;
+                    pp += pf * pf;
+                    if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+                }
+                if (mode & SW_UPD) {
+                    const double psrc = (mode & SW_SPEC) ? a.pn_in[j] : pin;
+                    const double hi = a.high[j], lo = a.low[j];
+                    double pj = psrc - a.c_u * grad;
+                    xj = xj + a.dt * pj;
+                    if (xj > hi) {
+                        xj = hi;
+                        pj = -pj;
+                    } else if (xj < lo) {
+                        xj = lo;
+                        pj = -pj;
+                    }
+                    a.p_out[j] = pj;
+                    a.x_out[j] = xj;
+                }
+            }
+            if (mode & SW_FWD) xs[k] = xj * iwj;
+        }
+        if (mode & SW_FWD) {
+            __syncthreads();
+            for (int f = tid; f < nf; f += LW_THREADS) g.Xhat[(int64_t)c * nf + f] = lh_dft_part(xs, tws, 0, n, f, n);
+        }
+    }
+    if (mode & SW_PFIN) {
+        __syncthreads();
+        const double t = block_allreduce_sum(pp, red, LW_THREADS / 64);
+        if (tid == 0) a.pp_part[blockIdx.x] = t;
+    }
+}
+
+// D^ partial of the cell rows [part * rows_per_part, ...): thread e = a * nf + f (one complex of a row of T^)
+__global__ void __launch_bounds__(LW_THREADS) lonsymw_forward_kernel(LonWideGeom g)
+{
+    const int nf = g.nf;
+    const int64_t tot = (int64_t)g.na * nf;
+    const int64_t e = (int64_t)blockIdx.x * LW_THREADS + threadIdx.x;
+    const bool ev = e < tot;
+    const int64_t ec = ev ? e : tot - 1;
+    const int f = (int)(ec % nf);
+    const int c0 = blockIdx.y * g.rows_per_part;
+    const int c1 = (c0 + g.rows_per_part < g.nc) ? c0 + g.rows_per_part : g.nc;
+    d2 acc = d2{0.0, 0.0};
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        d2 t[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            t[u] = g.That[(int64_t)(c + u) * tot + ec];
+            x[u] = g.Xhat[(int64_t)(c + u) * nf + f];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x += t[u].x * x[u].x - t[u].y * x[u].y;
+            acc.y += t[u].x * x[u].y + t[u].y * x[u].x;
+        }
+    }
+    for (; c < c1; ++c) {
+        const d2 t = g.That[(int64_t)c * tot + ec], x = g.Xhat[(int64_t)c * nf + f];
+        acc.x += t.x * x.x - t.y * x.y;
+        acc.y += t.x * x.y + t.y * x.x;
+    }
+    if (ev) g.Dpart[(int64_t)blockIdx.y * tot + e] = acc;
+}
+
+// block = class a: sum of the parts, inverse transform, scatter to the class's observations (slab row 0), the
+// class's sum of predicted data (dsum[a])
+__global__ void __launch_bounds__(LW_THREADS) lonsymw_post_kernel(LonWideGeom g, int64_t ld, double *__restrict__ out,
+                                                                  double *__restrict__ dsum)
+{
+    __shared__ d2 Dh[LW_NMAX / 2 + 1];
+    __shared__ d2 tws[LW_NMAX];
+    __shared__ double red[8];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const int n = g.n, nf = g.nf;
+    const int64_t tot = (int64_t)g.na * nf;
+    for (int m = tid; m < n; m += LW_THREADS) tws[m] = g.tw[m];
+    for (int f = tid; f < nf; f += LW_THREADS) {
+        d2 s = d2{0.0, 0.0};
+        const d2 *src = g.Dpart + (int64_t)a * nf + f;
+        for (int p = 0; p < g.parts; ++p) {
+            const d2 v = src[(int64_t)p * tot];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        const double wf = (f == 0 || (2 * f == n)) ? 1.0 : 2.0;
+        Dh[f] = d2{s.x * wf, s.y * wf};
+    }
+    __syncthreads();
+    double rs = 0.0;
+    for (int m = tid; m < n; m += LW_THREADS) {
+        const double d = lh_idft_part(Dh, tws, 0, nf, m, n) / (double)n;
+        const int e = a * n + m, i0 = g.slot_first[e];
+        if (i0 >= 0) {
+            out[i0] = d;
+            rs += d;
+            for (int x = 0; x < g.n_xslots; ++x)
+                if (g.xslot[x] == e)
+                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) {
+                        out[g.xobs[qq]] = d;
+                        rs += d;
+                    }
+        }
+    }
+    if (a == 0)
+        for (int64_t i = g.N + tid; i < ld; i += LW_THREADS) out[i] = 0.0;  // (the padding rows of the slab row)
+    const double t = block_allreduce_sum(rs, red, LW_THREADS / 64);
+    if (tid == 0 && dsum) dsum[a] = t;
+}
+
+}  // namespace ghk

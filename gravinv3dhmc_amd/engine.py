@@ -118,10 +118,12 @@ class Engine(object):
         return {"n_lon": n.value, "n_classes": na.value, "n_rows": nc.value, "table_bytes": tb.value}
 
     def shift_invariant_harmonic(self):
-        """The store in the longitude-harmonic domain (csrc/lonsymh.hip.h): on, frequencies, bytes of T^, workgroups."""
+        """The store in the longitude-harmonic domain: on, form ("registers": csrc/lonsymh.hip.h, "streamed":
+        csrc/lonsymw.hip.h for grids beyond 126 longitudes / 64 observation classes), frequencies, bytes of T^, workgroups."""
         on, nf, tb, wg = C.c_int(0), C.c_int(0), C.c_int64(0), C.c_int(0)
         self._chk(self._lib.gh_shift_invariant_harmonic(self._h, C.byref(on), C.byref(nf), C.byref(tb), C.byref(wg)))
-        return {"on": bool(on.value), "n_freq": nf.value, "table_bytes": tb.value, "workgroups": wg.value}
+        return {"on": bool(on.value), "form": {0: None, 1: "registers", 2: "streamed"}[on.value], "n_freq": nf.value,
+                "table_bytes": tb.value, "workgroups": wg.value}
 
     def matrix_free_stats(self):
         """Entries / GLQ leaves evaluated and launches of the fused matrix-free pass since

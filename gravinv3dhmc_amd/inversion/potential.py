@@ -128,9 +128,8 @@ class GravMagModule(object):
         if matrix_free:
             eng.set_matrix_free(True)      # (with wavelet: the compressor's rows are evaluated, never stored)
         if shift_invariant:
-            if wavelet or not spherical:
-                raise NotImplementedError("the shift-invariant store is for spherical (tesseroid) models "
-                                          "without wavelet compression")
+            if not spherical:
+                raise NotImplementedError("the shift-invariant store is for spherical (tesseroid) models")
             eng.set_shift_invariant(True)
         self.matrix_free = bool(matrix_free or shift_invariant)
         eng.set_obs(self.lonobs, self.latobs, self.heightobs)

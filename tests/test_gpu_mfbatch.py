@@ -222,14 +222,17 @@ def _global_model(G, dlon, dlat, dr, obs_h, nlat_obs_step=None):
 
 
 @pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size", "c4_full_size_direct_correlations",
-                                  "c4_full_size_one_launch_epilogue"])
+                                  "c4_full_size_one_launch_epilogue", "coarse_odd_sizes_streamed", "c4_full_size_streamed",
+                                  "lon180_streamed", "classes91_streamed"])
 def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
     """gh_set_shift_invariant: K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] for regular spherical grids
     (example/global/main_global.py:25-28; BASELINE configs[3]'s geometry) against the dense engine on the
     same problem: column norms, unweighted forward (the reference's gz), adjoint, potential + gradient
     for a cell-local and a stencil regulariser, and a chain with identical decisions.  coarse: 36 longitudes
     (not a multiple of 8 per block boundary: 36 = 4.5 blocks), duplicated +-180 observations, shuffled
-    observation order, two observation heights (classes = (lat, h) pairs)."""
+    observation order, two observation heights (classes = (lat, h) pairs).  *_streamed: the harmonic form as
+    streaming passes over T^ (lonsymw.hip.h) -- forced on the two geometries above, and chosen by the library
+    where the register form does not apply: 180 longitudes (91 frequencies > 64) and 91 observation classes (> 64)."""
     rng = np.random.default_rng(12)
     # (default: the longitude-harmonic form with its three-launch epilogue; the direct correlations of round 3 and the
     # one-launch epilogue -- built, not the default, DESIGN 4.9 -- stay covered)
@@ -237,11 +240,19 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
         monkeypatch.setenv("GRAVHMC_LONSYM_HARMONIC", "0")
     if case.endswith("one_launch_epilogue"):
         monkeypatch.setenv("GRAVHMC_LONSYM_FUSED", "1")
-    if case == "coarse_odd_sizes":
+    if case in ("coarse_odd_sizes_streamed", "c4_full_size_streamed"):
+        monkeypatch.setenv("GRAVHMC_LONSYM_WIDE", "2")
+    if case.startswith("coarse_odd_sizes"):
         mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
         h[::3] = 45000.0
         perm = rng.permutation(lon.size)
         lon, lat, h = lon[perm], lat[perm], h[perm]
+        tol = 1e-10
+    elif case == "lon180_streamed":
+        mesh, lon, lat, h = _global_model(G, 2.0, 3.0, -1500000, 5000.0)       # 180 longitudes, 61 classes, 120 cell rows
+        tol = 1e-10
+    elif case == "classes91_streamed":
+        mesh, lon, lat, h = _global_model(G, 4.0, 2.0, -1500000, 5000.0)       # 90 longitudes, 91 classes, 180 cell rows
         tol = 1e-10
     else:
         mesh, lon, lat, h = _global_model(G, 3.0, 3.0, -300000, 5000.0)
@@ -260,6 +271,8 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
     d, t = engs["dense"], engs["table"]
     info = t.shift_invariant_info()
     assert info["n_lon"] == mesh.shape[2] and info["n_rows"] == mesh.shape[0] * mesh.shape[1]
+    form = t.shift_invariant_harmonic()["form"]
+    assert form == ("streamed" if case.endswith("_streamed") else None if case.endswith("direct_correlations") else "registers"), form
     assert info["table_bytes"] < N * M * 8 / 10
     dtrue = d.forward(rho)
     e_fwd = relmax(t.forward(rho), dtrue)
@@ -276,8 +289,8 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
             e.set_reg(reg, 0.05, 0.01, mesh.shape, 0.001 * wd)
         a, b = t.misfit_and_grad(x), d.misfit_and_grad(x)
         worst = max(worst, abs(a[0] - b[0]) / abs(b[0]), relmax(a[1], b[1]), relmax(a[2], b[2]))
-    print("shift-invariant store [%s]: %r; vs dense: forward %.2e weights %.2e adjoint %.2e potential/gradient %.2e"
-          % (case, info, e_fwd, e_w, e_adj, worst))
+    print("shift-invariant store [%s, harmonic form %s]: %r; vs dense: forward %.2e weights %.2e adjoint %.2e potential/gradient %.2e"
+          % (case, form, info, e_fwd, e_w, e_adj, worst))
     assert e_fwd < tol and e_w < tol and e_adj < tol and worst < tol
     trajs = [(int(rng.integers(2, 7)), rng.normal(size=M) * 0.001, float(rng.uniform())) for _ in range(5)]
     outs = {}
@@ -443,3 +456,58 @@ def test_single_chain_matrix_free_on_teams_and_its_time_out(G, monkeypatch):
     print("single-chain matrix-free on teams %r vs column-per-workgroup pass / dense engine / after a time-out: %.2e"
           % (st_t, worst))
     assert worst < 1e-10
+
+
+@pytest.mark.parametrize("wavelet", ["3D", "1D"])
+def test_wavelet_forward_on_the_shift_invariant_store(G, wavelet):
+    """wavelet='1D'/'3D' together with shift_invariant=True (refused until round 4): the compressor's rows are
+    evaluated by the matrix-free row kernel (the store never holds G), the forward runs on the CSR operator, the
+    gradient on the table's adjoint (potential.py:693-708: compressed forward, exact adjoint).  Against the same
+    module with the stored kernel: the same CSR, potential, gradient and chain; batched chains are refused."""
+    rng = np.random.default_rng(23)
+    mrange, mspacing = (-180, 180, -90, 90, 0, -3000000), (-1000000, 15, 10)
+    lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 10.0), np.arange(-90, 91, 15.0), indexing="ij")]
+    h = np.full_like(lon, 30000.0)
+    mesh = G.mesher.TesseroidMesh(mrange, mspacing)
+    M, N = mesh.size, lon.size
+    probe = G.GravMagModule(np.zeros(N), mrange, mspacing, (lon, lat, h), coordinate="spherical", verbose=False)
+    rho = np.zeros(mesh.shape)
+    rho[1:, 4:8, 10:20] = 0.3
+    dobs = probe._engine.forward(probe.Wm.diagonal() * rho.ravel()) * (1.0 + 0.01 * rng.normal(size=N))
+    probe._engine.close()
+    mods = {}
+    for tag, si in (("stored", False), ("table", True)):
+        mods[tag] = G.GravMagModule(dobs, mrange, mspacing, (lon, lat, h), coordinate="spherical", verbose=False,
+                                    wavelet=wavelet, shift_invariant=si)
+    a, b = mods["table"], mods["stored"]
+    assert a._engine.shift_invariant_info()["n_lon"] == mesh.shape[2]
+    ca, cb = a.Awcp, b.Awcp
+    assert ca.shape == cb.shape and ca.nnz == cb.nnz and np.array_equal(ca.indices, cb.indices)
+    assert relmax(ca.data, cb.data) < 1e-11
+    wm = b.Wm.diagonal()
+    mwapr = 0.001 * wm
+    worst = 0.0
+    for reg in ("MS", "TV"):
+        x = rng.uniform(0, 0.8, M) * wm
+        ra = a.misfit_and_grad(x, mwapr, None, None, "mandatory", 1000, 0.7, regulization=reg, beta=0.001)
+        rb = b.misfit_and_grad(x, mwapr, None, None, "mandatory", 1000, 0.7, regulization=reg, beta=0.001)
+        worst = max(worst, abs(ra[0] - rb[0]) / abs(rb[0]), relmax(ra[1], rb[1]), relmax(ra[2], rb[2]))
+    assert worst < 1e-10, worst
+    trajs = [(int(rng.integers(1, 9)), rng.normal(size=M) * 0.001, float(rng.uniform())) for _ in range(6)]
+    outs = []
+    for m in (a, b):
+        e = m._engine
+        e.set_reg("MS", 0.05, 0.001, mesh.shape, mwapr)
+        e.chain_init(0.001 * wm, 0.0 * wm, 0.8 * wm)
+        res = []
+        e.run_chain(iter(trajs), 0.005, lambda L, acc, o, x, res=res: res.append((acc, o.copy())))
+        outs.append((res, e.chain_get_x()))
+    for (a1, o1), (a2, o2) in zip(outs[0][0], outs[1][0]):
+        assert a1 == a2 and relmax(o1, o2) < 1e-10
+    assert relmax(outs[0][1], outs[1][1]) < 1e-10
+    print("wavelet %s forward on the shift-invariant store vs the stored kernel: nnz %d, potential/gradient %.2e, chain of %d "
+          "trajectories identical decisions" % (wavelet, ca.nnz, worst, len(trajs)))
+    with pytest.raises(NotImplementedError, match="wavelet"):
+        a._engine.batch_init(np.stack([0.001 * wm, 0.002 * wm]), 0.0 * wm, 0.8 * wm)
+    for m in mods.values():
+        m._engine.close()

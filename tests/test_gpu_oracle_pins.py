@@ -103,14 +103,16 @@ def test_matrix_free_batch_and_team_chain_against_oracle_trajectories(G, orc, mo
         e.close()
 
 
-@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size"])
-def test_shift_invariant_store_against_the_oracle(G, orc, case):
+@pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size", "coarse_odd_sizes_streamed", "c4_full_size_streamed"])
+def test_shift_invariant_store_against_the_oracle(G, orc, case, monkeypatch):
     """lonsym_sweep_kernel's table against the oracle's tesseroid kernel itself.  coarse: the whole dense K
     (forward, weights, adjoint, potential + gradient for a cell-local and a stencil regulariser, a chain
     against oracle.Problem.leapfrog).  C4 at full size: 68 oracle rows x 72000 cells (64 random
     observations, two polar rows, two more) against K[i, :] = wm * (Aw^T e_i) read through the table."""
     rng = np.random.default_rng(13)
-    if case == "coarse_odd_sizes":
+    if case.endswith("_streamed"):      # the harmonic form as streaming passes over T^ (lonsymw.hip.h), forced
+        monkeypatch.setenv("GRAVHMC_LONSYM_WIDE", "2")
+    if case.startswith("coarse_odd_sizes"):
         mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
         h[::3] = 45000.0
         perm = rng.permutation(lon.size)
@@ -125,6 +127,7 @@ def test_shift_invariant_store_against_the_oracle(G, orc, case):
     t.set_cells(bounds, 1, 1.6)
     t.build_G()
     assert t.shift_invariant_info()["n_lon"] == mesh.shape[2]
+    assert t.shift_invariant_harmonic()["form"] == ("streamed" if case.endswith("_streamed") else "registers")
     if case.startswith("c4_full_size"):
         wt = t.weight(0.5)
         rows = np.r_[rng.choice(N, 64, replace=False), [0, 60, 60 * 61 + 30, N - 1]]
@@ -545,4 +548,78 @@ def test_shift_invariant_persistent_pass_gives_up_cleanly(G, orc, monkeypatch):
         assert relmax(t.chain_get_x(), xo) < 1e-10
         st = t.shift_invariant_resident_stats()
         assert st["timeouts"] == (0 if call == 0 else 1) and st["launches"] == (1 if call < 2 else 2), (call, st)
+    t.close()
+
+
+def test_one_degree_global_grid_on_the_streamed_harmonic_store(G, orc):
+    """A 1-degree global grid (example/global/SetPMTS.txt's geometry family at 1 degree: 360 x 180 x 10 = 648 000 cells,
+    361 x 181 = 65 341 observations; refused by every form of the store until round 4): the dense kernel would be 339 GB,
+    the store is T^ = 0.94 GB read twice per leapfrog step (lonsymw.hip.h).  Nothing dense exists to compare with at
+    this size: 6 ORACLE rows x 648 000 cells (two polar, four random observations) against K[i, :] = wm * (Aw^T e_i),
+    4 oracle columns x 65 341 observations against forward(e_j) and the weights, <A x, r> = <x, A^T r>, linearity of the
+    forward, and a chain whose potential the host re-evaluates from forward() at the final state."""
+    rng = np.random.default_rng(31)
+    mesh, lon, lat, h = _global_model(G, 1.0, 1.0, -300000, 5000.0)
+    N, M = lon.size, mesh.size
+    assert (N, M) == (65341, 648000)
+    bounds = mesh.cell_bounds()
+    t = G.Engine(N, M)
+    t.set_shift_invariant(True)
+    t.set_obs(lon, lat, h)
+    t.set_cells(bounds, 1, 1.6)
+    t.build_G()
+    info, hinfo = t.shift_invariant_info(), t.shift_invariant_harmonic()
+    assert info["n_lon"] == 360 and info["n_classes"] == 181 and info["n_rows"] == 1800
+    assert hinfo["form"] == "streamed" and hinfo["n_freq"] == 181 and hinfo["table_bytes"] == 1800 * 181 * 181 * 16
+    cols = np.r_[0, 359, 324000 + 180, M - 1]
+    Kc = orc.tess_gz_kernel(lon, lat, h, bounds[cols])
+    e_col = 0.0
+    for q, j in enumerate(cols):
+        ej = np.zeros(M)
+        ej[j] = 1.0
+        e_col = max(e_col, float(np.abs(t.forward(ej) - Kc[:, q]).max() / np.abs(Kc[:, q]).max()))
+    wt = t.weight(0.5)
+    e_w = relmax(wt[cols], np.sqrt((Kc ** 2).sum(0)))
+    rows = np.r_[0, 180, rng.choice(N, 4, replace=False)]
+    Ko = orc.tess_gz_kernel(lon[rows], lat[rows], h[rows], bounds)
+    e_row = 0.0
+    for q, i in enumerate(rows):
+        ei = np.zeros(N)
+        ei[i] = 1.0
+        Ki = t.adjoint(ei) * wt
+        e_row = max(e_row, float(np.abs(Ki - Ko[q]).max() / np.abs(Ko[q]).max()))
+    x1, x2, r = rng.uniform(0, 0.5, M) * wt, rng.uniform(0, 0.5, M) * wt, rng.normal(size=N)
+    f1, f2 = t.forward(x1), t.forward(x2)
+    e_lin = relmax(t.forward(x1 + 2.0 * x2), f1 + 2.0 * f2)
+    e_adj = abs(f1 @ r - x1 @ t.adjoint(r)) / (np.linalg.norm(f1) * np.linalg.norm(r))
+    print("1-degree global grid on the streamed harmonic store (%r, %r): 6 ORACLE rows x 648000 cells %.2e, 4 oracle columns %.2e, "
+          "weights %.2e, linearity %.2e, adjointness %.2e" % (info, hinfo, e_row, e_col, e_w, e_lin, e_adj))
+    assert e_row < 1e-10 and e_col < 1e-10 and e_w < 1e-11 and e_lin < 1e-12 and e_adj < 1e-13
+    # a chain: the potential of the final state against a host evaluation from forward()
+    rho = np.zeros(mesh.shape)
+    rho[2:5, 60:90, 100:160] = 0.3
+    dtrue = t.forward(rho.ravel() * wt)
+    dobs = dtrue + 0.02 * np.abs(dtrue).max() * rng.normal(size=N)
+    t.set_data(dobs)
+    t.set_reg("Damping", 0.05, 0.01, mesh.shape, 0.001 * wt)
+    t.chain_init(0.001 * wt, 0.0 * wt, 0.8 * wt)
+    n_acc = 0
+    import time
+    t0 = time.perf_counter()
+    steps = 0
+    for _ in range(4):
+        L = int(rng.integers(3, 8))
+        acc, o = t.chain_trajectory(rng.normal(size=M) * 0.001, 0.002, L, float(rng.uniform()))
+        n_acc += int(acc)
+        steps += L
+    dt_s = time.perf_counter() - t0
+    x = t.chain_get_x()
+    U = t.misfit_and_grad(x)
+    d = t.forward(x)
+    res = (d - d.mean()) - (dobs - dobs.mean())
+    phi = float(res @ res)
+    assert abs(U[3] - phi) < 1e-10 * phi, (U[3], phi)
+    assert relmax(U[1], 2.0 * t.adjoint(res) + 0.05 * 2.0 * (x - 0.001 * wt)) < 1e-10
+    print("   chain of 4 trajectories (%d leapfrog steps, %d accepted) in %.3f s incl. the host's momentum uploads" % (steps, n_acc, dt_s))
+    assert n_acc > 0
     t.close()
