@@ -124,6 +124,9 @@ EXTRA = {
     # + 123 MB of the dense compressed-forward form -- beyond LDS + registers: resident kernel with
     # the columns that do not fit streamed from L2 / Infinity Cache
     "x2_ratiogrid_900x17100_wavelet3d": dict(kind=0, reg="MS", alpha=1.0, beta=0.001, dt=0.01, hi=0.4, wavelet=3),
+    # C4's geometry family (example/global/SetPMTS.txt) at 1 degree: 360 x 180 x 10 tesseroids (M = 648 000), 361 x 181
+    # observations (N = 65 341) -- a dense kernel of 339 GB; with --shift-invariant the streamed harmonic store, 0.94 GB
+    "x3_global_one_degree": dict(kind=1, reg="Damping", alpha=0.05, beta=0.01, dt=0.002, hi=0.8, wavelet=0),
 }
 
 
@@ -154,6 +157,13 @@ def make_extra(name):
         obs = (xp, yp, np.zeros_like(xp))
         rho = np.zeros(mesh.shape)
         rho[10:30, 80:120, 80:120] = 1.0
+    elif name == "x3_global_one_degree":
+        mesh = mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 1, 1))
+        lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 1.0), np.arange(-90, 91, 1.0),
+                                                   indexing="ij")]
+        obs = (lon, lat, np.full_like(lon, 5000.0))
+        rho = np.zeros(mesh.shape)
+        rho[2:5, 60:90, 100:160] = 0.3
     else:
         mesh = mesher.TesseroidMesh((-180, 180, -90, 90, 0, -3000000), (-300000, 3, 3))
         lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 3.0), np.arange(-90, 91, 3.0),
@@ -315,6 +325,8 @@ EXTRA_RUNS = [
                                                       "--chains-per-gpu", "8", "--steps", "2000", "--warmup", "200"]),
     ("c4_global_tesseroid_matrix_free_8_chains", ["--workload", "c4_global_tesseroid", "--matrix-free",
                                                   "--chains-per-gpu", "8", "--steps", "100", "--warmup", "20"]),
+    ("x3_global_one_degree_shift_invariant", ["--workload", "x3_global_one_degree", "--shift-invariant", "--steps", "2000",
+                                              "--warmup", "200"]),
     ("c5_share_of_one_gpu_of_8", ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "8", "--steps", "40",
                                   "--warmup", "10"]),
     # (the same 96 GB as the row block one of 8 GPUs holds: 5000 observations x all 2.4e6 cells, two reads per step)
@@ -605,6 +617,7 @@ def config_values(line):
              "c4_global_tesseroid_shift_invariant": "c4_si",
              "c4_global_tesseroid_shift_invariant_8_chains": "c4_si8",
              "c4_global_tesseroid_matrix_free_8_chains": "c4_mf8", "c5_share_of_one_gpu_of_8": "c5_share",
+             "x3_global_one_degree_shift_invariant": "g1deg_si",
              "c5_share_row_blocks": "c5_rows"}
     for tag, d in (line.get("extra") or {}).items():
         if tag in short:
@@ -964,19 +977,29 @@ def main():
             if hm["on"]:
                 # harmonic domain: n_rows x n_classes x n_freq complex multiply-adds per product; what the pass
                 # must move is the complex table T^ (beyond L2: Infinity Cache / HBM), once per step
-                byts = float(hm["table_bytes"])
+                streamed = hm.get("form") == "streamed"
+                # (the streamed form for large grids, csrc/lonsymw.hip.h, reads T^ twice: row-parallel adjoint, forward product)
+                byts = float(hm["table_bytes"]) * (2.0 if streamed else 1.0)
                 ach = byts * prof["sweeps"] / secs / 1e9 if secs > 0 else None
                 line["roofline"] = {
                     "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                     "frac": ach / 8000.0 if ach else None, "traffic": None,
-                    "kernel": "lonsymh_rhat_kernel + lonsymh_sweep_kernel + lonsymh_post_kernel (longitude-harmonic "
+                    "kernel": ("lonsymw_rhat_kernel + lonsymw_sweep_kernel + lonsymw_forward_kernel + lonsymw_post_kernel "
+                               "(longitude-harmonic domain, STREAMED: %d frequencies x %d classes x %d cell rows, complex "
+                               "table T^ of %.1f MB read twice per step -- adjoint per cell row, forward product per "
+                               "(class, frequency) over ranges of rows; transforms of length %d; the dense kernel of this "
+                               "grid would be %.0f GB)"
+                               % (hm["n_freq"], si["n_classes"], si["n_rows"], hm["table_bytes"] / 1e6, si["n_lon"],
+                                  N * M * 8 / 1e9)) if streamed else
+                              "lonsymh_rhat_kernel + lonsymh_sweep_kernel + lonsymh_post_kernel (longitude-harmonic "
                               "domain: %d frequencies x %d classes x %d cell rows, complex table T^ of %.1f MB read once "
                               "per step by %d workgroups; transforms of length %d inside the cell row's workgroup)"
                               % (hm["n_freq"], si["n_classes"], si["n_rows"], byts / 1e6, hm["workgroups"], si["n_lon"]),
                     "launches": prof["sweeps"], "avg_ms": sweep_ms, "table": dict(si, harmonic=hm),
                     "algorithmic_bytes_per_launch": byts,
-                    "byte_model": "the complex table T^[row][class][frequency] (16 bytes per entry), read once per pass",
-                    "note": "three dependent, latency-bound launches per pass (time between the first one's start and "
+                    "byte_model": "the complex table T^[row][class][frequency] (16 bytes per entry), read %s per pass"
+                                  % ("twice" if streamed else "once"),
+                    "note": ("four plain launches per pass, no inter-workgroup waits" if streamed else "three dependent, latency-bound launches per pass") + "  (time between the first one's start and "
                             "the last one's end)" + ("; %d chains on their own streams: the passes overlap, their "
                                                      "durations are summed" % CPG if CPG > 1 else ""),
                     "dense_G_equiv_GBps": N * M * 8 / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else None}

@@ -7,7 +7,7 @@ struct LonSymHost {
     int n = 0, na = 0, nc = 0, SW = 0, AG = 0, KB = 0;
     int64_t ldT = 0;
     double *T = nullptr;
-    int *slot_first = nullptr, *xslot = nullptr, *xptr = nullptr, *xobs = nullptr, *lds_of = nullptr, *a_of = nullptr,
+    int *slot_first = nullptr, *slot_x = nullptr, *xslot = nullptr, *xptr = nullptr, *xobs = nullptr, *lds_of = nullptr, *a_of = nullptr,
         *m_of = nullptr;
     int n_xslots = 0, max_extra = 0;  // max_extra: most observations a slot holds beyond its first
     long long *dbg = nullptr;  // GRAVHMC_LONSYM_TIMING: per-phase clocks of one workgroup
@@ -17,6 +17,7 @@ struct LonSymHost {
     ghk::d2 *That = nullptr, *tw = nullptr, *Rhat = nullptr, *Dpart = nullptr;
     // the harmonic store as streaming passes over T^ (lonsymw.hip.h): grids beyond the register form's limits
     bool wide = false, direct_ok = false;
+    int nfp = 0, wbreak = 0;               // pitch of a row of T^ / R^ / D^ in the streamed form (complex entries)
     int wgrid = 0, wparts = 0, wrows = 0;  // workgroups of the sweep; parts of the forward product, cell rows per part
     ghk::d2 *Xhat = nullptr;
     size_t wlds = 0;
@@ -244,6 +245,8 @@ static int lonsym_build(gh_ctx *c)
             }
     }
     h.n_xslots = (int)xslot.size();
+    std::vector<int> slotx((size_t)Np, -1);
+    for (size_t x = 0; x < xslot.size(); ++x) slotx[(size_t)xslot[x]] = (int)x;
     if (xslot.empty()) xslot.push_back(0);
     if (xobs.empty()) xobs.push_back(0);
     for (int64_t i = 0; i < N; ++i) ldsof[(size_t)i] = a_of[(size_t)i] * h.SW + m_of[(size_t)i];
@@ -253,6 +256,7 @@ static int lonsym_build(gh_ctx *c)
         return GH_OK;
     };
     TRY(up(&h.slot_first, sfirst));
+    TRY(up(&h.slot_x, slotx));
     TRY(up(&h.xslot, xslot));
     TRY(up(&h.xptr, xptr));
     TRY(up(&h.xobs, xobs));
@@ -283,7 +287,7 @@ static int lonsym_build(gh_ctx *c)
         TRY(dalloc(c, &h.Rhat, (size_t)na * (size_t)h.nf));
         TRY(dalloc(c, &h.Dpart, (size_t)h.hgrid * (size_t)na * (size_t)h.nf));
         lonsymh_twiddle_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>((int)n, h.tw);
-        lonsymh_table_kernel<<<dim3((unsigned)(nc * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That);
+        lonsymh_table_kernel<<<dim3((unsigned)(nc * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That, h.nf);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         h.harm = true;
@@ -303,23 +307,27 @@ static int lonsym_build(gh_ctx *c)
     // n <= 1024.  GRAVHMC_LONSYM_WIDE=0: off (the direct correlations, or a refusal), 2: also where the register form applies.
     h.wide = false;
     if (!h.harm && wide_can && (env_int("GRAVHMC_LONSYM_HARMONIC", 1) != 0 || force_wide || !h.direct_ok)) {
-        h.wlds = lonsymw_lds_doubles((int)n, h.nf) * sizeof(double);
+        // (rows of T^ start on 128-byte lines: a wave's 1 KB request then touches 8 of them, not 9)
+        h.nfp = (h.nf + 7) / 8 * 8;
+        // (GRAVHMC_LW_LDS_PAD: extra LDS per workgroup in KB -- a diagnostic that lowers the workgroups per CU)
+        h.wlds = lonsymw_lds_doubles((int)n, h.nf) * sizeof(double) + (size_t)env_int("GRAVHMC_LW_LDS_PAD", 0) * 1024;
         HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsymw_sweep_kernel), h.wlds));
         h.wgrid = (int)std::min<int64_t>(nc, (int64_t)c->cus * 8);
         // parts of the forward product: ~8 waves per SIMD over the chip, at least 8 cell rows per part
-        const int64_t waves_row = ((int64_t)na * h.nf + 63) / 64;
-        int64_t parts = std::max<int64_t>(1, ((int64_t)c->cus * 32 + waves_row - 1) / waves_row);
+        const int64_t waves_row = ((int64_t)na * h.nfp + 63) / 64;
+        int64_t parts = std::max<int64_t>(1, ((int64_t)c->cus * env_int("GRAVHMC_LW_WAVES_PER_CU", 64) + waves_row - 1) / waves_row);
         parts = std::min<int64_t>(parts, std::max<int64_t>(1, nc / 8));
         parts = std::min<int64_t>(parts, 64);
         h.wrows = (int)((nc + parts - 1) / parts);
         h.wparts = (int)((nc + h.wrows - 1) / h.wrows);
+        h.wbreak = env_int("GRAVHMC_LW_BREAK", 0);  // (diagnostic: phases of the sweep switched off -- wrong results, timing only)
         TRY(dalloc(c, &h.tw, (size_t)n, false));
-        TRY(dalloc(c, &h.That, (size_t)nc * (size_t)na * (size_t)h.nf, false));
-        TRY(dalloc(c, &h.Rhat, (size_t)na * (size_t)h.nf));
+        TRY(dalloc(c, &h.That, (size_t)nc * (size_t)na * (size_t)h.nfp, false));
+        TRY(dalloc(c, &h.Rhat, (size_t)na * (size_t)h.nfp));
         TRY(dalloc(c, &h.Xhat, (size_t)nc * (size_t)h.nf));
-        TRY(dalloc(c, &h.Dpart, (size_t)h.wparts * (size_t)na * (size_t)h.nf));
+        TRY(dalloc(c, &h.Dpart, (size_t)h.wparts * (size_t)na * (size_t)h.nfp));
         lonsymh_twiddle_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>((int)n, h.tw);
-        lonsymh_table_kernel<<<dim3((unsigned)(nc * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That);
+        lonsymh_table_kernel<<<dim3((unsigned)(nc * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That, h.nfp);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         h.wide = true;
@@ -337,6 +345,8 @@ static LonWideGeom lonsymw_geom(const gh_ctx *c)
     g.nf = h.nf;
     g.na = h.na;
     g.nc = h.nc;
+    g.nfp = h.nfp;
+    g.brk = h.wbreak;
     g.parts = h.wparts;
     g.rows_per_part = h.wrows;
     g.That = h.That;
@@ -345,8 +355,7 @@ static LonWideGeom lonsymw_geom(const gh_ctx *c)
     g.Xhat = h.Xhat;
     g.Dpart = h.Dpart;
     g.slot_first = h.slot_first;
-    g.n_xslots = h.n_xslots;
-    g.xslot = h.xslot;
+    g.slot_x = h.slot_x;
     g.xptr = h.xptr;
     g.xobs = h.xobs;
     g.N = c->N;
@@ -366,6 +375,7 @@ static LonHarmGeom lonsymh_geom(const gh_ctx *c)
     g.Rhat = h.Rhat;
     g.Dpart = h.Dpart;
     g.slot_first = h.slot_first;
+    g.slot_x = h.slot_x;
     g.n_xslots = h.n_xslots;
     g.xslot = h.xslot;
     g.xptr = h.xptr;
@@ -418,7 +428,7 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
         hipLaunchKernelGGL(lonsymw_sweep_kernel, dim3((unsigned)h.wgrid), dim3(LW_THREADS), h.wlds, c->stream, g, a,
                            c->weighted ? c->wm : nullptr);
         if (a.mode & SW_FWD) {
-            const int64_t tot = (int64_t)h.na * h.nf;
+            const int64_t tot = (int64_t)h.na * h.nfp;
             lonsymw_forward_kernel<<<dim3((unsigned)((tot + LW_THREADS - 1) / LW_THREADS), (unsigned)h.wparts), dim3(LW_THREADS), 0,
                                      c->stream>>>(g);
             lonsymw_post_kernel<<<dim3((unsigned)h.na), dim3(LW_THREADS), 0, c->stream>>>(g, c->ld, a.slab, a.dsum);

@@ -34,6 +34,7 @@ struct LonHarmGeom {
     d2 *Rhat;                // [na][nf]
     d2 *Dpart;               // [grid][na][nf]
     const int *slot_first;   // na * n: first observation of slot (a, m), or -1
+    const int *slot_x;       // na * n: the slot's entry in xptr (slots holding several observations), or -1
     int n_xslots;
     const int *xslot, *xptr, *xobs;
     int64_t N;
@@ -49,7 +50,9 @@ static inline size_t lonsymh_lds_doubles(int n, int nf, int na, int rw)
 }
 
 // T^[c][a][f] = sum_delta T[c][a][delta] e^{-2 pi i f delta / n}: one block per (c, a) row of the table
-__global__ void __launch_bounds__(64) lonsymh_table_kernel(const double *T, int64_t ldT, int n, int nf, int na, const d2 *tw, d2 *That)
+// (nfp: pitch of a row of T^ in complex entries, >= nf; the entries past nf are written as zeros)
+__global__ void __launch_bounds__(64) lonsymh_table_kernel(const double *T, int64_t ldT, int n, int nf, int na, const d2 *tw, d2 *That,
+                                                           int nfp)
 {
     __shared__ double row[1024];
     const int c = blockIdx.x / na, a = blockIdx.x - c * na;
@@ -66,8 +69,9 @@ __global__ void __launch_bounds__(64) lonsymh_table_kernel(const double *T, int6
             idx += f;
             if (idx >= n) idx -= n;
         }
-        That[((int64_t)c * na + a) * nf + f] = d2{re, im};
+        That[((int64_t)c * na + a) * nfp + f] = d2{re, im};
     }
+    for (int f = nf + threadIdx.x; f < nfp; f += 64) That[((int64_t)c * na + a) * nfp + f] = d2{0.0, 0.0};
 }
 
 __global__ void __launch_bounds__(256) lonsymh_twiddle_kernel(int n, d2 *tw)
@@ -154,9 +158,9 @@ __global__ void __launch_bounds__(256) lonsymh_rhat_kernel(LonHarmGeom g, const 
     for (int m = tid; m < n; m += 256) {
         const int e = a * n + m, idx = g.slot_first[e];
         double v = idx >= 0 ? r[idx] : 0.0;
-        for (int x = 0; x < g.n_xslots; ++x)
-            if (g.xslot[x] == e)
-                for (int q = g.xptr[x]; q < g.xptr[x + 1]; ++q) v += r[g.xobs[q]];
+        const int x = g.slot_x[e];
+        if (x >= 0)
+            for (int q = g.xptr[x]; q < g.xptr[x + 1]; ++q) v += r[g.xobs[q]];
         row[m] = v;
         tws[m] = g.tw[m];
     }
@@ -468,12 +472,12 @@ __global__ void __launch_bounds__(512) lonsymh_post_kernel(LonHarmGeom g, int np
         if (i0 >= 0) {
             out[i0] = d;
             rs += d;
-            for (int x = 0; x < g.n_xslots; ++x)
-                if (g.xslot[x] == e)
-                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) {
-                        out[g.xobs[qq]] = d;
-                        rs += d;
-                    }
+            const int x = g.slot_x[e];
+            if (x >= 0)
+                for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) {
+                    out[g.xobs[qq]] = d;
+                    rs += d;
+                }
         }
     }
     if (a == 0)
@@ -573,9 +577,9 @@ __global__ void __launch_bounds__(256) lonsymh_epilogue_kernel(LonHarmGeom g, Lh
         i0 = g.slot_first[sl];
         if (i0 >= 0) {
             rs += dm + (e.gfix ? e.gfix[i0] : 0.0);
-            for (int x = 0; x < g.n_xslots; ++x)
-                if (g.xslot[x] == sl)
-                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) rs += dm + (e.gfix ? e.gfix[g.xobs[qq]] : 0.0);
+            const int x = g.slot_x[sl];
+            if (x >= 0)
+                for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) rs += dm + (e.gfix ? e.gfix[g.xobs[qq]] : 0.0);
         }
     }
     const double csum = block_allreduce_sum(rs, red, 4);
@@ -614,9 +618,9 @@ __global__ void __launch_bounds__(256) lonsymh_epilogue_kernel(LonHarmGeom g, Lh
                 r2 += ri * ri;
             };
             one(i0);
-            for (int x = 0; x < g.n_xslots; ++x)
-                if (g.xslot[x] == sl)
-                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) one(g.xobs[qq]);
+            const int x = g.slot_x[sl];
+            if (x >= 0)
+                for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) one(g.xobs[qq]);
         }
         row[tid] = Rm;
     }

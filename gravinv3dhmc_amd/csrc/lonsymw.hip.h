@@ -23,24 +23,94 @@
 namespace ghk {
 
 struct LonWideGeom {
-    int n, nf, na, nc, parts, rows_per_part;
-    const d2 *That;          // [nc][na][nf]
+    int n, nf, nfp, na, nc, parts, rows_per_part;
+    int brk;                 // diagnostic (GRAVHMC_LW_BREAK): 1 no stream of T^, 2 no inverse transform, 4 no transform of xs
+    const d2 *That;          // [nc][na][nfp]   (nfp = nf rounded up to 8 complex: rows start on 128-byte lines; the pad is zero)
     const d2 *tw;            // n
-    d2 *Rhat;                // [na][nf]
+    d2 *Rhat;                // [na][nfp]
     d2 *Xhat;                // [nc][nf]
-    d2 *Dpart;               // [parts][na][nf]
+    d2 *Dpart;               // [parts][na][nfp]
     const int *slot_first;   // na * n
-    int n_xslots;
-    const int *xslot, *xptr, *xobs;
+    const int *slot_x;       // na * n: the slot's entry in xptr, or -1
+    const int *xptr, *xobs;
     int64_t N;
 };
 
 constexpr int LW_THREADS = 256;
 constexpr int LW_NMAX = 1024;  // longitudes per cell row (the transforms' tables live in LDS)
+constexpr int LW_NP = (LW_NMAX / 2 + 1 + LW_THREADS - 1) / LW_THREADS;  // pairs of longitudes (m, n - m) per thread at most
 
 static inline size_t lonsymw_lds_doubles(int n, int nf)
 {
-    return 2 * (size_t)n + 8 * (size_t)nf + 2 * (size_t)nf + (size_t)n + 16;
+    return 2 * (size_t)n + 8 * (size_t)nf + 2 * (size_t)nf + 2 * (size_t)nf + 16;
+}
+
+// The two transforms of a cell row from the pairs of longitudes (m, n - m), m = 0 .. n / 2 (half the terms: the
+// twiddle reads -- a different LDS address per lane -- are what the transforms cost):
+//   s[m] = E - O, s[n - m] = E + O   with E = sum_f Re(H[f]) cos(2 pi f m / n), O = sum_f Im(H[f]) sin(2 pi f m / n)
+//   X^[f] = sum_m (xe[m] cos(2 pi f m / n), -xo[m] sin(2 pi f m / n)),  xe = x[m] + x[n - m], xo = x[m] - x[n - m]
+//   (m = 0 and, n even, m = n / 2 stand alone: xe = x[m], xo = 0)
+__device__ __forceinline__ void lw_idft_pair(const d2 *H, const d2 *tws, int nf, int m, int n, double &E, double &O)
+{
+    double e = 0.0, o = 0.0;
+    int idx = 0, ff = 0;
+    for (; ff + 8 <= nf; ff += 8) {
+        d2 h[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            h[u] = H[ff + u];
+            w[u] = tws[idx];
+            idx += m;
+            if (idx >= n) idx -= n;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            e += h[u].x * w[u].x;
+            o += h[u].y * w[u].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; ff < nf; ++ff) {
+        const d2 h = H[ff], w = tws[idx];
+        e += h.x * w.x;
+        o += h.y * w.y;
+        idx += m;
+        if (idx >= n) idx -= n;
+    }
+    E = e;
+    O = o;
+}
+
+__device__ __forceinline__ d2 lw_dft_pairs(const d2 *XE, const d2 *tws, int np, int f, int n)
+{
+    d2 acc = d2{0.0, 0.0};
+    int idx = 0, m = 0;
+    for (; m + 8 <= np; m += 8) {
+        d2 x[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = XE[m + u];
+            w[u] = tws[idx];
+            idx += f;
+            if (idx >= n) idx -= n;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x += x[u].x * w[u].x;
+            acc.y -= x[u].y * w[u].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; m < np; ++m) {
+        const d2 x = XE[m], w = tws[idx];
+        acc.x += x.x * w.x;
+        acc.y -= x.y * w.y;
+        idx += f;
+        if (idx >= n) idx -= n;
+    }
+    return acc;
 }
 
 __global__ void __launch_bounds__(LW_THREADS) lonsymw_rhat_kernel(LonWideGeom g, const double *__restrict__ r)
@@ -51,14 +121,14 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_rhat_kernel(LonWideGeom g,
     for (int m = tid; m < n; m += LW_THREADS) {
         const int e = a * n + m, idx = g.slot_first[e];
         double v = idx >= 0 ? r[idx] : 0.0;
-        for (int x = 0; x < g.n_xslots; ++x)
-            if (g.xslot[x] == e)
-                for (int q = g.xptr[x]; q < g.xptr[x + 1]; ++q) v += r[g.xobs[q]];
+        const int x = g.slot_x[e];
+        if (x >= 0)
+            for (int q = g.xptr[x]; q < g.xptr[x + 1]; ++q) v += r[g.xobs[q]];
         row[m] = v;
         tws[m] = g.tw[m];
     }
     __syncthreads();
-    for (int f = tid; f < nf; f += LW_THREADS) g.Rhat[(int64_t)a * nf + f] = lh_dft_part(row, tws, 0, n, f, n);
+    for (int f = tid; f < nf; f += LW_THREADS) g.Rhat[(int64_t)a * g.nfp + f] = lh_dft_part(row, tws, 0, n, f, n);
 }
 
 // modes of SweepArgs as lonsym_sweep_kernel / lonsymh_sweep_kernel; SW_FWD leaves X^ of every cell row in g.Xhat
@@ -66,43 +136,72 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = g.n, nf = g.nf, na = g.na;
+    const int n = g.n, nf = g.nf, nfp = g.nfp, na = g.na;
     const int mode = a.mode;
     d2 *tws = reinterpret_cast<d2 *>(smem);                   // n
     d2 *Gp = tws + n;                                         // 4 x nf: partial S^ of the waves' classes
     d2 *Gh = Gp + 4 * nf;                                     // nf
-    double *xs = reinterpret_cast<double *>(Gh + nf);         // n
-    double *red = xs + n;
+    d2 *XE = Gh + nf;                                         // nf: (even, odd) parts of xs of the pairs (m, n - m)
+    double *red = reinterpret_cast<double *>(XE + nf);
     for (int e = tid; e < n; e += LW_THREADS) tws[e] = g.tw[e];
     double pp = 0.0;
     for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
-        __syncthreads();  // tws in place; the previous row is done with Gp / Gh / xs
+        // the operands of the row's updates: requested in front of the stream of T^.  Thread <-> pairs of longitudes
+        // m = tid, tid + 256, ...: item 0 = longitude m, item 1 = longitude n - m (none for m = 0 and 2 m = n)
+        double u_w[LW_NP][2], u_x[LW_NP][2], u_g[LW_NP][2], u_p[LW_NP][2], u_pn[LW_NP][2], u_hi[LW_NP][2], u_lo[LW_NP][2];
+#pragma unroll
+        for (int q = 0; q < LW_NP; ++q) {
+            const int m = tid + q * LW_THREADS;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int k = w == 0 ? m : n - m;
+                u_w[q][w] = 1.0;
+                u_x[q][w] = u_g[q][w] = u_p[q][w] = u_pn[q][w] = u_hi[q][w] = u_lo[q][w] = 0.0;
+                if (m < nf && (w == 0 || (m > 0 && 2 * m != n))) {
+                    const int64_t j = (int64_t)c * n + k;
+                    u_w[q][w] = wm ? wm[j] : 1.0;
+                    u_x[q][w] = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+                    if (mode & SW_ADJ) {
+                        u_g[q][w] = a.greg ? a.greg[j] : 0.0;
+                        if (mode & (SW_PFIN | SW_UPD)) u_p[q][w] = a.p_in[j];
+                        if (mode & SW_SPEC) u_pn[q][w] = a.pn_in[j];
+                        if (mode & SW_UPD) {
+                            u_hi[q][w] = a.high[j];
+                            u_lo[q][w] = a.low[j];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // tws in place; the previous row is done with Gp / Gh / XE
         if (mode & SW_ADJ) {
             // S^[f] = sum_a conj(T^[a][f]) R^[a][f]: wave wv takes the classes wv, wv + 4, ..., eight of them in flight
-            const d2 *Tg = g.That + (int64_t)c * na * nf;
+            const d2 *Tg = g.That + (int64_t)c * na * nfp;
             for (int f0 = 0; f0 < nf; f0 += 64) {
                 const int f = f0 + lane;
                 const bool fv = f < nf;
                 const int fc = fv ? f : nf - 1;
                 d2 acc = d2{0.0, 0.0};
                 int aa = wv;
-                for (; aa + 28 < na; aa += 32) {
-                    d2 t[8], rr[8];
+                if (!(g.brk & 1)) {
+                    for (; aa + 28 < na; aa += 32) {
+                        d2 t[8], rr[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        t[u] = Tg[(int64_t)(aa + 4 * u) * nf + fc];
-                        rr[u] = g.Rhat[(int64_t)(aa + 4 * u) * nf + fc];
-                    }
+                        for (int u = 0; u < 8; ++u) {
+                            t[u] = __builtin_nontemporal_load(&Tg[(int64_t)(aa + 4 * u) * nfp + fc]);
+                            rr[u] = g.Rhat[(int64_t)(aa + 4 * u) * nfp + fc];
+                        }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        acc.x += t[u].x * rr[u].x + t[u].y * rr[u].y;
-                        acc.y += t[u].x * rr[u].y - t[u].y * rr[u].x;
+                        for (int u = 0; u < 8; ++u) {
+                            acc.x += t[u].x * rr[u].x + t[u].y * rr[u].y;
+                            acc.y += t[u].x * rr[u].y - t[u].y * rr[u].x;
+                        }
                     }
-                }
-                for (; aa < na; aa += 4) {
-                    const d2 t = Tg[(int64_t)aa * nf + fc], rr = g.Rhat[(int64_t)aa * nf + fc];
-                    acc.x += t.x * rr.x + t.y * rr.y;
-                    acc.y += t.x * rr.y - t.y * rr.x;
+                    for (; aa < na; aa += 4) {
+                        const d2 t = __builtin_nontemporal_load(&Tg[(int64_t)aa * nfp + fc]), rr = g.Rhat[(int64_t)aa * nfp + fc];
+                        acc.x += t.x * rr.x + t.y * rr.y;
+                        acc.y += t.x * rr.y - t.y * rr.x;
+                    }
                 }
                 if (fv) Gp[wv * nf + f] = acc;
             }
@@ -121,43 +220,64 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
             __syncthreads();
         }
         // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}), gradient, update (hmc.py:114-152)
-        for (int k = tid; k < n; k += LW_THREADS) {
-            const int64_t j = (int64_t)c * n + k;
-            const double wj = wm ? wm[j] : 1.0;
-            const double iwj = (wj != 0.0) ? 1.0 / wj : 1.0;
-            double xj = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
-            if (mode & SW_ADJ) {
-                const double s = lh_idft_part(Gh, tws, 0, nf, k, n);
-                const double t = (s / (double)n) * iwj;
-                const double grad = 2.0 * t + (a.greg ? a.greg[j] : 0.0);
-                if (mode & SW_GOUT) a.g_out[j] = grad;
-                const double pin = (mode & (SW_PFIN | SW_UPD)) ? a.p_in[j] : 0.0;
-                if (mode & SW_PFIN) {
-                    const double pf = pin - a.c_p * grad;
-                    pp += pf * pf;
-                    if (!(mode & SW_SPEC)) a.p_out[j] = pf;
-                }
-                if (mode & SW_UPD) {
-                    const double psrc = (mode & SW_SPEC) ? a.pn_in[j] : pin;
-                    const double hi = a.high[j], lo = a.low[j];
-                    double pj = psrc - a.c_u * grad;
-                    xj = xj + a.dt * pj;
-                    if (xj > hi) {
-                        xj = hi;
-                        pj = -pj;
-                    } else if (xj < lo) {
-                        xj = lo;
-                        pj = -pj;
+#pragma unroll
+        for (int q = 0; q < LW_NP; ++q) {
+            const int m = tid + q * LW_THREADS;
+            if (m < nf) {
+                double E = 0.0, O = 0.0;
+                if (mode & SW_ADJ) {
+                    if (g.brk & 2) {
+                        E = Gh[m].x;
+                        O = Gh[m].y;
+                    } else {
+                        lw_idft_pair(Gh, tws, nf, m, n, E, O);
                     }
-                    a.p_out[j] = pj;
-                    a.x_out[j] = xj;
                 }
+                double xe = 0.0, xo = 0.0;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    if (w == 1 && (m == 0 || 2 * m == n)) continue;
+                    const int k = w == 0 ? m : n - m;
+                    const int64_t j = (int64_t)c * n + k;
+                    const double iwj = (u_w[q][w] != 0.0) ? 1.0 / u_w[q][w] : 1.0;
+                    double xj = u_x[q][w];
+                    if (mode & SW_ADJ) {
+                        const double s = w == 0 ? E - O : E + O;
+                        const double t = (s / (double)n) * iwj;
+                        const double grad = 2.0 * t + u_g[q][w];
+                        if (mode & SW_GOUT) a.g_out[j] = grad;
+                        if (mode & SW_PFIN) {
+                            const double pf = u_p[q][w] - a.c_p * grad;
+                            pp += pf * pf;
+                            if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+                        }
+                        if (mode & SW_UPD) {
+                            const double psrc = (mode & SW_SPEC) ? u_pn[q][w] : u_p[q][w];
+                            double pj = psrc - a.c_u * grad;
+                            xj = xj + a.dt * pj;
+                            if (xj > u_hi[q][w]) {
+                                xj = u_hi[q][w];
+                                pj = -pj;
+                            } else if (xj < u_lo[q][w]) {
+                                xj = u_lo[q][w];
+                                pj = -pj;
+                            }
+                            a.p_out[j] = pj;
+                            a.x_out[j] = xj;
+                        }
+                    }
+                    const double xsj = xj * iwj;
+                    xe += xsj;
+                    xo += w == 0 ? xsj : -xsj;
+                }
+                if (m == 0 || 2 * m == n) xo = 0.0;
+                if (mode & SW_FWD) XE[m] = d2{xe, xo};
             }
-            if (mode & SW_FWD) xs[k] = xj * iwj;
         }
         if (mode & SW_FWD) {
             __syncthreads();
-            for (int f = tid; f < nf; f += LW_THREADS) g.Xhat[(int64_t)c * nf + f] = lh_dft_part(xs, tws, 0, n, f, n);
+            for (int f = tid; f < nf; f += LW_THREADS)
+                g.Xhat[(int64_t)c * nf + f] = (g.brk & 4) ? XE[f] : lw_dft_pairs(XE, tws, nf, f, n);
         }
     }
     if (mode & SW_PFIN) {
@@ -171,11 +291,12 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
 __global__ void __launch_bounds__(LW_THREADS) lonsymw_forward_kernel(LonWideGeom g)
 {
     const int nf = g.nf;
-    const int64_t tot = (int64_t)g.na * nf;
+    const int64_t tot = (int64_t)g.na * g.nfp;
     const int64_t e = (int64_t)blockIdx.x * LW_THREADS + threadIdx.x;
     const bool ev = e < tot;
     const int64_t ec = ev ? e : tot - 1;
-    const int f = (int)(ec % nf);
+    const int fp = (int)(ec % g.nfp);
+    const int f = fp < nf ? fp : nf - 1;  // (the pad of a row of T^ is zero: any X^ will do)
     const int c0 = blockIdx.y * g.rows_per_part;
     const int c1 = (c0 + g.rows_per_part < g.nc) ? c0 + g.rows_per_part : g.nc;
     d2 acc = d2{0.0, 0.0};
@@ -211,11 +332,11 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_post_kernel(LonWideGeom g,
     __shared__ double red[8];
     const int a = blockIdx.x, tid = threadIdx.x;
     const int n = g.n, nf = g.nf;
-    const int64_t tot = (int64_t)g.na * nf;
+    const int64_t tot = (int64_t)g.na * g.nfp;
     for (int m = tid; m < n; m += LW_THREADS) tws[m] = g.tw[m];
     for (int f = tid; f < nf; f += LW_THREADS) {
         d2 s = d2{0.0, 0.0};
-        const d2 *src = g.Dpart + (int64_t)a * nf + f;
+        const d2 *src = g.Dpart + (int64_t)a * g.nfp + f;
         for (int p = 0; p < g.parts; ++p) {
             const d2 v = src[(int64_t)p * tot];
             s.x += v.x;
@@ -232,12 +353,12 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_post_kernel(LonWideGeom g,
         if (i0 >= 0) {
             out[i0] = d;
             rs += d;
-            for (int x = 0; x < g.n_xslots; ++x)
-                if (g.xslot[x] == e)
-                    for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) {
-                        out[g.xobs[qq]] = d;
-                        rs += d;
-                    }
+            const int x = g.slot_x[e];
+            if (x >= 0)
+                for (int qq = g.xptr[x]; qq < g.xptr[x + 1]; ++qq) {
+                    out[g.xobs[qq]] = d;
+                    rs += d;
+                }
         }
     }
     if (a == 0)

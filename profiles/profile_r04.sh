@@ -97,4 +97,15 @@ if [ $which = all ] || [ $which = c5r ]; then
     cp $OUT/c5r_trace.json $SUM/bench_c5_row_block_share_under_rocprof_trace.json
   fi
 fi
+if [ $which = all ] || [ $which = g1 ]; then
+  # a 1-degree global grid (648 000 cells x 65 341 observations) on the STREAMED harmonic store (csrc/lonsymw.hip.h)
+  A="--workload x3_global_one_degree --shift-invariant --no-cpu-baseline --no-extra"
+  if prof g1_trace --kernel-trace --stats -- $A --steps 2000 --warmup 200 \
+     && prof g1_sq --pmc $SQ1 --kernel-trace -- $A --steps 400 --warmup 0 \
+     && prof g1_fetch --pmc FETCH_SIZE --kernel-trace -- $A --steps 400 --warmup 0; then
+    python3 $REPO/profiles/summarize.py stats $OUT/g1_trace $SUM/global_one_degree_streamed_kernel_stats.csv
+    python3 $REPO/profiles/summarize.py pmc $SUM/global_one_degree_streamed_pmc_summary.json "rocprofv3 --pmc passes (SQ counters; FETCH_SIZE in its own pass; with --kernel-trace only) of python3 bench.py $A --steps 400 --warmup 0 $NOTE" $OUT/g1_sq $OUT/g1_fetch
+    cp $OUT/g1_trace.json $SUM/bench_global_one_degree_streamed_under_rocprof_trace.json
+  fi
+fi
 ls -la $SUM
