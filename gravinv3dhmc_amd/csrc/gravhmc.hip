@@ -671,7 +671,10 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     if (!(thr >= 0)) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: threshold must be >= 0");
     gh_ctx::Wavelet &w = c->wv;
     if (w.on || w.indptr) return fail(c, GH_ERR_ARG, "gh_compress_wavelet: already compressed");
-    if (c->sh.kind != 0) return fail(c, GH_ERR_UNSUPPORTED, "wavelet forward on a sharded kernel is not supported");
+    // (row blocks hold whole rows of the kernel: the compressor works row by row, compressor3D.py:17-44, so every rank
+    // compresses its own rows; column blocks would have to exchange the rows first)
+    if (c->sh.kind != 0 && !shard_rows(c))
+        return fail(c, GH_ERR_UNSUPPORTED, "wavelet forward on a kernel sharded in column blocks is not supported (row blocks: gh_shard_init_rows)");
     if (dims == 3) {
         if (!shape3 || (int64_t)shape3[0] * shape3[1] * shape3[2] != c->M)
             return fail(c, GH_ERR_ARG, "cannot reshape array of size %lld into shape (%d,%d,%d)",
@@ -763,7 +766,7 @@ int gh_compress_wavelet(gh_ctx *c, int dims, const int shape3[3], double thr, in
     wavelet_plan_lds(c);
     w.on = true;
     w.F_valid = false;
-    c->rs.state = 0;  // plan the resident chain kernel again (it would need the dense form)
+    if (!shard_rows(c)) c->rs.state = 0;  // plan the resident chain kernel again (it would need the dense form)
     if (c->ls) c->ls->res.state = 0;  // (the persistent harmonic pass has no compressed forward: planned again, refused)
     c->chain_ready = false;
     c->bt.ready = false;

@@ -114,7 +114,7 @@ static int shard_rows_init(gh_ctx *c, int rank, int world, int64_t N_global, int
     if (world < 1 || rank < 0 || rank >= world) return fail(c, GH_ERR_ARG, "gh_shard_init_rows: bad rank/world");
     if (n0 < 0 || n0 + c->N > N_global) return fail(c, GH_ERR_ARG, "gh_shard_init_rows: observation range outside the problem");
     if (c->mf) return fail(c, GH_ERR_UNSUPPORTED, "row blocks need the stored kernel");
-    if (c->wv.on) return fail(c, GH_ERR_UNSUPPORTED, "sharding with the wavelet forward is not supported");
+    if (c->wv.on) return fail(c, GH_ERR_UNSUPPORTED, "gh_shard_init_rows comes before gh_compress_wavelet (every rank compresses its own rows)");
     c->sh.axis = 1;
     c->sh.rank = rank;
     c->sh.world = world;

@@ -57,6 +57,11 @@ static int finalize(gh_ctx *c, const double *x, const gh_ctx::StateSet &o)
         fa.ld = c->ld;
         fa.N_global = c->sh.N_global;
         fa.nseg = c->slab_live > 0 ? c->slab_live : c->grid;
+        if (c->wv.on) {
+            // the local rows of the compressed operator (every rank compressed its own rows of Aw): one finished row
+            TRY(wavelet_forward(c, x, c->slab));
+            fa.nseg = 1;
+        }
         fa.n_regpart = c->n_regpart;
         fa.src = c->slab;
         fa.gfix = gfix;

@@ -53,6 +53,8 @@ class GravMagModule(object):
     * shard: a `dist.Ranks` object: the cells of ONE model are split in column blocks over the
       ranks' GPUs (each holds N x M/world of G); shard_backend "rccl" or "gloo"; shard_planes=True
       splits in whole z-planes, which the Smoothness/TV regularisers need on a sharded model.
+      shard_axis="rows": the OBSERVATIONS are split instead (row blocks, the model replicated: a gradient
+      all-reduce per step); the wavelet-compressed forward works on row blocks only.
     * matrix_free: never store G; re-evaluate the prism / tesseroid entries in every potential
       evaluation (for kernels larger than HBM; the global tesseroid example: ~5x slower per step than
       the dense path).
@@ -66,7 +68,7 @@ class GravMagModule(object):
                  mratio=1, mseg=False, mdivisionsection=[], weightfactor=0.5,
                  coordinate="cartesian", njobs=1, field="gravity",
                  mangle=(90, 0), wavelet=False, device=0, verbose=True, shard=None,
-                 shard_backend="rccl", matrix_free=False, shard_planes=False, shift_invariant=False,
+                 shard_backend="rccl", matrix_free=False, shard_planes=False, shift_invariant=False, shard_axis="cells",
                  **kwargs):
         self.dobs = dobs
         self.fixed = fixed
@@ -114,15 +116,18 @@ class GravMagModule(object):
         self._say("Start of calculate kernel")
         start = time.time()
         if shard is not None and shard.world > 1:
-            if wavelet:
-                raise NotImplementedError("wavelet forward on a sharded kernel is not supported")
+            if shard_axis not in ("cells", "rows"):
+                raise ValueError("shard_axis must be 'cells' (column blocks) or 'rows' (row blocks)")
+            if wavelet and shard_axis != "rows":
+                raise NotImplementedError("wavelet forward on a kernel sharded in column blocks is not supported "
+                                          "(shard_axis='rows': every rank compresses its own rows)")
             from ..dist import make_sharded_engine
             align = 1
             if shard_planes:
                 if bounds.shape[0] != mesh.size:
                     raise ValueError("shard_planes needs the full (uncarved) mesh")
                 align = int(mesh.shape[1]) * int(mesh.shape[2])
-            eng = make_sharded_engine(N, bounds.shape[0], shard, backend=shard_backend, align=align)
+            eng = make_sharded_engine(N, bounds.shape[0], shard, backend=shard_backend, align=align, axis=shard_axis)
         else:
             eng = Engine(N, bounds.shape[0], device=device)
         if matrix_free:

@@ -50,6 +50,15 @@ def main():
     sh.chain_init(0.001 * wm, low, high)
     res = []
     sh.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res.append((acc, o.copy(), xs)), want_x=True, batch=2)
+    # the wavelet-compressed forward on row blocks (potential.py:693-696; compressor3D.py:17-44 works row by row: every
+    # rank compresses its own rows of Aw): potential, gradient and the same chain again
+    nnz, ncols = sh.compress_wavelet(3, mesh.shape, 1e-3, 2)
+    sh.set_reg("MS", 0.7, 0.001, mesh.shape, 0.001 * wm)
+    got_w = sh.misfit_and_grad(x_test * wm)
+    sh.chain_init(0.001 * wm, low, high)
+    res_w = []
+    sh.run_chain(iter(trajs), 0.002, lambda L, acc, o, xs: res_w.append((acc, o.copy(), xs)), want_x=True, batch=2)
+    nnzs = ranks.gather(int(nnz))
     rows = ranks.gather(sh.N)
     ranks.barrier()
     if ranks.rank == 0:
@@ -73,6 +82,21 @@ def main():
                         "out5": max(relmax(r[1], c[1]) for r, c in zip(res, ref)),
                         "x": max([relmax(r[2], c[2]) for r, c in zip(res, ref) if r[0]] or [0.0]),
                         "accepted": int(sum(r[0] for r in res))}
+        from oracle import wavelet as ow
+        csr = ow.compress_kernel(Aw, 3, mesh.shape)
+        Pw = orc.Problem(Aw, dobs, 0.001 * wm, "MS", 0.7, 0.001, wm=wm, shape=mesh.shape, csr=csr,
+                         dwt=lambda v: ow.model_coeffs(v, 3, mesh.shape))
+        a, b = got_w, Pw.misfit_and_grad(x_test * wm)
+        out["wavelet"] = {"nnz": [int(sum(nnzs)), int(csr.nnz)], "ncols": [int(ncols), int(csr.shape[1])],
+                          "U": abs(a[0] - b[0]) / abs(b[0]), "grad": relmax(a[1], b[1]), "dpre": relmax(a[2], b[2])}
+        xo, ref = 0.001 * wm, []
+        for (L, p0, u) in trajs:
+            xo, acco, oo, _ = Pw.leapfrog(xo, p0, 0.002, L, low, high, u)
+            ref.append((acco, oo.copy(), xo.copy()))
+        out["wavelet"]["chain"] = {"n": len(res_w), "decisions_equal": [r[0] for r in res_w] == [c[0] for c in ref],
+                                   "out5": max(relmax(r[1], c[1]) for r, c in zip(res_w, ref)),
+                                   "x": max([relmax(r[2], c[2]) for r, c in zip(res_w, ref) if r[0]] or [0.0]),
+                                   "accepted": int(sum(r[0] for r in res_w))}
         print("RESULT " + json.dumps(out))
     ranks.barrier()
     sh.close()

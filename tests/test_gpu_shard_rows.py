@@ -32,3 +32,10 @@ def test_row_block_shards_three_ranks_against_the_oracle():
         assert r["U"] < 1e-11 and r["grad"] < 1e-10 and r["dpre"] < 1e-10, (reg, r)
     c = res["chain"]
     assert c["decisions_equal"] and c["n"] == 5 and c["out5"] < 1e-9 and c["x"] < 1e-9 and c["accepted"] > 0, c
+    # the wavelet-compressed forward on the row blocks (refused on any sharded kernel until round 4) against
+    # oracle.Problem(csr=..., dwt=...): the ranks' CSR rows together are the oracle's operator
+    w = res["wavelet"]
+    assert w["nnz"][0] == w["nnz"][1] and w["ncols"][0] == w["ncols"][1], w
+    assert w["U"] < 1e-11 and w["grad"] < 1e-10 and w["dpre"] < 1e-10, w
+    c = w["chain"]
+    assert c["decisions_equal"] and c["n"] == 5 and c["out5"] < 1e-9 and c["x"] < 1e-9, c
