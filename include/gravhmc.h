@@ -32,10 +32,13 @@
  *     copy of G instead of teams reading it once), GRAVHMC_RESIDENT_BATCH=0 (chains of a batch take turns in the
  *     resident kernel instead of running in lock-step), GRAVHMC_LONSYM_HARMONIC=0 / GRAVHMC_LONSYM_FUSED=1 /
  *     GRAVHMC_LONSYM_RESIDENT=0 (shift-invariant store: direct correlations / one-launch epilogue / one launch per
- *     phase instead of the persistent launch), GRAVHMC_LONSYM_W,
+ *     phase instead of the persistent launch), GRAVHMC_LONSYM_WIDE=0 / 2 (the streamed harmonic form of large grids:
+ *     off / also where the register form applies), GRAVHMC_LONSYM_W, GRAVHMC_LW_WAVES_PER_CU,
  *     GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
  *   arithmetic of an entry (within the path's stated 1e-10, ~1e-14 measured): GRAVHMC_MF_EXACT -- the
  *     DEFAULT of gh_set_matrix_free_exact only; that call overrides it;
+ *   diagnostics that BREAK the results (timing only): GRAVHMC_LW_BREAK (phases of lonsymw_sweep_kernel off),
+ *     GRAVHMC_BT_BREAK; GRAVHMC_LW_LDS_PAD (fewer workgroups per CU, results intact);
  *   tuning without any effect on results: GRAVHMC_PF, _NT, _TW, _TW8, _WG_PER_CU, _MIN_COLS,
  *     _INFLIGHT_MB, GRAVHMC_MF_T, _MF_WG_PER_CU, GRAVHMC_MFB_WG_PER_CU, _MFB_RANGES, GRAVHMC_RNG_THREADS;
  *   test hooks (force a time-out path): GRAVHMC_TEAM_TEST_ABORT, GRAVHMC_RESIDENT_TEST_ABORT,
@@ -117,7 +120,9 @@ int gh_set_matrix_free_exact(gh_ctx *ctx, int exact);
  * fused leapfrog step -- becomes circular correlations along the longitude served from LDS.  Values
  * agree with the stored kernel to the rounding of cos(lon - lon') at a shifted pair of longitudes
  * (stated tolerance 1e-10).  gh_build_G fails with GH_ERR_UNSUPPORTED and the reason when the geometry
- * lacks the structure (or a cell row's table does not fit the LDS). */
+ * lacks the structure (or has more than 1024 longitudes per cell row: the transforms' tables live in the LDS).
+ * gh_compress_wavelet works on such a context (the compressor's rows are evaluated, the forward runs on the CSR
+ * operator, the gradient on the table's adjoint pass); batches of chains are refused with it. */
 int gh_set_shift_invariant(gh_ctx *ctx, int enable);
 /* The structure gh_build_G found: longitudes per cell row, observation classes (distinct latitude /
  * height pairs), cell rows, bytes of the table (all 0 when the store is not in use). */
@@ -128,7 +133,11 @@ int gh_shift_invariant_info(const gh_ctx *ctx, int *n_lon, int *n_classes, int *
  * forward and adjoint cost n_rows x n_classes x (n / 2 + 1) complex multiply-adds each instead of N M real ones
  * (C4: 2.2e6 against 5.3e8) from a complex table T^[row][class][frequency] of the same size, read once per
  * leapfrog step; the clamp-and-reflect update (hmc.py:135-141) happens at the longitudes, between an inverse
- * and a forward transform inside the cell row's workgroup.  on, frequencies n / 2 + 1, bytes of T^, workgroups
+ * and a forward transform inside the cell row's workgroup.  Grids beyond that form's limits (up to 1024 longitudes,
+ * any number of classes -- a 1-degree global grid: 360 longitudes, 181 classes, 1800 cell rows, T^ = 0.96 GB where
+ * the dense kernel would be 339 GB) run the same arithmetic as four streaming launches per step that read T^ twice
+ * (csrc/lonsymw.hip.h; GRAVHMC_LONSYM_WIDE=0 off, =2 everywhere).  on: 0 = direct correlations, 1 = the register
+ * form, 2 = the streamed form; frequencies n / 2 + 1, bytes of T^, workgroups
  * of the pass.  gh_batch_* on a shift-invariant context (BASELINE configs[3]: 8 chains) runs every chain as a
  * light context of its own -- stream, chain state, work buffers -- on the shared tables, one host thread per
  * chain; nothing stays in flight between calls (n_started = n_done = T in carry-over mode). */
@@ -214,7 +223,11 @@ int gh_reg_eval(gh_ctx *ctx, int kind, double beta, const int shape3[3], int ms_
  * compressor1D.kernelcompressor (:17-42); the reference uses thr = 1e-3, levels = 2.  After
  * this call gh_misfit_and_grad and the chain evaluate the FORWARD product as
  * Awcp @ DWT(mw) (modelcompressor, compressor3D.py:47-68) while the gradient keeps the exact
- * dense Aw^T (potential.py:693-708).  nnz_out / ncols_out receive the CSR size (N x ncols). */
+ * dense Aw^T (potential.py:693-708).  nnz_out / ncols_out receive the CSR size (N x ncols).
+ * Also on a matrix-free or shift-invariant context (the rows are evaluated instead of gathered) and on ROW blocks of
+ * a sharded kernel (after gh_shard_init_rows and gh_weight: the compressor works row by row, every rank compresses
+ * its own rows -- N, nnz and gh_download_csr are the rank's); refused on column blocks (a row's transform would span
+ * the ranks). */
 int gh_compress_wavelet(gh_ctx *ctx, int dims, const int shape3[3], double thr, int levels,
                         int64_t *nnz_out, int64_t *ncols_out);
 /* The CSR arrays (what GravMagModule.Awcp holds): indptr N+1, indices/data nnz. */
@@ -404,7 +417,8 @@ int gh_shard_init_callback(gh_ctx *ctx, gh_allreduce_fn fn, void *user, int rank
  * -- the fused one-read sweep is not possible: TWO reads of the local shard per leapfrog step, and M doubles
  * per step across the ranks instead of the column form's N + 2.  Updates and the regulariser are replicated
  * (any regulariser, no halo).  Same scalars on every rank, hence identical Metropolis decisions.  Stored
- * kernel only; no batches, no wavelet forward. */
+ * kernel only; no batches.  gh_compress_wavelet AFTER this call and gh_weight gives every rank the compressed form of its
+ * own rows (the forward of the local rows then runs on it). */
 int gh_shard_init_rows(gh_ctx *ctx, const void *id128, int rank, int world, int64_t N_global, int64_t n0);
 int gh_shard_init_rows_callback(gh_ctx *ctx, gh_allreduce_fn fn, void *user, int rank, int world,
                                 int64_t N_global, int64_t n0);
