@@ -126,7 +126,7 @@ EXTRA = {
     "x2_ratiogrid_900x17100_wavelet3d": dict(kind=0, reg="MS", alpha=1.0, beta=0.001, dt=0.01, hi=0.4, wavelet=3),
     # C4's geometry family (example/global/SetPMTS.txt) at 1 degree: 360 x 180 x 10 tesseroids (M = 648 000), 361 x 181
     # observations (N = 65 341) -- a dense kernel of 339 GB; with --shift-invariant the streamed harmonic store, 0.94 GB
-    "x3_global_one_degree": dict(kind=1, reg="Damping", alpha=0.05, beta=0.01, dt=0.002, hi=0.8, wavelet=0),
+    "x3_global_one_degree": dict(kind=1, reg="Damping", alpha=0.05, beta=0.01, dt=0.001, hi=0.8, wavelet=0),
 }
 
 
