@@ -17,6 +17,7 @@ struct LonSymHost {
     ghk::d2 *That = nullptr, *tw = nullptr, *Rhat = nullptr, *Dpart = nullptr;
     // the harmonic store as streaming passes over T^ (lonsymw.hip.h): grids beyond the register form's limits
     bool wide = false, direct_ok = false;
+    int wfwd = 0;                          // variant of the forward product's kernel
     int nfp = 0, wbreak = 0;               // pitch of a row of T^ / R^ / D^ in the streamed form (complex entries)
     int wgrid = 0, wparts = 0, wrows = 0;  // workgroups of the sweep; parts of the forward product, cell rows per part
     ghk::d2 *Xhat = nullptr;
@@ -320,6 +321,7 @@ static int lonsym_build(gh_ctx *c)
         parts = std::min<int64_t>(parts, 64);
         h.wrows = (int)((nc + parts - 1) / parts);
         h.wparts = (int)((nc + h.wrows - 1) / h.wrows);
+        h.wfwd = env_int("GRAVHMC_LW_FWD", 0);
         h.wbreak = env_int("GRAVHMC_LW_BREAK", 0);  // (diagnostic: phases of the sweep switched off -- wrong results, timing only)
         TRY(dalloc(c, &h.tw, (size_t)n, false));
         TRY(dalloc(c, &h.That, (size_t)nc * (size_t)na * (size_t)h.nfp, false));
@@ -429,8 +431,14 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
                            c->weighted ? c->wm : nullptr);
         if (a.mode & SW_FWD) {
             const int64_t tot = (int64_t)h.na * h.nfp;
-            lonsymw_forward_kernel<<<dim3((unsigned)((tot + LW_THREADS - 1) / LW_THREADS), (unsigned)h.wparts), dim3(LW_THREADS), 0,
-                                     c->stream>>>(g);
+            const dim3 fgrid((unsigned)((tot + LW_THREADS - 1) / LW_THREADS), (unsigned)h.wparts);
+            switch (h.wfwd) {  // (GRAVHMC_LW_FWD: rows in flight per thread / non-temporal loads; tuning, same results)
+            case 1: lonsymw_forward_kernel<8, true><<<fgrid, dim3(LW_THREADS), 0, c->stream>>>(g); break;
+            case 2: lonsymw_forward_kernel<16, false><<<fgrid, dim3(LW_THREADS), 0, c->stream>>>(g); break;
+            case 3: lonsymw_forward_kernel<16, true><<<fgrid, dim3(LW_THREADS), 0, c->stream>>>(g); break;
+            case 4: lonsymw_forward_kernel<4, false><<<fgrid, dim3(LW_THREADS), 0, c->stream>>>(g); break;
+            default: lonsymw_forward_kernel<8, false><<<fgrid, dim3(LW_THREADS), 0, c->stream>>>(g); break;
+            }
             lonsymw_post_kernel<<<dim3((unsigned)h.na), dim3(LW_THREADS), 0, c->stream>>>(g, c->ld, a.slab, a.dsum);
         }
         return GH_OK;

@@ -287,7 +287,9 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
     }
 }
 
-// D^ partial of the cell rows [part * rows_per_part, ...): thread e = a * nf + f (one complex of a row of T^)
+// D^ partial of the cell rows [part * rows_per_part, ...): thread e = a * nfp + f (one complex of a row of T^).
+// UN rows in flight per thread; NT: non-temporal loads of T^.
+template <int UN, bool NT>
 __global__ void __launch_bounds__(LW_THREADS) lonsymw_forward_kernel(LonWideGeom g)
 {
     const int nf = g.nf;
@@ -301,15 +303,16 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_forward_kernel(LonWideGeom
     const int c1 = (c0 + g.rows_per_part < g.nc) ? c0 + g.rows_per_part : g.nc;
     d2 acc = d2{0.0, 0.0};
     int c = c0;
-    for (; c + 8 <= c1; c += 8) {
-        d2 t[8], x[8];
+    for (; c + UN <= c1; c += UN) {
+        d2 t[UN], x[UN];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            t[u] = g.That[(int64_t)(c + u) * tot + ec];
+        for (int u = 0; u < UN; ++u) {
+            const d2 *src = &g.That[(int64_t)(c + u) * tot + ec];
+            t[u] = NT ? __builtin_nontemporal_load(src) : *src;
             x[u] = g.Xhat[(int64_t)(c + u) * nf + f];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UN; ++u) {
             acc.x += t[u].x * x[u].x - t[u].y * x[u].y;
             acc.y += t[u].x * x[u].y + t[u].y * x[u].x;
         }

@@ -33,7 +33,7 @@
  *     resident kernel instead of running in lock-step), GRAVHMC_LONSYM_HARMONIC=0 / GRAVHMC_LONSYM_FUSED=1 /
  *     GRAVHMC_LONSYM_RESIDENT=0 (shift-invariant store: direct correlations / one-launch epilogue / one launch per
  *     phase instead of the persistent launch), GRAVHMC_LONSYM_WIDE=0 / 2 (the streamed harmonic form of large grids:
- *     off / also where the register form applies), GRAVHMC_LONSYM_W, GRAVHMC_LW_WAVES_PER_CU,
+ *     off / also where the register form applies), GRAVHMC_LONSYM_W, GRAVHMC_LW_WAVES_PER_CU, GRAVHMC_LW_FWD,
  *     GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
  *   arithmetic of an entry (within the path's stated 1e-10, ~1e-14 measured): GRAVHMC_MF_EXACT -- the
  *     DEFAULT of gh_set_matrix_free_exact only; that call overrides it;

@@ -283,14 +283,19 @@ def test_c5_share_full_size_oracle_columns(G, orc):
     eng.close()
 
 
-def test_shift_invariant_batch_of_chains_against_the_oracle(G, orc):
-    """BASELINE configs[3] names 8 chains: gh_batch_* on the shift-invariant store runs every chain as a light
+@pytest.mark.parametrize("form", ["default", "streamed"])
+def test_shift_invariant_batch_of_chains_against_the_oracle(G, orc, form, monkeypatch):
+    """(streamed: the same with the harmonic store as streaming passes, csrc/lonsymw.hip.h -- every chain's light context
+    with its own R^, X^ and D^ partials, on its own stream and thread.)
+    BASELINE configs[3] names 8 chains: gh_batch_* on the shift-invariant store runs every chain as a light
     context of its own on the shared tables -- on the harmonic store the chains take turns in the persistent launch
     of csrc/lonres.hip.h, on the direct form each runs on its own stream and thread (tests/test_gpu_mfbatch.py covers
     those).  Coarse geometry: every chain against
     oracle.Problem.leapfrog on the oracle's dense kernel, rounds (gh_batch_trajectory) and lists (gh_batch_run,
     with and without carry-over); C4 geometry: chains 0 and 5 of 8 against a single chain on the table."""
     rng = np.random.default_rng(17)
+    if form == "streamed":
+        monkeypatch.setenv("GRAVHMC_LONSYM_WIDE", "2")
     mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
     N, M = lon.size, mesh.size
     bounds = mesh.cell_bounds()
@@ -313,6 +318,7 @@ def test_shift_invariant_batch_of_chains_against_the_oracle(G, orc):
 
     t, w = make(lon, lat, h, bounds, mesh.shape, dobs, "MS", wm)
     assert relmax(w, wm) < 1e-11
+    assert t.shift_invariant_harmonic()["form"] == ("streamed" if form == "streamed" else "registers")
     C, dt = 4, 0.005
     low, high = 0.0 * wm, 0.8 * wm
     x0s = np.stack([(0.001 + 0.05 * c) * wm for c in range(C)])
@@ -344,7 +350,7 @@ def test_shift_invariant_batch_of_chains_against_the_oracle(G, orc):
                 worst = max(worst, relmax(out5[c, q], oo))
                 if ao:
                     worst = max(worst, relmax(xs[c, q], xo[c]))
-    print("shift-invariant store, %d chains [coarse] vs ORACLE trajectories: worst %.2e" % (C, worst))
+    print("shift-invariant store [%s], %d chains [coarse] vs ORACLE trajectories: worst %.2e" % (form, C, worst))
     assert worst < 1e-10
     t.close()
     # C4 geometry, 8 chains
