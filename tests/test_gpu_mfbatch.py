@@ -511,3 +511,47 @@ def test_wavelet_forward_on_the_shift_invariant_store(G, wavelet):
         a._engine.batch_init(np.stack([0.001 * wm, 0.002 * wm]), 0.0 * wm, 0.8 * wm)
     for m in mods.values():
         m._engine.close()
+
+
+@pytest.mark.parametrize("form", ["registers", "streamed"])
+def test_hmcsample_on_the_shift_invariant_store(G, tmp_path, capsys, monkeypatch, form):
+    """The reference's global example as a user runs it (example/global/main_global.py:25-60: GravMagModule(coordinate=
+    'spherical') -> HMCSample) with shift_invariant=True -- the sampler's calls reach the store's passes (registers: the
+    persistent launch of csrc/lonres.hip.h; streamed: the four launches of csrc/lonsymw.hip.h, forced on this small
+    geometry) -- against the same run on the DENSE module: the same console lines (7 printed digits), the same model.dat
+    and misfit.dat rows."""
+    if form == "streamed":
+        monkeypatch.setenv("GRAVHMC_LONSYM_WIDE", "2")
+    rng = np.random.default_rng(27)
+    mrange, mspacing = (-180, 180, -90, 90, 0, -3000000), (-1000000, 15, 10)
+    lon, lat = [a.ravel() for a in np.meshgrid(np.arange(-180, 181, 10.0), np.arange(-90, 91, 15.0), indexing="ij")]
+    h = np.full_like(lon, 30000.0)
+    mesh = G.mesher.TesseroidMesh(mrange, mspacing)
+    M, N = mesh.size, lon.size
+    dense = G.GravMagModule(np.zeros(N), mrange, mspacing, (lon, lat, h), coordinate="spherical", verbose=False)
+    rho = np.zeros(mesh.shape)
+    rho[1:, 4:8, 10:20] = 0.3
+    dobs = dense._engine.forward(dense.Wm.diagonal() * rho.ravel()) * (1.0 + 0.01 * rng.normal(size=N))
+    dense._engine.close()
+    args = (np.full(M, 0.001), np.full(M, 0.001), np.c_[np.zeros(M), np.full(M, 0.8)], "mandatory", 1000, dobs,
+            "Fixed", 0.8, 0.05, "Damping", 0.01, 100, 0.001)
+    nsamp, dt = 8, 0.005
+    outs = {}
+    for tag in ("table", "dense"):
+        gm = G.GravMagModule(dobs, mrange, mspacing, (lon, lat, h), coordinate="spherical", verbose=False,
+                             shift_invariant=(tag == "table"))
+        if tag == "table":
+            assert gm._engine.shift_invariant_harmonic()["form"] == form
+        capsys.readouterr()
+        G.HMCSample(gm, nsamp, 0, dt, [5, 20], *args, myrank=0, save_folder=str(tmp_path / tag))
+        lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chain 0:")]
+        folder = str(tmp_path / tag) + "0"
+        outs[tag] = (lines, np.loadtxt(folder + "/model.dat"), np.loadtxt(folder + "/misfit.dat"))
+        if tag == "table" and form == "registers":
+            st = gm._engine.shift_invariant_resident_stats()
+            assert st["launches"] > 0 and st["timeouts"] == 0, st
+        gm._engine.close()
+    assert len(outs["table"][0]) > 0 and outs["table"][0] == outs["dense"][0]
+    assert outs["table"][1].shape == (nsamp, M)
+    np.testing.assert_allclose(outs["table"][1], outs["dense"][1], atol=2e-8)
+    np.testing.assert_allclose(outs["table"][2], outs["dense"][2], rtol=1e-7)
