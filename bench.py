@@ -327,6 +327,8 @@ EXTRA_RUNS = [
                                                   "--chains-per-gpu", "8", "--steps", "100", "--warmup", "20"]),
     ("x3_global_one_degree_shift_invariant", ["--workload", "x3_global_one_degree", "--shift-invariant", "--steps", "2000",
                                               "--warmup", "200"]),
+    ("x3_global_one_degree_shift_invariant_8_chains", ["--workload", "x3_global_one_degree", "--shift-invariant",
+                                                       "--chains-per-gpu", "8", "--steps", "400", "--warmup", "40"]),
     ("c5_share_of_one_gpu_of_8", ["--workload", "c5_uniform_200x200x60", "--cells-fraction", "8", "--steps", "40",
                                   "--warmup", "10"]),
     # (the same 96 GB as the row block one of 8 GPUs holds: 5000 observations x all 2.4e6 cells, two reads per step)
@@ -618,6 +620,7 @@ def config_values(line):
              "c4_global_tesseroid_shift_invariant_8_chains": "c4_si8",
              "c4_global_tesseroid_matrix_free_8_chains": "c4_mf8", "c5_share_of_one_gpu_of_8": "c5_share",
              "x3_global_one_degree_shift_invariant": "g1deg_si",
+             "x3_global_one_degree_shift_invariant_8_chains": "g1deg_si8",
              "c5_share_row_blocks": "c5_rows"}
     for tag, d in (line.get("extra") or {}).items():
         if tag in short:

@@ -63,6 +63,12 @@ static lonsym_fn_t lonsym_fn(int items, int W, int T)
     return items <= 1 ? lonsym_sweep_kernel<1, 8, 1024> : items <= 2 ? lonsym_sweep_kernel<2, 8, 1024> : lonsym_sweep_kernel<4, 8, 1024>;
 }
 
+typedef void (*lonsymw_fn_t)(LonWideGeom, SweepArgs, const double *);
+static lonsymw_fn_t lonsymw_sweep_fn(int nf)
+{
+    return nf <= LW_THREADS ? lonsymw_sweep_kernel<1> : nf <= 2 * LW_THREADS ? lonsymw_sweep_kernel<2> : lonsymw_sweep_kernel<3>;
+}
+
 typedef void (*lonsymh_fn_t)(LonHarmGeom, SweepArgs, const double *);
 static lonsymh_fn_t lonsymh_fn(int rw)
 {
@@ -312,7 +318,7 @@ static int lonsym_build(gh_ctx *c)
         h.nfp = (h.nf + 7) / 8 * 8;
         // (GRAVHMC_LW_LDS_PAD: extra LDS per workgroup in KB -- a diagnostic that lowers the workgroups per CU)
         h.wlds = lonsymw_lds_doubles((int)n, h.nf) * sizeof(double) + (size_t)env_int("GRAVHMC_LW_LDS_PAD", 0) * 1024;
-        HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsymw_sweep_kernel), h.wlds));
+        HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsymw_sweep_fn(h.nf)), h.wlds));
         h.wgrid = (int)std::min<int64_t>(nc, (int64_t)c->cus * 8);
         // parts of the forward product: ~8 waves per SIMD over the chip, at least 8 cell rows per part
         const int64_t waves_row = ((int64_t)na * h.nfp + 63) / 64;
@@ -427,7 +433,7 @@ static int launch_lonsym(gh_ctx *c, SweepArgs &a)
         // transforms behind the row-parallel pass
         const LonWideGeom g = lonsymw_geom(c);
         if (a.mode & SW_ADJ) lonsymw_rhat_kernel<<<dim3((unsigned)h.na), dim3(LW_THREADS), 0, c->stream>>>(g, a.r);
-        hipLaunchKernelGGL(lonsymw_sweep_kernel, dim3((unsigned)h.wgrid), dim3(LW_THREADS), h.wlds, c->stream, g, a,
+        hipLaunchKernelGGL(lonsymw_sweep_fn(h.nf), dim3((unsigned)h.wgrid), dim3(LW_THREADS), h.wlds, c->stream, g, a,
                            c->weighted ? c->wm : nullptr);
         if (a.mode & SW_FWD) {
             const int64_t tot = (int64_t)h.na * h.nfp;

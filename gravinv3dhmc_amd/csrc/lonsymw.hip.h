@@ -131,8 +131,12 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_rhat_kernel(LonWideGeom g,
     for (int f = tid; f < nf; f += LW_THREADS) g.Rhat[(int64_t)a * g.nfp + f] = lh_dft_part(row, tws, 0, n, f, n);
 }
 
-// modes of SweepArgs as lonsym_sweep_kernel / lonsymh_sweep_kernel; SW_FWD leaves X^ of every cell row in g.Xhat
-__global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g, SweepArgs a, const double *__restrict__ wm)
+// modes of SweepArgs as lonsym_sweep_kernel / lonsymh_sweep_kernel; SW_FWD leaves X^ of every cell row in g.Xhat.
+// NP = pairs of longitudes per thread (nf <= NP * 256): the update's operands of a thread's pairs wait in registers
+// while the row's slab of T^ streams -- with NP = 3 for every grid the kernel took 189 registers (two waves per SIMD);
+// NP = 1 (n <= 510): 127, four waves per SIMD = four workgroups per CU.
+template <int NP>
+__device__ __forceinline__ void lonsymw_sweep_body(const LonWideGeom &g, const SweepArgs &a, const double *__restrict__ wm)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -148,9 +152,9 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
     for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
         // the operands of the row's updates: requested in front of the stream of T^.  Thread <-> pairs of longitudes
         // m = tid, tid + 256, ...: item 0 = longitude m, item 1 = longitude n - m (none for m = 0 and 2 m = n)
-        double u_w[LW_NP][2], u_x[LW_NP][2], u_g[LW_NP][2], u_p[LW_NP][2], u_pn[LW_NP][2], u_hi[LW_NP][2], u_lo[LW_NP][2];
+        double u_w[NP][2], u_x[NP][2], u_g[NP][2], u_p[NP][2], u_pn[NP][2], u_hi[NP][2], u_lo[NP][2];
 #pragma unroll
-        for (int q = 0; q < LW_NP; ++q) {
+        for (int q = 0; q < NP; ++q) {
             const int m = tid + q * LW_THREADS;
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
         }
         // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}), gradient, update (hmc.py:114-152)
 #pragma unroll
-        for (int q = 0; q < LW_NP; ++q) {
+        for (int q = 0; q < NP; ++q) {
             const int m = tid + q * LW_THREADS;
             if (m < nf) {
                 double E = 0.0, O = 0.0;
@@ -285,6 +289,12 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
         const double t = block_allreduce_sum(pp, red, LW_THREADS / 64);
         if (tid == 0) a.pp_part[blockIdx.x] = t;
     }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g, SweepArgs a, const double *__restrict__ wm)
+{
+    lonsymw_sweep_body<NP>(g, a, wm);
 }
 
 // D^ partial of the cell rows [part * rows_per_part, ...): thread e = a * nfp + f (one complex of a row of T^).

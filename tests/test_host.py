@@ -333,7 +333,8 @@ def test_bench_config_values_and_resident_rooflines():
             "c3_segment_wavelet3d_tv", "c3_segment_wavelet3d_tv_16_chains", "c4_global_tesseroid_matrix_free",
             "c4_global_tesseroid_dense", "c4_global_tesseroid_shift_invariant",
             "c4_global_tesseroid_shift_invariant_8_chains", "c4_global_tesseroid_matrix_free_8_chains",
-            "c5_share_of_one_gpu_of_8", "c5_share_row_blocks", "x3_global_one_degree_shift_invariant")}}))) < 600
+            "c5_share_of_one_gpu_of_8", "c5_share_row_blocks", "x3_global_one_degree_shift_invariant",
+            "x3_global_one_degree_shift_invariant_8_chains")}}))) < 600
     prof = {"sweep_ms": 6.48, "sweeps": 1000}
     one = bench.resident_roofline(600, 6000, 1, prof, 100, {"resident_launches": 4})
     assert one["bound"] == "lds" and abs(one["achieved"] - 2 * 600 * 6000 * 8 / 6.48e-6 / 1e9) < 1e-6 * one["achieved"]
