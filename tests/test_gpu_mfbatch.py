@@ -223,7 +223,7 @@ def _global_model(G, dlon, dlat, dr, obs_h, nlat_obs_step=None):
 
 @pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size", "c4_full_size_direct_correlations",
                                   "c4_full_size_one_launch_epilogue", "coarse_odd_sizes_streamed", "c4_full_size_streamed",
-                                  "lon180_streamed", "classes91_streamed"])
+                                  "lon180_streamed", "classes91_streamed", "odd45", "odd45_streamed"])
 def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
     """gh_set_shift_invariant: K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] for regular spherical grids
     (example/global/main_global.py:25-28; BASELINE configs[3]'s geometry) against the dense engine on the
@@ -240,13 +240,16 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
         monkeypatch.setenv("GRAVHMC_LONSYM_HARMONIC", "0")
     if case.endswith("one_launch_epilogue"):
         monkeypatch.setenv("GRAVHMC_LONSYM_FUSED", "1")
-    if case in ("coarse_odd_sizes_streamed", "c4_full_size_streamed"):
+    if case in ("coarse_odd_sizes_streamed", "c4_full_size_streamed", "odd45_streamed"):
         monkeypatch.setenv("GRAVHMC_LONSYM_WIDE", "2")
     if case.startswith("coarse_odd_sizes"):
         mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
         h[::3] = 45000.0
         perm = rng.permutation(lon.size)
         lon, lat, h = lon[perm], lat[perm], h[perm]
+        tol = 1e-10
+    elif case.startswith("odd45"):
+        mesh, lon, lat, h = _global_model(G, 8.0, 15.0, -1000000, 30000.0)     # an ODD number of longitudes: no pair (n / 2, n / 2)
         tol = 1e-10
     elif case == "lon180_streamed":
         mesh, lon, lat, h = _global_model(G, 2.0, 3.0, -1500000, 5000.0)       # 180 longitudes, 61 classes, 120 cell rows

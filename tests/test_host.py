@@ -362,3 +362,23 @@ def test_native_legacy_draws_from_a_seed_are_numpys_randomstate(built_lib):
         assert np.array_equal(p0s[i], r.randn(M) * sig)
         assert float(us[i]) == r.rand()
     assert np.array_equal(np.random.get_state()[1], before)
+
+
+def test_bench_one_degree_workload_geometry():
+    """bench.py's x3_global_one_degree: example/global/SetPMTS.txt's geometry family at 1 degree -- full circles of 360
+    cells per row (what gh_set_shift_invariant looks for), observations on the cells' spacing with the duplicated +-180
+    meridian, an extra run and a config_values tag of its own (host code: no GPU call)."""
+    import bench
+    mesh, (lon, lat, h), rho = bench.make_extra("x3_global_one_degree")
+    assert mesh.shape == (10, 180, 360) and mesh.size == 648000 and rho.size == mesh.size
+    assert lon.size == 361 * 181 and float(lon.min()) == -180.0 and float(lon.max()) == 180.0
+    b = mesh.cell_bounds()
+    assert np.allclose(b[:360, 1] - b[:360, 0], 1.0) and abs((b[359, 1] - b[0, 0]) - 360.0) < 1e-9
+    assert np.all(b[:360, 2:] == b[0, 2:])                       # one cell row: the longitudes differ, nothing else
+    tags = dict(bench.EXTRA_RUNS)
+    assert "--shift-invariant" in tags["x3_global_one_degree_shift_invariant"]
+    assert "8" in tags["x3_global_one_degree_shift_invariant_8_chains"]
+    cv = bench.config_values({"value": 1.0, "roofline": {"frac": 0.5}, "extra": {
+        "x3_global_one_degree_shift_invariant": {"value": 2163.4, "roofline": {"frac": 0.5531}},
+        "x3_global_one_degree_shift_invariant_8_chains": {"value": 2476.5, "roofline": {"frac": None}}}})
+    assert cv["g1deg_si"] == [2163.4, 0.5531] and cv["g1deg_si8"] == [2476.5, None]
