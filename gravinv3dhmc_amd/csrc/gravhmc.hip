@@ -234,7 +234,7 @@ int gh_shift_invariant_harmonic(const gh_ctx *c, int *on, int *n_freq, int64_t *
     const bool h = lonsym_one_row(c);
     if (on) *on = !h ? 0 : c->ls->harm ? 1 : 2;
     if (n_freq) *n_freq = h ? c->ls->nf : 0;
-    if (table_bytes) *table_bytes = h ? (int64_t)c->ls->nc * c->ls->na * (c->ls->harm ? c->ls->nf : c->ls->nfp) * 16 : 0;
+    if (table_bytes) *table_bytes = h ? (c->ls->harm ? (int64_t)c->ls->nc * c->ls->na * c->ls->nf : (int64_t)c->ls->witems * c->ls->na * c->ls->nfp) * 16 : 0;
     if (workgroups) *workgroups = h ? lonsym_grid(c) : 0;
     return GH_OK;
 }
@@ -1286,7 +1286,7 @@ static int kids_make(gh_ctx *c, int C, const double *x0s, const double *low, con
             k->ls->Xhat = nullptr;
             int rc = dalloc(k, &k->ls->Rhat, (size_t)k->ls->na * (size_t)k->ls->nfp);
             if (rc == GH_OK) rc = dalloc(k, &k->ls->Xhat, (size_t)k->ls->nc * (size_t)k->ls->nf);
-            if (rc == GH_OK) rc = dalloc(k, &k->ls->Dpart, (size_t)k->ls->wparts * (size_t)k->ls->na * (size_t)k->ls->nfp);
+            if (rc == GH_OK) rc = dalloc(k, &k->ls->Dpart, (size_t)k->ls->wparts * (k->ls->wmirror ? 2 : 1) * (size_t)k->ls->na * (size_t)k->ls->nfp);
             if (rc != GH_OK) return fail(c, rc, "gh_batch_init: %s", gh_last_error(k));
         }
         int rc = configure_mf(k);

@@ -18,6 +18,10 @@ struct LonSymHost {
     // the harmonic store as streaming passes over T^ (lonsymw.hip.h): grids beyond the register form's limits
     bool wide = false, direct_ok = false;
     int wfwd = 0;                          // variant of the forward product's kernel
+    // north-south mirror of the streamed form: one row of T^ per pair of mirrored cell rows (lonsymw.hip.h)
+    bool wmirror = false;
+    int witems = 0;
+    int *item_c = nullptr, *item_c2 = nullptr, *amir = nullptr;
     int nfp = 0, wbreak = 0;               // pitch of a row of T^ / R^ / D^ in the streamed form (complex entries)
     int wgrid = 0, wparts = 0, wrows = 0;  // workgroups of the sweep; parts of the forward product, cell rows per part
     ghk::d2 *Xhat = nullptr;
@@ -316,26 +320,74 @@ static int lonsym_build(gh_ctx *c)
     if (!h.harm && wide_can && (env_int("GRAVHMC_LONSYM_HARMONIC", 1) != 0 || force_wide || !h.direct_ok)) {
         // (rows of T^ start on 128-byte lines: a wave's 1 KB request then touches 8 of them, not 9)
         h.nfp = (h.nf + 7) / 8 * 8;
+        // North-south mirror: a grid symmetric about the equator (cell rows and observation classes come in mirrored pairs)
+        // has K(row c, class a) = K(mirror row, mirror class): ONE row of T^ per pair, every entry read serves both rows
+        // -- half the table, half the bytes per step.  GRAVHMC_LW_MIRROR=0: off.
+        std::vector<int> itc, itc2, amirv((size_t)na, -1);
+        h.wmirror = false;
+        if (env_int("GRAVHMC_LW_MIRROR", 1) != 0) {
+            auto near = [](double x, double y) { return std::fabs(x - y) <= 1e-9 * std::max(1.0, std::max(std::fabs(x), std::fabs(y))); };
+            bool ok = true;
+            for (int64_t a = 0; a < na && ok; ++a) {
+                for (int64_t b2 = 0; b2 < na; ++b2)
+                    if (near(cl_lat[(size_t)b2], -cl_lat[(size_t)a]) && near(cl_h[(size_t)b2], cl_h[(size_t)a])) {
+                        amirv[(size_t)a] = (int)b2;
+                        break;
+                    }
+                ok = amirv[(size_t)a] >= 0;
+            }
+            for (int64_t a = 0; a < na && ok; ++a) ok = amirv[(size_t)amirv[(size_t)a]] == (int)a;
+            std::vector<int> rmir((size_t)nc, -1);
+            for (int64_t cc = 0; cc < nc && ok; ++cc) {
+                const double *q = &sb[(size_t)cc * 6];
+                for (int64_t c2 = 0; c2 < nc; ++c2) {
+                    const double *r2 = &sb[(size_t)c2 * 6];
+                    if (near(r2[2], -q[3]) && near(r2[3], -q[2]) && near(r2[4], q[4]) && near(r2[5], q[5])) {
+                        rmir[(size_t)cc] = (int)c2;
+                        break;
+                    }
+                }
+                ok = rmir[(size_t)cc] >= 0;
+            }
+            for (int64_t cc = 0; cc < nc && ok; ++cc) ok = rmir[(size_t)rmir[(size_t)cc]] == (int)cc;
+            if (ok) {
+                for (int64_t cc = 0; cc < nc; ++cc) {
+                    const int m2 = rmir[(size_t)cc];
+                    if (m2 < cc) continue;  // (listed with its partner)
+                    itc.push_back((int)cc);
+                    itc2.push_back(m2 == cc ? -1 : m2);
+                }
+                h.wmirror = true;
+            }
+        }
+        h.witems = h.wmirror ? (int)itc.size() : (int)nc;
+        const int64_t ni = h.witems;
         // (GRAVHMC_LW_LDS_PAD: extra LDS per workgroup in KB -- a diagnostic that lowers the workgroups per CU)
         h.wlds = lonsymw_lds_doubles((int)n, h.nf) * sizeof(double) + (size_t)env_int("GRAVHMC_LW_LDS_PAD", 0) * 1024;
         HIPCHK(c, allow_dynamic_lds(reinterpret_cast<const void *>(lonsymw_sweep_fn(h.nf)), h.wlds));
-        h.wgrid = (int)std::min<int64_t>(nc, (int64_t)c->cus * 8);
-        // parts of the forward product: ~8 waves per SIMD over the chip, at least 8 cell rows per part
+        h.wgrid = (int)std::min<int64_t>(ni, (int64_t)c->cus * 8);
+        // parts of the forward product: ~8 waves per SIMD over the chip, at least 8 rows of T^ per part
         const int64_t waves_row = ((int64_t)na * h.nfp + 63) / 64;
-        int64_t parts = std::max<int64_t>(1, ((int64_t)c->cus * env_int("GRAVHMC_LW_WAVES_PER_CU", 64) + waves_row - 1) / waves_row);
-        parts = std::min<int64_t>(parts, std::max<int64_t>(1, nc / 8));
+        int64_t parts = std::max<int64_t>(1, ((int64_t)c->cus * env_int("GRAVHMC_LW_WAVES_PER_CU", 32) + waves_row - 1) / waves_row);
+        parts = std::min<int64_t>(parts, std::max<int64_t>(1, ni / 8));
         parts = std::min<int64_t>(parts, 64);
-        h.wrows = (int)((nc + parts - 1) / parts);
-        h.wparts = (int)((nc + h.wrows - 1) / h.wrows);
+        h.wrows = (int)((ni + parts - 1) / parts);
+        h.wparts = (int)((ni + h.wrows - 1) / h.wrows);
         h.wfwd = env_int("GRAVHMC_LW_FWD", 0);
         h.wbreak = env_int("GRAVHMC_LW_BREAK", 0);  // (diagnostic: phases of the sweep switched off -- wrong results, timing only)
         TRY(dalloc(c, &h.tw, (size_t)n, false));
-        TRY(dalloc(c, &h.That, (size_t)nc * (size_t)na * (size_t)h.nfp, false));
+        TRY(dalloc(c, &h.That, (size_t)ni * (size_t)na * (size_t)h.nfp, false));
         TRY(dalloc(c, &h.Rhat, (size_t)na * (size_t)h.nfp));
         TRY(dalloc(c, &h.Xhat, (size_t)nc * (size_t)h.nf));
-        TRY(dalloc(c, &h.Dpart, (size_t)h.wparts * (size_t)na * (size_t)h.nfp));
+        TRY(dalloc(c, &h.Dpart, (size_t)h.wparts * (h.wmirror ? 2 : 1) * (size_t)na * (size_t)h.nfp));
+        if (h.wmirror) {
+            TRY(up(&h.item_c, itc));
+            TRY(up(&h.item_c2, itc2));
+            TRY(up(&h.amir, amirv));
+        }
         lonsymh_twiddle_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>((int)n, h.tw);
-        lonsymh_table_kernel<<<dim3((unsigned)(nc * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That, h.nfp);
+        lonsymh_table_kernel<<<dim3((unsigned)(ni * na)), dim3(64), 0, c->stream>>>(h.T, h.ldT, (int)n, h.nf, (int)na, h.tw, h.That, h.nfp,
+                                                                                     h.wmirror ? h.item_c : nullptr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         h.wide = true;
@@ -355,6 +407,11 @@ static LonWideGeom lonsymw_geom(const gh_ctx *c)
     g.nc = h.nc;
     g.nfp = h.nfp;
     g.brk = h.wbreak;
+    g.nitems = h.witems;
+    g.planes = h.wmirror ? 2 : 1;
+    g.item_c = h.wmirror ? h.item_c : nullptr;
+    g.item_c2 = h.wmirror ? h.item_c2 : nullptr;
+    g.amir = h.wmirror ? h.amir : nullptr;
     g.parts = h.wparts;
     g.rows_per_part = h.wrows;
     g.That = h.That;

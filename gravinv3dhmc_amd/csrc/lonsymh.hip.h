@@ -51,12 +51,13 @@ static inline size_t lonsymh_lds_doubles(int n, int nf, int na, int rw)
 
 // T^[c][a][f] = sum_delta T[c][a][delta] e^{-2 pi i f delta / n}: one block per (c, a) row of the table
 // (nfp: pitch of a row of T^ in complex entries, >= nf; the entries past nf are written as zeros)
+// (rowmap: row c of T^ comes from row rowmap[c] of T, or nullptr: from row c)
 __global__ void __launch_bounds__(64) lonsymh_table_kernel(const double *T, int64_t ldT, int n, int nf, int na, const d2 *tw, d2 *That,
-                                                           int nfp)
+                                                           int nfp, const int *rowmap = nullptr)
 {
     __shared__ double row[1024];
     const int c = blockIdx.x / na, a = blockIdx.x - c * na;
-    const double *src = T + (int64_t)c * ldT + (int64_t)a * n;
+    const double *src = T + (int64_t)(rowmap ? rowmap[c] : c) * ldT + (int64_t)a * n;
     for (int e = threadIdx.x; e < n; e += 64) row[e] = src[e];
     __syncthreads();
     for (int f = threadIdx.x; f < nf; f += 64) {

@@ -34,6 +34,12 @@ struct LonWideGeom {
     const int *slot_x;       // na * n: the slot's entry in xptr, or -1
     const int *xptr, *xobs;
     int64_t N;
+    // North-south mirror (grids symmetric about the equator: K of (cell row c, class a) = K of (mirror row, mirror class)):
+    // T^ holds ONE row per pair of mirrored cell rows -- item p stands for the rows item_c[p] and item_c2[p] (-1: the row
+    // is its own mirror) -- and every entry read serves both.  nitems rows in That; planes = 2 planes of D^ partials
+    // (the second one lands on the mirrored class).  item_c == nullptr: no mirror, item p = cell row p.
+    int nitems, planes;
+    const int *item_c, *item_c2, *amir;
 };
 
 constexpr int LW_THREADS = 256;
@@ -42,7 +48,7 @@ constexpr int LW_NP = (LW_NMAX / 2 + 1 + LW_THREADS - 1) / LW_THREADS;  // pairs
 
 static inline size_t lonsymw_lds_doubles(int n, int nf)
 {
-    return 2 * (size_t)n + 8 * (size_t)nf + 2 * (size_t)nf + 2 * (size_t)nf + 16;
+    return 2 * (size_t)n + 16 * (size_t)nf + 4 * (size_t)nf + 2 * (size_t)nf + 16;
 }
 
 // The two transforms of a cell row from the pairs of longitudes (m, n - m), m = 0 .. n / 2 (half the terms: the
@@ -143,145 +149,191 @@ __device__ __forceinline__ void lonsymw_sweep_body(const LonWideGeom &g, const S
     const int n = g.n, nf = g.nf, nfp = g.nfp, na = g.na;
     const int mode = a.mode;
     d2 *tws = reinterpret_cast<d2 *>(smem);                   // n
-    d2 *Gp = tws + n;                                         // 4 x nf: partial S^ of the waves' classes
-    d2 *Gh = Gp + 4 * nf;                                     // nf
-    d2 *XE = Gh + nf;                                         // nf: (even, odd) parts of xs of the pairs (m, n - m)
+    d2 *Gp = tws + n;                                         // 2 x 4 x nf: partial S^ of the waves' classes, both rows of the item
+    d2 *Gh = Gp + 8 * nf;                                     // 2 x nf
+    d2 *XE = Gh + 2 * nf;                                     // nf: (even, odd) parts of xs of the pairs (m, n - m)
     double *red = reinterpret_cast<double *>(XE + nf);
     for (int e = tid; e < n; e += LW_THREADS) tws[e] = g.tw[e];
     double pp = 0.0;
-    for (int c = blockIdx.x; c < g.nc; c += gridDim.x) {
-        // the operands of the row's updates: requested in front of the stream of T^.  Thread <-> pairs of longitudes
-        // m = tid, tid + 256, ...: item 0 = longitude m, item 1 = longitude n - m (none for m = 0 and 2 m = n)
+    for (int p = blockIdx.x; p < g.nitems; p += gridDim.x) {
+        const int c1 = g.item_c ? g.item_c[p] : p, c2 = g.item_c ? g.item_c2[p] : -1;
+        // the operands of a row's updates.  Thread <-> pairs of longitudes m = tid, tid + 256, ...: item 0 = longitude m,
+        // item 1 = longitude n - m (none for m = 0 and 2 m = n).  The first row's are requested in front of the stream of T^.
         double u_w[NP][2], u_x[NP][2], u_g[NP][2], u_p[NP][2], u_pn[NP][2], u_hi[NP][2], u_lo[NP][2];
+        auto fetch = [&](int c) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int m = tid + q * LW_THREADS;
+            for (int q = 0; q < NP; ++q) {
+                const int m = tid + q * LW_THREADS;
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const int k = w == 0 ? m : n - m;
-                u_w[q][w] = 1.0;
-                u_x[q][w] = u_g[q][w] = u_p[q][w] = u_pn[q][w] = u_hi[q][w] = u_lo[q][w] = 0.0;
-                if (m < nf && (w == 0 || (m > 0 && 2 * m != n))) {
-                    const int64_t j = (int64_t)c * n + k;
-                    u_w[q][w] = wm ? wm[j] : 1.0;
-                    u_x[q][w] = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
-                    if (mode & SW_ADJ) {
-                        u_g[q][w] = a.greg ? a.greg[j] : 0.0;
-                        if (mode & (SW_PFIN | SW_UPD)) u_p[q][w] = a.p_in[j];
-                        if (mode & SW_SPEC) u_pn[q][w] = a.pn_in[j];
-                        if (mode & SW_UPD) {
-                            u_hi[q][w] = a.high[j];
-                            u_lo[q][w] = a.low[j];
+                for (int w = 0; w < 2; ++w) {
+                    const int k = w == 0 ? m : n - m;
+                    u_w[q][w] = 1.0;
+                    u_x[q][w] = u_g[q][w] = u_p[q][w] = u_pn[q][w] = u_hi[q][w] = u_lo[q][w] = 0.0;
+                    if (m < nf && (w == 0 || (m > 0 && 2 * m != n))) {
+                        const int64_t j = (int64_t)c * n + k;
+                        u_w[q][w] = wm ? wm[j] : 1.0;
+                        u_x[q][w] = (mode & (SW_UPD | SW_FWD)) ? a.x_in[j] : 0.0;
+                        if (mode & SW_ADJ) {
+                            u_g[q][w] = a.greg ? a.greg[j] : 0.0;
+                            if (mode & (SW_PFIN | SW_UPD)) u_p[q][w] = a.p_in[j];
+                            if (mode & SW_SPEC) u_pn[q][w] = a.pn_in[j];
+                            if (mode & SW_UPD) {
+                                u_hi[q][w] = a.high[j];
+                                u_lo[q][w] = a.low[j];
+                            }
                         }
                     }
                 }
             }
-        }
-        __syncthreads();  // tws in place; the previous row is done with Gp / Gh / XE
+        };
+        fetch(c1);
+        __syncthreads();  // tws in place; the previous item is done with Gp / Gh / XE
         if (mode & SW_ADJ) {
-            // S^[f] = sum_a conj(T^[a][f]) R^[a][f]: wave wv takes the classes wv, wv + 4, ..., eight of them in flight
-            const d2 *Tg = g.That + (int64_t)c * na * nfp;
+            // S^[f] = sum_a conj(T^[a][f]) R^[a][f] (and, for the mirrored row, R^ of the mirrored class): wave wv takes the
+            // classes wv, wv + 4, ...; eight requests of T^ in flight per wave (four when the entry serves two rows)
+            const d2 *Tg = g.That + (int64_t)p * na * nfp;
             for (int f0 = 0; f0 < nf; f0 += 64) {
                 const int f = f0 + lane;
                 const bool fv = f < nf;
                 const int fc = fv ? f : nf - 1;
-                d2 acc = d2{0.0, 0.0};
+                d2 acc = d2{0.0, 0.0}, acc2 = d2{0.0, 0.0};
                 int aa = wv;
                 if (!(g.brk & 1)) {
-                    for (; aa + 28 < na; aa += 32) {
-                        d2 t[8], rr[8];
+                    if (c2 < 0) {
+                        for (; aa + 28 < na; aa += 32) {
+                            d2 t[8], rr[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            t[u] = __builtin_nontemporal_load(&Tg[(int64_t)(aa + 4 * u) * nfp + fc]);
-                            rr[u] = g.Rhat[(int64_t)(aa + 4 * u) * nfp + fc];
-                        }
+                            for (int u = 0; u < 8; ++u) {
+                                t[u] = __builtin_nontemporal_load(&Tg[(int64_t)(aa + 4 * u) * nfp + fc]);
+                                rr[u] = g.Rhat[(int64_t)(aa + 4 * u) * nfp + fc];
+                            }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            acc.x += t[u].x * rr[u].x + t[u].y * rr[u].y;
-                            acc.y += t[u].x * rr[u].y - t[u].y * rr[u].x;
+                            for (int u = 0; u < 8; ++u) {
+                                acc.x += t[u].x * rr[u].x + t[u].y * rr[u].y;
+                                acc.y += t[u].x * rr[u].y - t[u].y * rr[u].x;
+                            }
                         }
-                    }
-                    for (; aa < na; aa += 4) {
-                        const d2 t = __builtin_nontemporal_load(&Tg[(int64_t)aa * nfp + fc]), rr = g.Rhat[(int64_t)aa * nfp + fc];
-                        acc.x += t.x * rr.x + t.y * rr.y;
-                        acc.y += t.x * rr.y - t.y * rr.x;
+                        for (; aa < na; aa += 4) {
+                            const d2 t = __builtin_nontemporal_load(&Tg[(int64_t)aa * nfp + fc]), rr = g.Rhat[(int64_t)aa * nfp + fc];
+                            acc.x += t.x * rr.x + t.y * rr.y;
+                            acc.y += t.x * rr.y - t.y * rr.x;
+                        }
+                    } else {
+                        for (; aa + 12 < na; aa += 16) {
+                            d2 t[4], rr[4], r2[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int ac = aa + 4 * u;
+                                t[u] = __builtin_nontemporal_load(&Tg[(int64_t)ac * nfp + fc]);
+                                rr[u] = g.Rhat[(int64_t)ac * nfp + fc];
+                                r2[u] = g.Rhat[(int64_t)g.amir[ac] * nfp + fc];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc.x += t[u].x * rr[u].x + t[u].y * rr[u].y;
+                                acc.y += t[u].x * rr[u].y - t[u].y * rr[u].x;
+                                acc2.x += t[u].x * r2[u].x + t[u].y * r2[u].y;
+                                acc2.y += t[u].x * r2[u].y - t[u].y * r2[u].x;
+                            }
+                        }
+                        for (; aa < na; aa += 4) {
+                            const d2 t = __builtin_nontemporal_load(&Tg[(int64_t)aa * nfp + fc]), rr = g.Rhat[(int64_t)aa * nfp + fc],
+                                     r2 = g.Rhat[(int64_t)g.amir[aa] * nfp + fc];
+                            acc.x += t.x * rr.x + t.y * rr.y;
+                            acc.y += t.x * rr.y - t.y * rr.x;
+                            acc2.x += t.x * r2.x + t.y * r2.y;
+                            acc2.y += t.x * r2.y - t.y * r2.x;
+                        }
                     }
                 }
-                if (fv) Gp[wv * nf + f] = acc;
+                if (fv) {
+                    Gp[wv * nf + f] = acc;
+                    Gp[(4 + wv) * nf + f] = acc2;
+                }
             }
             __syncthreads();
-            for (int f = tid; f < nf; f += LW_THREADS) {
-                d2 s = Gp[f];
+            for (int e = tid; e < 2 * nf; e += LW_THREADS) {
+                const int r = e >= nf ? 1 : 0, f = e - r * nf;
+                d2 s = Gp[(4 * r) * nf + f];
 #pragma unroll
                 for (int q = 1; q < 4; ++q) {
-                    s.x += Gp[q * nf + f].x;
-                    s.y += Gp[q * nf + f].y;
+                    s.x += Gp[(4 * r + q) * nf + f].x;
+                    s.y += Gp[(4 * r + q) * nf + f].y;
                 }
                 // weight of the frequency in the inverse transform of a real sequence
                 const double wf = (f == 0 || (2 * f == n)) ? 1.0 : 2.0;
-                Gh[f] = d2{s.x * wf, s.y * wf};
+                Gh[e] = d2{s.x * wf, s.y * wf};
             }
             __syncthreads();
         }
-        // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}), gradient, update (hmc.py:114-152)
+        for (int r = 0; r < 2; ++r) {
+            const int c = r == 0 ? c1 : c2;
+            if (c < 0) break;  // (uniform over the workgroup)
+            if (r == 1) {
+                __syncthreads();  // the first row's transform is done with XE
+                fetch(c);
+            }
+            const d2 *Ghr = Gh + r * nf;
+            // s[k] = (1 / n) sum_f w_f Re(S^[f] e^{+2 pi i f k / n}), gradient, update (hmc.py:114-152)
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int m = tid + q * LW_THREADS;
-            if (m < nf) {
-                double E = 0.0, O = 0.0;
-                if (mode & SW_ADJ) {
-                    if (g.brk & 2) {
-                        E = Gh[m].x;
-                        O = Gh[m].y;
-                    } else {
-                        lw_idft_pair(Gh, tws, nf, m, n, E, O);
-                    }
-                }
-                double xe = 0.0, xo = 0.0;
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    if (w == 1 && (m == 0 || 2 * m == n)) continue;
-                    const int k = w == 0 ? m : n - m;
-                    const int64_t j = (int64_t)c * n + k;
-                    const double iwj = (u_w[q][w] != 0.0) ? 1.0 / u_w[q][w] : 1.0;
-                    double xj = u_x[q][w];
+            for (int q = 0; q < NP; ++q) {
+                const int m = tid + q * LW_THREADS;
+                if (m < nf) {
+                    double E = 0.0, O = 0.0;
                     if (mode & SW_ADJ) {
-                        const double s = w == 0 ? E - O : E + O;
-                        const double t = (s / (double)n) * iwj;
-                        const double grad = 2.0 * t + u_g[q][w];
-                        if (mode & SW_GOUT) a.g_out[j] = grad;
-                        if (mode & SW_PFIN) {
-                            const double pf = u_p[q][w] - a.c_p * grad;
-                            pp += pf * pf;
-                            if (!(mode & SW_SPEC)) a.p_out[j] = pf;
-                        }
-                        if (mode & SW_UPD) {
-                            const double psrc = (mode & SW_SPEC) ? u_pn[q][w] : u_p[q][w];
-                            double pj = psrc - a.c_u * grad;
-                            xj = xj + a.dt * pj;
-                            if (xj > u_hi[q][w]) {
-                                xj = u_hi[q][w];
-                                pj = -pj;
-                            } else if (xj < u_lo[q][w]) {
-                                xj = u_lo[q][w];
-                                pj = -pj;
-                            }
-                            a.p_out[j] = pj;
-                            a.x_out[j] = xj;
+                        if (g.brk & 2) {
+                            E = Ghr[m].x;
+                            O = Ghr[m].y;
+                        } else {
+                            lw_idft_pair(Ghr, tws, nf, m, n, E, O);
                         }
                     }
-                    const double xsj = xj * iwj;
-                    xe += xsj;
-                    xo += w == 0 ? xsj : -xsj;
+                    double xe = 0.0, xo = 0.0;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        if (w == 1 && (m == 0 || 2 * m == n)) continue;
+                        const int k = w == 0 ? m : n - m;
+                        const int64_t j = (int64_t)c * n + k;
+                        const double iwj = (u_w[q][w] != 0.0) ? 1.0 / u_w[q][w] : 1.0;
+                        double xj = u_x[q][w];
+                        if (mode & SW_ADJ) {
+                            const double s = w == 0 ? E - O : E + O;
+                            const double t = (s / (double)n) * iwj;
+                            const double grad = 2.0 * t + u_g[q][w];
+                            if (mode & SW_GOUT) a.g_out[j] = grad;
+                            if (mode & SW_PFIN) {
+                                const double pf = u_p[q][w] - a.c_p * grad;
+                                pp += pf * pf;
+                                if (!(mode & SW_SPEC)) a.p_out[j] = pf;
+                            }
+                            if (mode & SW_UPD) {
+                                const double psrc = (mode & SW_SPEC) ? u_pn[q][w] : u_p[q][w];
+                                double pj = psrc - a.c_u * grad;
+                                xj = xj + a.dt * pj;
+                                if (xj > u_hi[q][w]) {
+                                    xj = u_hi[q][w];
+                                    pj = -pj;
+                                } else if (xj < u_lo[q][w]) {
+                                    xj = u_lo[q][w];
+                                    pj = -pj;
+                                }
+                                a.p_out[j] = pj;
+                                a.x_out[j] = xj;
+                            }
+                        }
+                        const double xsj = xj * iwj;
+                        xe += xsj;
+                        xo += w == 0 ? xsj : -xsj;
+                    }
+                    if (m == 0 || 2 * m == n) xo = 0.0;
+                    if (mode & SW_FWD) XE[m] = d2{xe, xo};
                 }
-                if (m == 0 || 2 * m == n) xo = 0.0;
-                if (mode & SW_FWD) XE[m] = d2{xe, xo};
             }
-        }
-        if (mode & SW_FWD) {
-            __syncthreads();
-            for (int f = tid; f < nf; f += LW_THREADS)
-                g.Xhat[(int64_t)c * nf + f] = (g.brk & 4) ? XE[f] : lw_dft_pairs(XE, tws, nf, f, n);
+            if (mode & SW_FWD) {
+                __syncthreads();
+                for (int f = tid; f < nf; f += LW_THREADS)
+                    g.Xhat[(int64_t)c * nf + f] = (g.brk & 4) ? XE[f] : lw_dft_pairs(XE, tws, nf, f, n);
+            }
         }
     }
     if (mode & SW_PFIN) {
@@ -297,8 +349,9 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_sweep_kernel(LonWideGeom g
     lonsymw_sweep_body<NP>(g, a, wm);
 }
 
-// D^ partial of the cell rows [part * rows_per_part, ...): thread e = a * nfp + f (one complex of a row of T^).
-// UN rows in flight per thread; NT: non-temporal loads of T^.
+// D^ partial of the items [part * rows_per_part, ...): thread e = a * nfp + f (one complex of a row of T^); an entry of a
+// mirrored pair of cell rows feeds two accumulators (plane 0: class a from the row itself, plane 1: the mirrored class from
+// the mirrored row).  UN rows in flight per thread; NT: non-temporal loads of T^.
 template <int UN, bool NT>
 __global__ void __launch_bounds__(LW_THREADS) lonsymw_forward_kernel(LonWideGeom g)
 {
@@ -309,30 +362,43 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_forward_kernel(LonWideGeom
     const int64_t ec = ev ? e : tot - 1;
     const int fp = (int)(ec % g.nfp);
     const int f = fp < nf ? fp : nf - 1;  // (the pad of a row of T^ is zero: any X^ will do)
-    const int c0 = blockIdx.y * g.rows_per_part;
-    const int c1 = (c0 + g.rows_per_part < g.nc) ? c0 + g.rows_per_part : g.nc;
-    d2 acc = d2{0.0, 0.0};
-    int c = c0;
-    for (; c + UN <= c1; c += UN) {
-        d2 t[UN], x[UN];
+    const int p0 = blockIdx.y * g.rows_per_part;
+    const int p1 = (p0 + g.rows_per_part < g.nitems) ? p0 + g.rows_per_part : g.nitems;
+    const bool mir = g.item_c != nullptr;
+    d2 acc = d2{0.0, 0.0}, acc2 = d2{0.0, 0.0};
+    int p = p0;
+    for (; p + UN <= p1; p += UN) {
+        d2 t[UN], x[UN], x2[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const d2 *src = &g.That[(int64_t)(c + u) * tot + ec];
+            const d2 *src = &g.That[(int64_t)(p + u) * tot + ec];
             t[u] = NT ? __builtin_nontemporal_load(src) : *src;
-            x[u] = g.Xhat[(int64_t)(c + u) * nf + f];
+            const int c1 = mir ? g.item_c[p + u] : p + u, c2 = mir ? g.item_c2[p + u] : -1;
+            x[u] = g.Xhat[(int64_t)c1 * nf + f];
+            x2[u] = c2 >= 0 ? g.Xhat[(int64_t)c2 * nf + f] : d2{0.0, 0.0};
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             acc.x += t[u].x * x[u].x - t[u].y * x[u].y;
             acc.y += t[u].x * x[u].y + t[u].y * x[u].x;
+            acc2.x += t[u].x * x2[u].x - t[u].y * x2[u].y;
+            acc2.y += t[u].x * x2[u].y + t[u].y * x2[u].x;
         }
     }
-    for (; c < c1; ++c) {
-        const d2 t = g.That[(int64_t)c * tot + ec], x = g.Xhat[(int64_t)c * nf + f];
+    for (; p < p1; ++p) {
+        const d2 t = g.That[(int64_t)p * tot + ec];
+        const int c1 = mir ? g.item_c[p] : p, c2 = mir ? g.item_c2[p] : -1;
+        const d2 x = g.Xhat[(int64_t)c1 * nf + f];
+        const d2 x2 = c2 >= 0 ? g.Xhat[(int64_t)c2 * nf + f] : d2{0.0, 0.0};
         acc.x += t.x * x.x - t.y * x.y;
         acc.y += t.x * x.y + t.y * x.x;
+        acc2.x += t.x * x2.x - t.y * x2.y;
+        acc2.y += t.x * x2.y + t.y * x2.x;
     }
-    if (ev) g.Dpart[(int64_t)blockIdx.y * tot + e] = acc;
+    if (ev) {
+        g.Dpart[((int64_t)blockIdx.y * g.planes) * tot + e] = acc;
+        if (g.planes > 1) g.Dpart[((int64_t)blockIdx.y * g.planes + 1) * tot + e] = acc2;
+    }
 }
 
 // block = class a: sum of the parts, inverse transform, scatter to the class's observations (slab row 0), the
@@ -351,9 +417,18 @@ __global__ void __launch_bounds__(LW_THREADS) lonsymw_post_kernel(LonWideGeom g,
         d2 s = d2{0.0, 0.0};
         const d2 *src = g.Dpart + (int64_t)a * g.nfp + f;
         for (int p = 0; p < g.parts; ++p) {
-            const d2 v = src[(int64_t)p * tot];
+            const d2 v = src[(int64_t)p * g.planes * tot];
             s.x += v.x;
             s.y += v.y;
+        }
+        if (g.planes > 1) {
+            // what the mirrored cell rows contribute to this class was accumulated at the mirrored class's entries
+            const d2 *src2 = g.Dpart + tot + (int64_t)g.amir[a] * g.nfp + f;
+            for (int p = 0; p < g.parts; ++p) {
+                const d2 v = src2[(int64_t)p * g.planes * tot];
+                s.x += v.x;
+                s.y += v.y;
+            }
         }
         const double wf = (f == 0 || (2 * f == n)) ? 1.0 : 2.0;
         Dh[f] = d2{s.x * wf, s.y * wf};

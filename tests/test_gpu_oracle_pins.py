@@ -576,7 +576,7 @@ def test_one_degree_global_grid_on_the_streamed_harmonic_store(G, orc):
     t.build_G()
     info, hinfo = t.shift_invariant_info(), t.shift_invariant_harmonic()
     assert info["n_lon"] == 360 and info["n_classes"] == 181 and info["n_rows"] == 1800
-    assert hinfo["form"] == "streamed" and hinfo["n_freq"] == 181 and hinfo["table_bytes"] == 1800 * 181 * 184 * 16      # (rows of T^ padded to 128-byte lines)
+    assert hinfo["form"] == "streamed" and hinfo["n_freq"] == 181 and hinfo["table_bytes"] == 900 * 181 * 184 * 16   # (rows of T^ padded to 128-byte lines; ONE row per north-south mirrored pair of cell rows)
     cols = np.r_[0, 359, 324000 + 180, M - 1]
     Kc = orc.tess_gz_kernel(lon, lat, h, bounds[cols])
     e_col = 0.0
