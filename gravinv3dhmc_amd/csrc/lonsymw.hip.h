@@ -14,7 +14,8 @@
 //   lonsymw_post_kernel     sum of the parts, inverse transform per class, scatter to the class's observations
 // T^ is read twice per leapfrog step (the forward product needs every row's X^, which needs every row's update): 2 x 0.94 GB
 // on the 1-degree grid = 0.24 ms at 8 TB/s, where the dense kernel of that grid (65 341 x 648 000 doubles = 339 GB) fits no
-// GPU.  No inter-workgroup waits: four plain launches per step.  Sums in a fixed order: reproducible bit for bit.
+// GPU.  On a grid symmetric about the equator ONE row of T^ stands for a north-south mirrored pair of cell rows (the
+// struct's item_* fields): half the table, every entry read serves both rows.  No inter-workgroup waits: four plain launches per step.  Sums in a fixed order: reproducible bit for bit.
 // Reference arithmetic: gravmag/_tesseroid_numba.py:207-222 (cos(lon - lon')), gravmag/tesseroid.py:189-232,
 // inversion/potential.py:698,708, inversion/hmc.py:114-152; geometry family example/global/SetPMTS.txt.
 #pragma once

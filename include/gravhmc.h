@@ -33,7 +33,7 @@
  *     resident kernel instead of running in lock-step), GRAVHMC_LONSYM_HARMONIC=0 / GRAVHMC_LONSYM_FUSED=1 /
  *     GRAVHMC_LONSYM_RESIDENT=0 (shift-invariant store: direct correlations / one-launch epilogue / one launch per
  *     phase instead of the persistent launch), GRAVHMC_LONSYM_WIDE=0 / 2 (the streamed harmonic form of large grids:
- *     off / also where the register form applies), GRAVHMC_LONSYM_W, GRAVHMC_LW_WAVES_PER_CU, GRAVHMC_LW_FWD,
+ *     off / also where the register form applies), GRAVHMC_LONSYM_W, GRAVHMC_LW_WAVES_PER_CU, GRAVHMC_LW_FWD, GRAVHMC_LW_MIRROR=0 (one row of T^ per cell row),
  *     GRAVHMC_DWT_LDS / _MAX (one-launch wavelet transform);
  *   arithmetic of an entry (within the path's stated 1e-10, ~1e-14 measured): GRAVHMC_MF_EXACT -- the
  *     DEFAULT of gh_set_matrix_free_exact only; that call overrides it;
@@ -136,7 +136,9 @@ int gh_shift_invariant_info(const gh_ctx *ctx, int *n_lon, int *n_classes, int *
  * and a forward transform inside the cell row's workgroup.  Grids beyond that form's limits (up to 1024 longitudes,
  * any number of classes -- a 1-degree global grid: 360 longitudes, 181 classes, 1800 cell rows, T^ = 0.96 GB where
  * the dense kernel would be 339 GB) run the same arithmetic as four streaming launches per step that read T^ twice
- * (csrc/lonsymw.hip.h; GRAVHMC_LONSYM_WIDE=0 off, =2 everywhere).  on: 0 = direct correlations, 1 = the register
+ * (csrc/lonsymw.hip.h; GRAVHMC_LONSYM_WIDE=0 off, =2 everywhere); on a grid symmetric about the equator that form
+ * keeps one row of T^ per north-south mirrored pair of cell rows and lets every entry read serve both (half the bytes;
+ * mirrored entries of the reference's kernel agree to rounding, within the stated 1e-10; GRAVHMC_LW_MIRROR=0: off).  on: 0 = direct correlations, 1 = the register
  * form, 2 = the streamed form; frequencies n / 2 + 1, bytes of T^, workgroups
  * of the pass.  gh_batch_* on a shift-invariant context (BASELINE configs[3]: 8 chains) runs every chain as a
  * light context of its own -- stream, chain state, work buffers -- on the shared tables, one host thread per
