@@ -223,7 +223,8 @@ def _global_model(G, dlon, dlat, dr, obs_h, nlat_obs_step=None):
 
 @pytest.mark.parametrize("case", ["coarse_odd_sizes", "c4_full_size", "c4_full_size_direct_correlations",
                                   "c4_full_size_one_launch_epilogue", "coarse_odd_sizes_streamed", "c4_full_size_streamed",
-                                  "lon180_streamed", "classes91_streamed", "odd45", "odd45_streamed"])
+                                  "lon180_streamed", "classes91_streamed", "odd45", "odd45_streamed",
+                                  "selfmirror_streamed", "c4_full_size_streamed_no_mirror"])
 def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
     """gh_set_shift_invariant: K[i, (c, k)] = T[c][class_i][(m_i - k) mod n] for regular spherical grids
     (example/global/main_global.py:25-28; BASELINE configs[3]'s geometry) against the dense engine on the
@@ -240,13 +241,20 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
         monkeypatch.setenv("GRAVHMC_LONSYM_HARMONIC", "0")
     if case.endswith("one_launch_epilogue"):
         monkeypatch.setenv("GRAVHMC_LONSYM_FUSED", "1")
-    if case in ("coarse_odd_sizes_streamed", "c4_full_size_streamed", "odd45_streamed"):
+    if case in ("coarse_odd_sizes_streamed", "c4_full_size_streamed", "odd45_streamed", "selfmirror_streamed",
+                "c4_full_size_streamed_no_mirror"):
         monkeypatch.setenv("GRAVHMC_LONSYM_WIDE", "2")
+    if case.endswith("_no_mirror"):      # (one row of T^ per cell row although the grid is symmetric about the equator)
+        monkeypatch.setenv("GRAVHMC_LW_MIRROR", "0")
     if case.startswith("coarse_odd_sizes"):
         mesh, lon, lat, h = _global_model(G, 10.0, 15.0, -1000000, 30000.0)
         h[::3] = 45000.0
         perm = rng.permutation(lon.size)
         lon, lat, h = lon[perm], lat[perm], h[perm]
+        tol = 1e-10
+    elif case == "selfmirror_streamed":
+        # nine latitude bands of 20 degrees: the band on the equator is its own north-south mirror image
+        mesh, lon, lat, h = _global_model(G, 10.0, 20.0, -1000000, 30000.0)
         tol = 1e-10
     elif case.startswith("odd45"):
         mesh, lon, lat, h = _global_model(G, 8.0, 15.0, -1000000, 30000.0)     # an ODD number of longitudes: no pair (n / 2, n / 2)
@@ -275,7 +283,13 @@ def test_shift_invariant_store_matches_the_stored_kernel(G, monkeypatch, case):
     info = t.shift_invariant_info()
     assert info["n_lon"] == mesh.shape[2] and info["n_rows"] == mesh.shape[0] * mesh.shape[1]
     form = t.shift_invariant_harmonic()["form"]
-    assert form == ("streamed" if case.endswith("_streamed") else None if case.endswith("direct_correlations") else "registers"), form
+    assert form == ("streamed" if "_streamed" in case else None if case.endswith("direct_correlations") else "registers"), form
+    if form == "streamed":
+        # the north-south mirror halves the table on grids symmetric about the equator (one row per pair, the equator's alone)
+        nrows, full = info["n_rows"], t.shift_invariant_harmonic()["table_bytes"]
+        per_row = info["n_classes"] * ((mesh.shape[2] // 2 + 1 + 7) // 8 * 8) * 16
+        expect = {"selfmirror_streamed": mesh.shape[0] * 5, "c4_full_size_streamed_no_mirror": nrows}
+        assert full == per_row * expect.get(case, nrows // 2), (case, full, per_row, nrows)
     assert info["table_bytes"] < N * M * 8 / 10
     dtrue = d.forward(rho)
     e_fwd = relmax(t.forward(rho), dtrue)
